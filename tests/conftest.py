@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def load_golden():
+    return golden
+
+
+def order_insensitive_topk_match(ref_vals, ref_idx, got_vals, got_idx, tol):
+    """Top-k parity rule: values within tol; ids exact wherever neighbouring reference scores are
+    more than 2*tol apart, and the same id *set* inside a tolerance-tie group.  Returns number of permuted slots."""
+    ref_vals = np.asarray(ref_vals, dtype=np.float64)
+    got_vals = np.asarray(got_vals, dtype=np.float64)
+    assert ref_vals.shape == got_vals.shape
+    np.testing.assert_allclose(got_vals, ref_vals, rtol=tol, atol=tol)
+    permuted = 0
+    for r in range(ref_vals.shape[0]):
+        if np.array_equal(ref_idx[r], got_idx[r]):
+            continue
+        k = ref_vals.shape[1]
+        j = 0
+        while j < k:
+            e = j
+            while e + 1 < k and abs(ref_vals[r, e] - ref_vals[r, e + 1]) <= 2 * tol * (1 + abs(ref_vals[r, e])):
+                e += 1
+            a, b = ref_idx[r, j:e + 1], got_idx[r, j:e + 1]
+            if e == k - 1:
+                # last group may be cut by k: ids in `got` must score within tol of the boundary — checked by values
+                common = len(set(a.tolist()) & set(b.tolist()))
+                permuted += (e - j + 1) - common
+            else:
+                assert set(a.tolist()) == set(b.tolist()), (r, j, e, a, b)
+                permuted += int((a != b).sum())
+            j = e + 1
+    return permuted
