@@ -1,0 +1,82 @@
+"""ctypes binding of libgdr_hip.so (include/gdr_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.  PyTorch is used only
+for device memory and streams (tensor.data_ptr(), torch.cuda.current_stream()).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgdr_hip.so")
+
+GDR_OK, GDR_EINVAL, GDR_ENOSPC, GDR_EHIP = 0, -1, -2, -3
+EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL, EPI_BIAS_GELU = range(7)
+
+
+class GdrError(RuntimeError):
+    pass
+
+
+class GdrT5Dims(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("d_model", C.c_int32), ("d_kv", C.c_int32), ("d_ff", C.c_int32),
+                ("num_heads", C.c_int32), ("num_layers", C.c_int32), ("rel_buckets", C.c_int32),
+                ("rel_max_distance", C.c_int32), ("eps", C.c_float)]
+
+
+class GdrT5EncLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln_attn", "wqkv", "wo", "ln_ff", "wi", "wo_ff")]
+
+
+class GdrT5EncoderWeights(C.Structure):
+    _fields_ = [("dims", GdrT5Dims), ("embed", C.c_void_p), ("rel_bias", C.c_void_p), ("final_ln", C.c_void_p),
+                ("layers", C.POINTER(GdrT5EncLayer))]
+
+
+# name -> (restype, argtypes); every symbol declared in include/gdr_hip.h
+_vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+SIGNATURES = {
+    "gdr_last_error": (C.c_char_p, []),
+    "gdr_abi_version": (_i, []),
+    "gdr_linear_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    "gdr_t5_encoder_workspace_bytes": (_sz, [C.POINTER(GdrT5Dims), _i, _i]),
+    "gdr_t5_encoder_forward": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "gdr_sim_topk_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
+    "gdr_sim_topk": (_i, [_vp, _i, _vp, _i64, _i, _i, C.c_int32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gdr_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "gdr_rerank_topk": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "gdr_t5_relative_bucket_table": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GdrError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C gdr_amd/csrc`). gdr_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)            # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().gdr_last_error().decode("utf-8", "replace")
+        raise GdrError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

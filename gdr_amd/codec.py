@@ -1,0 +1,157 @@
+"""Host logic around the kernels: docid codec, cluster index (CSR), retrieval metrics, res1 TSV.
+
+Mirrors the reference's names and argument meaning so call sites read the same:
+  encode_single_newid / decode_token   GDR_model/main_models.py:297-346
+  dec_2d                               GDR_model/main_utils.py:70-76
+  recall / MRR100                      GDR_model/main_metrics.py:194-267
+  id_mapping (cluster -> doc ids)      GDR_model/main_models.py:874-889  -> flat CSR here
+Both call styles are accepted: the reference's `f(args, x)` with an argparse namespace, or `f(x, kary=..)`.
+"""
+import numpy as np
+import torch
+
+
+def _split_args(a, b, **kw):
+    """(args, x) or (x, **kw) -> (x, kary, output_vocab_size, position)."""
+    if b is not None and hasattr(a, "kary"):
+        return b, a.kary, getattr(a, "output_vocab_size", a.kary or 10), getattr(a, "position", 1)
+    return a, kw.get("kary", 30), kw.get("output_vocab_size", kw.get("kary", 30) or 10), kw.get("position", 1)
+
+
+def encode_single_newid(a, b=None, **kw):
+    """'3-17-5' -> [5, 49, 67, 1]: token = i*kary + c_i + 2, EOS(1) appended (main_models.py:297-319)."""
+    seq, kary, _v, position = _split_args(a, b, **kw)
+    out = []
+    if kary:
+        for i, c in enumerate(seq.split("-")):
+            out.append(i * kary + int(c) + 2 if position else int(c) + 2)
+    else:
+        for i, c in enumerate(seq):
+            out.append(i * 10 + int(c) + 2 if position else int(c) + 2)   # hard-coded vocab 10 as in the reference
+    return out + [1]
+
+
+def decode_token(a, b=None, **kw):
+    """2-D int array of generated ids -> docid strings (main_models.py:322-346): drop START, cut at the first
+    EOS, subtract arange*V+2.  A row without EOS is decoded whole, START included, as the reference does."""
+    seqs, kary, V, position = _split_args(a, b, **kw)
+    if torch.is_tensor(seqs):
+        seqs = seqs.cpu().numpy()
+    result = []
+    for seq in np.asarray(seqs):
+        lst = seq.tolist()
+        if 1 in lst:
+            seq = seq[1:lst.index(1)]
+        offset = np.arange(len(seq)) * V + 2 if position else 2
+        res = seq - offset
+        result.append(("-" if kary else "").join(str(c) for c in res))
+    return result
+
+
+def dec_2d(dec, size):
+    return [dec[i:i + size] for i in range(0, len(dec), size)]
+
+
+class ClusterIndex:
+    """cluster-id string -> member doc ids, as flat CSR (offsets int32[n+1], members int32[N]).
+    Replaces the reference's pickled dict `id_mapping` (main_models.py:874-889)."""
+
+    def __init__(self, names, offsets, members):
+        self.names = list(names)
+        self.offsets = np.asarray(offsets, dtype=np.int32)
+        self.members = np.asarray(members, dtype=np.int32)
+        self.lookup = {n: i for i, n in enumerate(self.names)}
+
+    @staticmethod
+    def from_id_mapping(id_mapping):
+        names = list(id_mapping)
+        lens = [len(id_mapping[n]) for n in names]
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        members = np.concatenate([np.asarray(id_mapping[n], dtype=np.int32) for n in names]) if names else np.zeros(0, np.int32)
+        return ClusterIndex(names, offsets, members)
+
+    def __getitem__(self, name):
+        c = self.lookup.get(name)
+        if c is None:
+            return []                       # unknown / undecodable cluster: empty segment
+        return self.members[self.offsets[c]:self.offsets[c + 1]].tolist()
+
+    def candidates(self, dec):
+        """dec: list[B] of list[R] cluster strings -> (cand_offsets int32[B*R+1], cand_ids int32[total], max per query)
+        in the order validation_step_i builds them (main_models.py:1441-1443)."""
+        offs, ids, max_cand = [0], [], 0
+        for row in dec:
+            start = offs[-1]
+            for name in row:
+                c = self.lookup.get(name)
+                if c is not None:
+                    ids.append(self.members[self.offsets[c]:self.offsets[c + 1]])
+                    offs.append(offs[-1] + int(self.offsets[c + 1] - self.offsets[c]))
+                else:
+                    offs.append(offs[-1])
+            max_cand = max(max_cand, offs[-1] - start)
+        ids = np.concatenate(ids) if ids else np.zeros(0, np.int32)
+        if ids.size == 0:
+            ids = np.zeros(1, np.int32)
+        return torch.from_numpy(np.asarray(offs, dtype=np.int32)), torch.from_numpy(ids.astype(np.int32)), max_cand
+
+
+# ------------------------------------------------------------------------------------------ metrics / res1 TSV
+def write_res1(path, rows):
+    """rows: (query, pred_csv, gt_csv, rank) — the reference's res1 TSV (main.py:244-247)."""
+    with open(path, "w") as f:
+        for q, pred, gt, rank in rows:
+            f.write(f"{q}\t{pred}\t{gt}\t{rank}\n")
+
+
+def _read_res1(path):
+    with open(path, "r") as f:
+        for line in f.readlines():
+            yield line[:-1].split("\t")
+
+
+def recall(args=None, rows=None, recall_num=None, verbose=True):
+    """hit@k averaged over queries (main_metrics.py:194-250, non-trivia and trivia branches are identical).
+    Accepts the reference call `recall(args)` (reads args.res1_save_path / args.recall_num) or rows directly.
+    Returns the last recall value like the reference; `recall.last` holds {k: value}."""
+    if rows is None:
+        rows = list(_read_res1(args.res1_save_path))
+        recall_num = args.recall_num
+    q_gt, q_pred, prev_q = {}, {}, ""
+    for query, pred, gt, _rank in rows:
+        if query != prev_q:
+            q_pred[query] = pred.split(",")
+            prev_q = query
+        if query in q_gt:
+            if len(q_gt[query]) <= 100:
+                q_gt[query].add(gt)
+        else:
+            q_gt[query] = set(gt.split(","))
+    out, recall_avg = {}, 0.0
+    for i in recall_num:
+        total = 0
+        for q in q_pred:
+            top = q_pred[q][:int(i)]
+            total += 1 if any(p in top for p in q_gt[q]) else 0
+        recall_avg = total / len(q_pred)
+        out[int(i)] = recall_avg
+        if verbose:
+            print(f"recall@{i}: {recall_avg}")
+    recall.last = out
+    return recall_avg
+
+
+def MRR100(args=None, rows=None, verbose=True):
+    """main_metrics.py:253-267."""
+    if rows is None:
+        rows = list(_read_res1(args.res1_save_path))
+    tot, n = 0.0, 0
+    for _q, pred, gt, _rank in rows:
+        pl = pred.split(",")
+        if gt in pl:
+            tot += 1 / (pl.index(gt) + 1)
+        n += 1
+    mrr = tot / n
+    if verbose:
+        print("MRR100: {}".format(mrr))
+    return mrr

@@ -1,0 +1,53 @@
+// Shared host-side helpers for libgdr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/gdr_hip.h"
+
+namespace gdr {
+
+void set_error(const char* fmt, ...);
+
+#define GDR_CHECK_ARG(cond, ...)                \
+  do {                                          \
+    if (!(cond)) {                              \
+      gdr::set_error(__VA_ARGS__);              \
+      return GDR_EINVAL;                        \
+    }                                           \
+  } while (0)
+
+#define GDR_CHECK_LAUNCH(what)                                                   \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      gdr::set_error("%s: %s", what, hipGetErrorString(e__));                    \
+      return GDR_EHIP;                                                           \
+    }                                                                            \
+  } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- internal launchers shared between translation units -------------------------------------
+// Similarity epilogue parameters of the GEMM core (see gemm_f32.hip / sim_topk.hip).
+struct SimEpilogue {
+  float* cand_val;        // [B][cap]
+  int32_t* cand_idx;      // [B][cap]
+  int32_t* cand_cnt;      // [B]
+  const float* thr;       // [B]
+  int32_t* status;        // [1] or null
+  int32_t cap;
+  int32_t tile_stride;    // sample tiles are the m-tiles with index % tile_stride == 0
+  int32_t mode;           // 1: sample tiles, store every score; 2: other tiles, append score >= thr
+};
+
+int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
+                      int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
+                      hipStream_t stream);
+// docs D[N,d] take the GEMM's row role, queries Q[B,d] the column role: a lane owns one query.
+int launch_sim_gemm(const float* D, int64_t N, const float* Q, int B, int d, const SimEpilogue& ep,
+                    hipStream_t stream);
+
+}  // namespace gdr

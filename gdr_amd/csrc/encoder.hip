@@ -1,0 +1,97 @@
+// T5 encoder forward on gfx950 — replaces `T5Stack.forward` of the reference
+// (GDR_model/transformers/modeling_t5.py:685-821, blocks :498-584, eval mode: dropout = identity).
+//
+// Per layer (pre-norm, T5 v1.0):   h += o(attn(qkv(rms(h))))    ;    h += wo(relu(wi(rms(h))))
+//   rms           layers.hip  rmsnorm_kernel                                  (modeling_t5.py:164-171)
+//   qkv / o / wi / wo   gemm_f32.hip on v_mfma_f32_32x32x2_f32; q,k,v fused into one [3*inner,d] GEMM,
+//                 residual add and ReLU fused into the GEMM epilogues        (:360-364,:413,:182-185,:199)
+//   attn          layers.hip  attention_kernel: QKᵀ (no 1/sqrt(d)) + bucketed relative bias + pad mask
+//                 (1-m)*-1e9 + fp32 softmax + PV, one workgroup per (query, head)   (:384-413, :290-314)
+// The position bias is never materialised as a [B,H,L,L] tensor: the kernel re-derives it from the
+// [buckets,H] table (layer 0's, shared by all layers as in :790-795).
+#include "layers.h"
+
+namespace gdr {
+
+struct EncWs {
+  size_t off_h, off_nx, off_qkv, off_ctx, off_ff, total;
+};
+
+static EncWs enc_ws(const GdrT5Dims& dm, int64_t M) {
+  EncWs w{};
+  const size_t inner = (size_t)dm.num_heads * dm.d_kv;
+  size_t o = 0;
+  w.off_h = o, o += align_up((size_t)M * dm.d_model * 4, 256);
+  w.off_nx = o, o += align_up((size_t)M * dm.d_model * 4, 256);
+  w.off_qkv = o, o += align_up((size_t)M * 3 * inner * 4, 256);
+  w.off_ctx = o, o += align_up((size_t)M * inner * 4, 256);
+  w.off_ff = o, o += align_up((size_t)M * dm.d_ff * 4, 256);
+  w.total = o;
+  return w;
+}
+
+}  // namespace gdr
+
+extern "C" size_t gdr_t5_encoder_workspace_bytes(const GdrT5Dims* dims, int B, int L) {
+  if (!dims || B <= 0 || L <= 0) return 0;
+  return gdr::enc_ws(*dims, (int64_t)B * L).total;
+}
+
+extern "C" int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B,
+                                      int L, float* out_hidden, float* out_pooled, void* workspace,
+                                      size_t workspace_bytes, void* stream_) {
+  using namespace gdr;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GDR_CHECK_ARG(w && ids && out_hidden && workspace, "t5_encoder: null pointer");
+  const GdrT5Dims& dm = w->dims;
+  GDR_CHECK_ARG(B > 0 && L > 0 && L <= 128, "t5_encoder: B=%d L=%d (L must be in [1,128])", B, L);
+  GDR_CHECK_ARG(dm.d_model % 4 == 0 && dm.d_kv % 4 == 0 && dm.d_ff % 4 == 0, "t5_encoder: dims must be multiples of 4");
+  GDR_CHECK_ARG(w->embed && w->rel_bias && w->final_ln && w->layers, "t5_encoder: null weight pointer");
+  const int64_t M = (int64_t)B * L;
+  const EncWs ws = enc_ws(dm, M);
+  if (workspace_bytes < ws.total) {
+    set_error("t5_encoder: workspace %zu < required %zu", workspace_bytes, ws.total);
+    return GDR_ENOSPC;
+  }
+  GDR_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "t5_encoder: workspace must be 256-byte aligned");
+  char* base = static_cast<char*>(workspace);
+  float* h = reinterpret_cast<float*>(base + ws.off_h);
+  float* nx = reinterpret_cast<float*>(base + ws.off_nx);
+  float* qkv = reinterpret_cast<float*>(base + ws.off_qkv);
+  float* ctx = reinterpret_cast<float*>(base + ws.off_ctx);
+  float* ff = reinterpret_cast<float*>(base + ws.off_ff);
+  const int d = dm.d_model, H = dm.num_heads, dk = dm.d_kv, inner = H * dk;
+
+  int rc = launch_embed(w->embed, ids, M, d, dm.vocab_size, h, stream);  // modeling_t5.py:725
+  if (rc) return rc;
+
+  AttnArgs at{};
+  at.q = qkv, at.k = qkv + inner, at.v = qkv + 2 * inner, at.out = ctx;
+  at.ldq = at.ldk = at.ldv = 3 * inner, at.ldo = inner;
+  at.q_bstride = at.k_bstride = at.o_bstride = L;
+  at.B = B, at.H = H, at.dk = dk, at.Lq = L, at.Lk = L;
+  at.q_pos0 = 0, at.scale = 1.0f;
+  at.rel_bias = w->rel_bias, at.bidirectional = 1, at.num_buckets = dm.rel_buckets;
+  at.lut = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
+  at.key_mask = mask, at.mask_bstride = L, at.causal = 0, at.causal_neg_inf = 0;
+
+  for (int i = 0; i < dm.num_layers; ++i) {
+    const GdrT5EncLayer& ly = w->layers[i];
+    GDR_CHECK_ARG(ly.ln_attn && ly.wqkv && ly.wo && ly.ln_ff && ly.wi && ly.wo_ff, "t5_encoder: layer %d null weight", i);
+    if ((rc = launch_rmsnorm(h, ly.ln_attn, nx, M, d, dm.eps, nullptr, 1, stream))) return rc;
+    if ((rc = launch_linear_f32(nx, d, ly.wqkv, d, qkv, 3 * inner, M, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0,
+                                stream)))
+      return rc;
+    if ((rc = launch_attention(at, stream))) return rc;
+    if ((rc = launch_linear_f32(ctx, inner, ly.wo, inner, h, d, M, d, inner, GDR_EPI_RESIDUAL, nullptr, h, d, stream)))
+      return rc;
+    if ((rc = launch_rmsnorm(h, ly.ln_ff, nx, M, d, dm.eps, nullptr, 1, stream))) return rc;
+    if ((rc = launch_linear_f32(nx, d, ly.wi, d, ff, dm.d_ff, M, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0, stream)))
+      return rc;
+    if ((rc = launch_linear_f32(ff, dm.d_ff, ly.wo_ff, dm.d_ff, h, d, M, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, h, d,
+                                stream)))
+      return rc;
+  }
+  // final_layer_norm (:803) + CLS pool h[:,0] (main_models.py:102-109)
+  return launch_rmsnorm(h, w->final_ln, out_hidden, M, d, dm.eps, out_pooled, L, stream);
+}

@@ -1,0 +1,303 @@
+// fp32 "NT" GEMM core for gfx950:  C[M,N] = epilogue(A[M,K] · W[N,K]^T), both operands K-contiguous.
+//
+// One kernel serves every dense contraction on GDR's inference path (reference call sites in
+// include/gdr_hip.h): the T5 / adaptor linears and — with the docs in the row role and the queries in
+// the column role — the corpus similarity Q·Dᵀ, whose epilogue filters scores against a per-query
+// threshold instead of storing them (sim_topk.hip).
+//
+// CDNA4 mapping
+//   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles/SIMD): 256-thread workgroup = 4 waves as 2x2, each
+//     wave owns a 64x64 output patch = 2x2 MFMA tiles (64 accumulator VGPRs), block tile 128x128, BK 32.
+//   * operands staged global -> VGPR (16 B/lane, full 128-B lines) -> LDS, double-buffered, one barrier
+//     per K-step; LDS rows padded to 36 floats so the ds_read_b128 fragment reads are conflict-free
+//     (row*36 mod 64 hits 16 distinct 4-bank slots for any 16-lane read group).
+//   * one ds_read_b128 feeds 4 MFMAs: the k index inside a K-chunk of 8 is permuted (lane half h reads
+//     k = 8j+4h..+3, MFMA s pairs element s of both halves) — the same permutation on both operands,
+//     so the sum over k is unchanged.
+//   * 1-D grid with the bijective XCD remap: the blocks that share a row panel (A tile) run on one XCD
+//     back to back, so the panel is fetched from HBM once and re-read from that XCD's L2.
+#include "common.h"
+
+namespace gdr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_STRIDE = BK + 4;  // floats; 144 B rows, 16-B aligned
+constexpr int GEMM_THREADS = 256;
+
+struct GemmArgs {
+  const float* A;
+  const float* W;
+  float* C;
+  const float* bias;
+  const float* residual;
+  int64_t lda, ldw, ldc, ldr;
+  int64_t M;
+  int N, K;
+  int tiles_n;
+  SimEpilogue sim;
+};
+
+enum { EPI_SIM_SAMPLE = 100, EPI_SIM_FILTER = 101 };
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDS_STRIDE + 2 * BN * LDS_STRIDE];
+  float* const As = smem;
+  float* const Bs = smem + 2 * BM * LDS_STRIDE;
+
+  // ---- block -> tile (XCD-aware, bijective for any grid size) ----
+  unsigned bid = blockIdx.x;
+  {
+    const unsigned nblk = gridDim.x, q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  int64_t mt = bid / (unsigned)g.tiles_n;
+  const int nt = bid % (unsigned)g.tiles_n;
+  int64_t slot_base = 0;
+  if (EPI == EPI_SIM_SAMPLE) {
+    slot_base = mt * BM;
+    mt = mt * g.sim.tile_stride;
+  } else if (EPI == EPI_SIM_FILTER) {
+    const int s1 = g.sim.tile_stride - 1;
+    mt = (mt / s1) * g.sim.tile_stride + 1 + (mt % s1);
+  }
+  const int64_t m0 = mt * BM;
+  const int n0 = nt * BN;
+
+  const int tid = threadIdx.x;
+  // ---- staging map: 8 lanes cover one 128-B row segment, 32 rows per pass, 4 passes ----
+  const int lrow = tid >> 3;
+  const int lcol = (tid & 7) * 4;
+  const float* a_src[4];
+  const float* w_src[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    int64_t ra = m0 + lrow + 32 * p;
+    ra = ra < g.M ? ra : g.M - 1;  // clamp: rows past the edge are computed and discarded
+    int rw = n0 + lrow + 32 * p;
+    rw = rw < g.N ? rw : g.N - 1;
+    a_src[p] = g.A + ra * g.lda + lcol;
+    w_src[p] = g.W + (int64_t)rw * g.ldw + lcol;
+  }
+  const int st_off = lrow * LDS_STRIDE + lcol;
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int a_rd = (wm * 64 + l31) * LDS_STRIDE + 4 * h;
+  const int b_rd = (wn * 64 + l31) * LDS_STRIDE + 4 * h;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (g.K + BK - 1) / BK;
+  float4 ra[4], rb[4];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto gload = [&](int kt) {
+    const int k = kt * BK + lcol;
+    const bool ok = k < g.K;  // K % 4 == 0: a float4 is entirely inside or outside
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      ra[p] = ok ? *reinterpret_cast<const float4*>(a_src[p] + kt * BK) : zero4;
+      rb[p] = ok ? *reinterpret_cast<const float4*>(w_src[p] + kt * BK) : zero4;
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* a = As + buf * BM * LDS_STRIDE + st_off;
+    float* b = Bs + buf * BN * LDS_STRIDE + st_off;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<float4*>(a + 32 * p * LDS_STRIDE) = ra[p];
+      *reinterpret_cast<float4*>(b + 32 * p * LDS_STRIDE) = rb[p];
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const float* a = As + buf * BM * LDS_STRIDE + a_rd;
+    const float* b = Bs + buf * BN * LDS_STRIDE + b_rd;
+#pragma unroll
+    for (int jj = 0; jj < BK / 8; ++jj) {
+      const float4 a0 = *reinterpret_cast<const float4*>(a + 8 * jj);
+      const float4 a1 = *reinterpret_cast<const float4*>(a + 32 * LDS_STRIDE + 8 * jj);
+      const float4 b0 = *reinterpret_cast<const float4*>(b + 8 * jj);
+      const float4 b1 = *reinterpret_cast<const float4*>(b + 32 * LDS_STRIDE + 8 * jj);
+      const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+      const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  Accumulator map (32x32 MFMA): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  if (EPI == EPI_SIM_SAMPLE || EPI == EPI_SIM_FILTER) {
+    // rows = docs, cols = queries: this lane owns query n for each of its two column tiles
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 64 + ni * 32 + l31;
+      if (n >= g.N) continue;
+      float* cv = g.sim.cand_val + (int64_t)n * g.sim.cap;
+      int32_t* ci = g.sim.cand_idx + (int64_t)n * g.sim.cap;
+      if (EPI == EPI_SIM_SAMPLE) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int roff = wm * 64 + mi * 32 + 8 * q4 + 4 * h;  // 4 consecutive docs
+            const int64_t m = m0 + roff;
+            float4 v;
+            int4 id;
+            v.x = m + 0 < g.M ? acc[mi][ni][4 * q4 + 0] : -INFINITY;
+            v.y = m + 1 < g.M ? acc[mi][ni][4 * q4 + 1] : -INFINITY;
+            v.z = m + 2 < g.M ? acc[mi][ni][4 * q4 + 2] : -INFINITY;
+            v.w = m + 3 < g.M ? acc[mi][ni][4 * q4 + 3] : -INFINITY;
+            id.x = (int)m, id.y = (int)m + 1, id.z = (int)m + 2, id.w = (int)m + 3;
+            *reinterpret_cast<float4*>(cv + slot_base + roff) = v;
+            *reinterpret_cast<int4*>(ci + slot_base + roff) = id;
+          }
+        }
+      } else {
+        const float thr = g.sim.thr[n];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          float mx = acc[mi][ni][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[mi][ni][r]);
+          if (mx >= thr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[mi][ni][r];
+              const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+              if (v >= thr && m < g.M) {
+                const int pos = atomicAdd(g.sim.cand_cnt + n, 1);
+                if (pos < g.sim.cap) {
+                  cv[pos] = v;
+                  ci[pos] = (int)m;
+                } else if (g.sim.status) {
+                  *g.sim.status = 1;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + wn * 64 + ni * 32 + l31;
+    if (n >= g.N) continue;
+    float bia = 0.f;
+    if (EPI == GDR_EPI_BIAS || EPI == GDR_EPI_BIAS_RELU || EPI == GDR_EPI_BIAS_RESIDUAL || EPI == GDR_EPI_BIAS_GELU)
+      bia = g.bias[n];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= g.M) continue;
+        float v = acc[mi][ni][r];
+        if (EPI == GDR_EPI_BIAS || EPI == GDR_EPI_BIAS_RELU || EPI == GDR_EPI_BIAS_RESIDUAL ||
+            EPI == GDR_EPI_BIAS_GELU)
+          v += bia;
+        if (EPI == GDR_EPI_RESIDUAL || EPI == GDR_EPI_BIAS_RESIDUAL) v += g.residual[m * g.ldr + n];
+        if (EPI == GDR_EPI_RELU || EPI == GDR_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        if (EPI == GDR_EPI_BIAS_GELU) v = gelu_erf(v);
+        g.C[m * g.ldc + n] = v;
+      }
+    }
+  }
+}
+
+template <int EPI>
+static int launch(const GemmArgs& g, int64_t tiles_m, hipStream_t stream) {
+  const int64_t blocks = tiles_m * g.tiles_n;
+  if (blocks <= 0) return GDR_OK;
+  if (blocks > 0x7fffffffLL) {
+    set_error("gemm: grid too large (%lld blocks)", (long long)blocks);
+    return GDR_EINVAL;
+  }
+  hipLaunchKernelGGL(gemm_nt_f32_kernel<EPI>, dim3((unsigned)blocks), dim3(GEMM_THREADS), 0, stream, g);
+  GDR_CHECK_LAUNCH("gemm_nt_f32_kernel");
+  return GDR_OK;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
+                      int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
+                      hipStream_t stream) {
+  GDR_CHECK_ARG(A && W && C, "linear: null pointer");
+  GDR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  GDR_CHECK_ARG(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "linear: K, lda, ldw must be multiples of 4");
+  GDR_CHECK_ARG(lda >= K && ldw >= K && ldc >= N, "linear: leading dimension smaller than the row");
+  GDR_CHECK_ARG(aligned16(A) && aligned16(W), "linear: A and W must be 16-byte aligned");
+  const bool needs_bias = epilogue == GDR_EPI_BIAS || epilogue == GDR_EPI_BIAS_RELU ||
+                          epilogue == GDR_EPI_BIAS_RESIDUAL || epilogue == GDR_EPI_BIAS_GELU;
+  const bool needs_res = epilogue == GDR_EPI_RESIDUAL || epilogue == GDR_EPI_BIAS_RESIDUAL;
+  GDR_CHECK_ARG(!needs_bias || bias, "linear: epilogue %d needs bias", epilogue);
+  GDR_CHECK_ARG(!needs_res || (residual && ldr >= N), "linear: epilogue %d needs residual", epilogue);
+  if (M == 0) return GDR_OK;
+  GemmArgs g{};
+  g.A = A, g.W = W, g.C = C, g.bias = bias, g.residual = residual;
+  g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr;
+  g.M = M, g.N = N, g.K = K;
+  g.tiles_n = (N + BN - 1) / BN;
+  const int64_t tiles_m = (M + BM - 1) / BM;
+  switch (epilogue) {
+    case GDR_EPI_NONE: return launch<GDR_EPI_NONE>(g, tiles_m, stream);
+    case GDR_EPI_RESIDUAL: return launch<GDR_EPI_RESIDUAL>(g, tiles_m, stream);
+    case GDR_EPI_RELU: return launch<GDR_EPI_RELU>(g, tiles_m, stream);
+    case GDR_EPI_BIAS: return launch<GDR_EPI_BIAS>(g, tiles_m, stream);
+    case GDR_EPI_BIAS_RELU: return launch<GDR_EPI_BIAS_RELU>(g, tiles_m, stream);
+    case GDR_EPI_BIAS_RESIDUAL: return launch<GDR_EPI_BIAS_RESIDUAL>(g, tiles_m, stream);
+    case GDR_EPI_BIAS_GELU: return launch<GDR_EPI_BIAS_GELU>(g, tiles_m, stream);
+    default: set_error("linear: unknown epilogue %d", epilogue); return GDR_EINVAL;
+  }
+}
+
+int launch_sim_gemm(const float* D, int64_t N, const float* Q, int B, int d, const SimEpilogue& ep,
+                    hipStream_t stream) {
+  GemmArgs g{};
+  g.A = D, g.W = Q, g.lda = d, g.ldw = d;
+  g.M = N, g.N = B, g.K = d;
+  g.tiles_n = (B + BN - 1) / BN;
+  g.sim = ep;
+  const int64_t tiles_m = (N + BM - 1) / BM;
+  const int64_t n_sample_tiles = (tiles_m + ep.tile_stride - 1) / ep.tile_stride;
+  if (ep.mode == 1) return launch<EPI_SIM_SAMPLE>(g, n_sample_tiles, stream);
+  return launch<EPI_SIM_FILTER>(g, tiles_m - n_sample_tiles, stream);
+}
+
+}  // namespace gdr
+
+extern "C" int gdr_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
+                              int64_t M, int N, int K, int epilogue, const float* bias, const float* residual,
+                              int64_t ldr, void* stream) {
+  return gdr::launch_linear_f32(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, residual, ldr,
+                                static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,45 @@
+// Internal launchers of the non-GEMM layer kernels (layers.hip), shared by encoder.hip / decode.hip.
+#pragma once
+#include "common.h"
+
+namespace gdr {
+
+// T5 relative-position bucket of distance n = query_pos - key_pos >= 0 for n in [0,128); distances
+// >= 128 saturate to the last bucket (reference modeling_t5.py:242-288, max_distance hard-coded 128).
+struct BucketLut {
+  uint8_t v[128];
+};
+// nb = buckets per direction (num_buckets/2 when bidirectional, num_buckets otherwise).
+BucketLut make_bucket_lut(int nb, int max_distance);
+
+struct AttnArgs {
+  const float* q;  // row (b*q_bstride + i), head h at column h*dk
+  const float* k;  // row (b*k_bstride + j)
+  const float* v;
+  float* out;      // row (b*o_bstride + i), head h at column h*dk
+  int64_t ldq, ldk, ldv, ldo;          // row strides in floats
+  int64_t q_bstride, k_bstride, o_bstride;  // rows per batch entry
+  int B, H, dk, Lq, Lk;
+  int q_pos0;                  // absolute position of query row 0 (decode with cache)
+  float scale;                 // 1.0 for T5 (modeling_t5.py:384-386), hd^-0.5 for nn.MultiheadAttention
+  const float* rel_bias;       // [num_buckets, H] or null
+  int bidirectional, num_buckets;
+  BucketLut lut;
+  const int64_t* key_mask;     // int64 [B, Lk] (1 = attend) or null  -> adds (1-m)*-1e9
+  int64_t mask_bstride;        // elements between batch entries of key_mask
+  int causal;                  // key j allowed iff j <= q_pos0 + i  -> adds -1e9 otherwise (neg_inf: -inf)
+  int causal_neg_inf;          // nn.Transformer masks use -inf (modeling_t5.py:1622-1627)
+};
+int launch_attention(const AttnArgs& a, hipStream_t stream);
+
+int launch_embed(const float* table, const int64_t* ids, int64_t rows, int d, int vocab, float* out,
+                 hipStream_t stream);
+// y = x / sqrt(mean(x^2) + eps) * w     (T5LayerNorm, modeling_t5.py:164-171); optional second output
+// `pooled` receives rows r with r % pool_every == 0 (CLS pool h[:,0]) when non-null.
+int launch_rmsnorm(const float* x, const float* w, float* y, int64_t rows, int d, float eps, float* pooled,
+                   int pool_every, hipStream_t stream);
+// y = (x - mean) / sqrt(var + eps) * w + b   (torch.nn.LayerNorm; BERT / nn.TransformerDecoderLayer)
+int launch_layernorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int d, float eps,
+                     hipStream_t stream);
+
+}  // namespace gdr

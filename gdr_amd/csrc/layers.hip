@@ -1,0 +1,309 @@
+// Non-GEMM layer kernels for gfx950: embedding gather, T5 RMS norm, LayerNorm, and a fused attention
+// (QKᵀ + relative-position bias + pad/causal mask + fp32 softmax + PV in one pass, K/V staged in LDS).
+//
+// All of them are HBM/LDS-bound at GDR's sequence lengths (L <= 128, 40 typical): 16-byte coalesced
+// global accesses, wave64 shuffle reductions, no score matrix in HBM.
+#include <math.h>
+
+#include "layers.h"
+
+namespace gdr {
+
+BucketLut make_bucket_lut(int nb, int max_distance) {
+  // reference: transformers/modeling_t5.py:272-287 (float32 log, truncation, clamp); checked bit-exact
+  // against the reference for all distances < 128 in tests/test_host_logic.py.
+  BucketLut l;
+  const int max_exact = nb / 2;
+  for (int n = 0; n < 128; ++n) {
+    int b;
+    if (n < max_exact) {
+      b = n;
+    } else {
+      const float v = logf((float)n / (float)max_exact) / (float)log((double)max_distance / max_exact) *
+                      (float)(nb - max_exact);
+      b = max_exact + (int)v;
+      if (b > nb - 1) b = nb - 1;
+    }
+    l.v[n] = (uint8_t)b;
+  }
+  return l;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------ embed
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids,
+                                                    int64_t rows, int d4, int vocab, float* __restrict__ out) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  int64_t id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float4* src = reinterpret_cast<const float4*>(table) + id * d4;
+  float4* dst = reinterpret_cast<float4*>(out) + row * d4;
+  for (int c = threadIdx.x & 63; c < d4; c += 64) dst[c] = src[c];
+}
+
+int launch_embed(const float* table, const int64_t* ids, int64_t rows, int d, int vocab, float* out,
+                 hipStream_t stream) {
+  GDR_CHECK_ARG(d % 4 == 0, "embed: d %% 4 != 0");
+  if (rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, table, ids, rows, d / 4,
+                     vocab, out);
+  GDR_CHECK_LAUNCH("embed_kernel");
+  return GDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ norms
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      float* __restrict__ y, int64_t rows, int d4, float eps,
+                                                      float* __restrict__ pooled, int pool_every) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float4* xr = reinterpret_cast<const float4*>(x) + row * d4;
+  float ss = 0.f;
+  for (int c = lane; c < d4; c += 64) {
+    const float4 v = xr[c];
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float denom = sqrtf(ss / (float)(d4 * 4) + eps);
+  float4* yr = reinterpret_cast<float4*>(y) + row * d4;
+  float4* pr = (pooled && row % pool_every == 0) ? reinterpret_cast<float4*>(pooled) + (row / pool_every) * d4
+                                                  : nullptr;
+  const float4* wr = reinterpret_cast<const float4*>(w);
+  for (int c = lane; c < d4; c += 64) {
+    const float4 v = xr[c], g = wr[c];
+    float4 o;
+    o.x = g.x * (v.x / denom), o.y = g.y * (v.y / denom), o.z = g.z * (v.z / denom), o.w = g.w * (v.w / denom);
+    yr[c] = o;
+    if (pr) pr[c] = o;
+  }
+}
+
+int launch_rmsnorm(const float* x, const float* w, float* y, int64_t rows, int d, float eps, float* pooled,
+                   int pool_every, hipStream_t stream) {
+  GDR_CHECK_ARG(d % 4 == 0, "rmsnorm: d %% 4 != 0");
+  if (rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, y, rows, d / 4, eps,
+                     pooled, pool_every > 0 ? pool_every : 1);
+  GDR_CHECK_LAUNCH("rmsnorm_kernel");
+  return GDR_OK;
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y,
+                                                        int64_t rows, int d4, float eps) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float4* xr = reinterpret_cast<const float4*>(x) + row * d4;
+  const float inv_d = 1.0f / (float)(d4 * 4);
+  float s = 0.f;
+  for (int c = lane; c < d4; c += 64) {
+    const float4 v = xr[c];
+    s += v.x + v.y + v.z + v.w;
+  }
+  const float mean = wave_sum(s) * inv_d;
+  float ss = 0.f;
+  for (int c = lane; c < d4; c += 64) {
+    const float4 v = xr[c];
+    const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+    ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv_d + eps);
+  float4* yr = reinterpret_cast<float4*>(y) + row * d4;
+  const float4* wr = reinterpret_cast<const float4*>(w);
+  const float4* br = reinterpret_cast<const float4*>(b);
+  for (int c = lane; c < d4; c += 64) {
+    const float4 v = xr[c], g = wr[c], bb = br[c];
+    float4 o;
+    o.x = (v.x - mean) * rstd * g.x + bb.x, o.y = (v.y - mean) * rstd * g.y + bb.y;
+    o.z = (v.z - mean) * rstd * g.z + bb.z, o.w = (v.w - mean) * rstd * g.w + bb.w;
+    yr[c] = o;
+  }
+}
+
+int launch_layernorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int d, float eps,
+                     hipStream_t stream) {
+  GDR_CHECK_ARG(d % 4 == 0, "layernorm: d %% 4 != 0");
+  if (rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, b, y, rows, d / 4,
+                     eps);
+  GDR_CHECK_LAUNCH("layernorm_kernel");
+  return GDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ attention
+// One workgroup per (batch, head): K and V rows of that head are staged once in LDS (row stride dk+4 floats:
+// ≡ 4 mod 64 banks for dk = 64, so the per-lane ds_read_b128 of "my key's row" is conflict-free); each of
+// the 4 waves then walks query rows: lane j scores keys j and j+64, softmax by wave shuffles, PV with lane = d.
+__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int dk = a.dk, dks = dk + 4, c4 = dk >> 2;
+  const int Lk = a.Lk, Lkp = (Lk + 3) & ~3;
+  float* Ks = smem;
+  float* Vs = Ks + Lk * dks;
+  float* Qs = Vs + Lk * dks;   // [4][dk]
+  float* Ps = Qs + 4 * dk;     // [4][Lkp]
+  float* Bs = Ps + 4 * Lkp;    // [num_buckets]
+  const int tid = threadIdx.x;
+  for (int e = tid; e < Lk * c4; e += 256) {
+    const int j = e / c4, c = e - j * c4;
+    const int64_t rk = (int64_t)b * a.k_bstride + j;
+    *reinterpret_cast<float4*>(Ks + j * dks + 4 * c) =
+        *reinterpret_cast<const float4*>(a.k + rk * a.ldk + h * dk + 4 * c);
+    *reinterpret_cast<float4*>(Vs + j * dks + 4 * c) =
+        *reinterpret_cast<const float4*>(a.v + rk * a.ldv + h * dk + 4 * c);
+  }
+  if (a.rel_bias && tid < a.num_buckets) Bs[tid] = a.rel_bias[tid * a.H + h];
+  const int wave = tid >> 6, lane = tid & 63;
+  float* qs = Qs + wave * dk;
+  float* ps = Ps + wave * Lkp;
+  const int half = a.num_buckets >> 1;
+  const float masked = a.causal_neg_inf ? -INFINITY : -1e9f;
+  const int iters = (a.Lq + 3) >> 2;
+  for (int it = 0; it < iters; ++it) {
+    const int i = it * 4 + wave;
+    const bool active = i < a.Lq;
+    if (active) {
+      const float* qr = a.q + ((int64_t)b * a.q_bstride + i) * a.ldq + h * dk;
+      for (int d = lane; d < dk; d += 64) qs[d] = qr[d] * a.scale;
+    }
+    __syncthreads();  // K/V staged (first pass) and this wave's q row visible
+    float sc[2];
+    float mx = -INFINITY;
+    if (active) {
+      const int i_abs = a.q_pos0 + i;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int j = lane + 64 * t;
+        float s = -INFINITY;
+        if (j < Lk) {
+          float acc = 0.f;
+          const float* kr = Ks + j * dks;
+          for (int c = 0; c < c4; ++c) {
+            const float4 qq = *reinterpret_cast<const float4*>(qs + 4 * c);
+            const float4 kk = *reinterpret_cast<const float4*>(kr + 4 * c);
+            acc = fmaf(qq.x, kk.x, acc);
+            acc = fmaf(qq.y, kk.y, acc);
+            acc = fmaf(qq.z, kk.z, acc);
+            acc = fmaf(qq.w, kk.w, acc);
+          }
+          float add = 0.f;
+          if (a.rel_bias) {
+            int n = i_abs - j;  // = -(memory_position - context_position)
+            int bucket = 0;
+            if (a.bidirectional) {
+              if (n < 0) {
+                bucket = half;
+                n = -n;
+              }
+            } else if (n < 0) {
+              n = 0;
+            }
+            bucket += a.lut.v[n < 127 ? n : 127];
+            add = Bs[bucket];
+          }
+          bool allowed = true;
+          if (a.causal) allowed = j <= i_abs;
+          if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)b * a.mask_bstride + j] != 0);
+          if (!allowed) add += masked;
+          s = acc + add;
+        }
+        sc[t] = s;
+        mx = fmaxf(mx, s);
+      }
+      mx = wave_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int j = lane + 64 * t;
+        if (j < Lk) {
+          const float p = expf(sc[t] - mx);
+          ps[j] = p;
+          sum += p;
+        }
+      }
+      sum = wave_sum(sum);
+      sc[0] = sum;
+    }
+    __syncthreads();  // probabilities visible to the whole wave
+    if (active) {
+      const float inv = 1.0f / sc[0];
+      float* orow = a.out + ((int64_t)b * a.o_bstride + i) * a.ldo + h * dk;
+      for (int d = lane; d < dk; d += 64) {
+        float o = 0.f;
+        int j = 0;
+        for (; j + 4 <= Lk; j += 4) {
+          const float4 pp = *reinterpret_cast<const float4*>(ps + j);
+          o = fmaf(pp.x * inv, Vs[(j + 0) * dks + d], o);
+          o = fmaf(pp.y * inv, Vs[(j + 1) * dks + d], o);
+          o = fmaf(pp.z * inv, Vs[(j + 2) * dks + d], o);
+          o = fmaf(pp.w * inv, Vs[(j + 3) * dks + d], o);
+        }
+        for (; j < Lk; ++j) o = fmaf(ps[j] * inv, Vs[j * dks + d], o);
+        orow[d] = o;
+      }
+    }
+    __syncthreads();  // before the next row overwrites qs / ps
+  }
+}
+
+int launch_attention(const AttnArgs& a, hipStream_t stream) {
+  GDR_CHECK_ARG(a.dk % 4 == 0 && a.dk >= 4 && a.dk <= 256, "attention: dk=%d unsupported", a.dk);
+  GDR_CHECK_ARG(a.Lk >= 1 && a.Lk <= 128, "attention: Lk=%d must be in [1,128]", a.Lk);
+  GDR_CHECK_ARG(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0, "attention: row strides must be multiples of 4");
+  GDR_CHECK_ARG(!a.rel_bias || (a.num_buckets >= 2 && a.num_buckets <= 256), "attention: bad num_buckets");
+  if (a.B == 0 || a.Lq == 0) return GDR_OK;
+  const int dks = a.dk + 4, Lkp = (a.Lk + 3) & ~3;
+  const size_t lds = sizeof(float) * ((size_t)2 * a.Lk * dks + 4 * a.dk + 4 * Lkp + 256);
+  GDR_CHECK_ARG(lds <= 160 * 1024, "attention: Lk=%d dk=%d needs %zu B of LDS", a.Lk, a.dk, lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return GDR_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(a.B * a.H)), dim3(256), lds, stream, a);
+  GDR_CHECK_LAUNCH("attention_kernel");
+  return GDR_OK;
+}
+
+}  // namespace gdr
+
+extern "C" int gdr_t5_relative_bucket_table(int bidirectional, int num_buckets, int max_distance, int qlen, int klen,
+                                            int32_t* out_host) {
+  using namespace gdr;
+  GDR_CHECK_ARG(out_host && num_buckets >= 2 && num_buckets <= 256 && qlen > 0 && klen > 0, "bucket_table: bad args");
+  const int nb = bidirectional ? num_buckets / 2 : num_buckets;
+  const BucketLut lut = make_bucket_lut(nb, max_distance);
+  for (int i = 0; i < qlen; ++i)
+    for (int j = 0; j < klen; ++j) {
+      int n = i - j, bucket = 0;
+      if (bidirectional) {
+        if (n < 0) {
+          bucket = nb;
+          n = -n;
+        }
+      } else if (n < 0) {
+        n = 0;
+      }
+      out_host[i * klen + j] = bucket + lut.v[n < 127 ? n : 127];
+    }
+  return GDR_OK;
+}

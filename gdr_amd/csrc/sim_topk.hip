@@ -1,0 +1,306 @@
+// Fused corpus similarity + top-k for gfx950 (include/gdr_hip.h: gdr_sim_topk, gdr_topk_merge).
+//
+// Replaces `scores = q_reps @ p_reps.T` (reference GDR_model/dense.py:53-54, encoder.py:128-129)
+// followed by `scores.topk(k, largest=True, sorted=True)` (as at main_models.py:1625) without ever
+// writing the [B,N] score matrix:
+//
+//   1. SAMPLE   the GEMM core (gemm_f32.hip) runs over every `stride`-th 128-doc tile of the corpus and
+//               stores those scores into per-query candidate lists  cand[q][0 .. n_slots).
+//   2. THRESH   one workgroup per query radix-selects the k-th largest sample score thr[q].  The k-th
+//               largest over ANY subset of the docs is a lower bound of the k-th largest over all of
+//               them, so `score >= thr[q]` can never reject a true top-k doc (ties included).
+//   3. FILTER   the GEMM core runs over the remaining tiles; its epilogue compares the accumulators
+//               (a lane owns one query: docs sit in the row role) against thr and appends the few
+//               survivors (expected k*N/n_sample per query) with one returning atomic each.
+//   4. SELECT   one workgroup per query radix-selects the exact k largest 64-bit keys
+//               (orderable(score) << 32 | ~doc) — distinct keys, so ties resolve as "higher score, then
+//               lower doc id" — then bitonic-sorts them in LDS and writes values + ids.
+//
+// n_sample ≈ sqrt(k·N) balances list length against survivors.  Small corpora take steps 1, 2, 4 only.
+#include "common.h"
+
+namespace gdr {
+
+constexpr int TILE = 128;
+constexpr int SEL_THREADS = 256;
+
+struct SimPlan {
+  int64_t tiles_m;
+  int stride;          // sample tiles: index % stride == 0
+  int64_t n_sample_tiles;
+  int64_t n_slots;     // n_sample_tiles * TILE
+  int64_t cap;         // candidate list capacity per query (multiple of TILE)
+  size_t off_val, off_idx, off_cnt, off_thr, total;
+};
+
+static SimPlan make_plan(int B, int64_t N, int k) {
+  SimPlan p{};
+  p.tiles_m = (N + TILE - 1) / TILE;
+  double target = sqrt((double)k * (double)N);
+  if (target < k) target = k;
+  int64_t ts = (int64_t)((target + TILE - 1) / TILE);
+  if (ts < 1) ts = 1;
+  if (N <= 16384 || p.tiles_m < 4 * ts) {
+    p.stride = 1;
+  } else {
+    p.stride = (int)(p.tiles_m / ts);
+  }
+  p.n_sample_tiles = (p.tiles_m + p.stride - 1) / p.stride;
+  p.n_slots = p.n_sample_tiles * TILE;
+  if (p.stride == 1) {
+    p.cap = p.n_slots;
+  } else {
+    const double n_sample = (double)p.n_slots;
+    const double expect = (double)k * (double)N / n_sample;
+    p.cap = p.n_slots + (int64_t)(4.0 * expect) + 4096;
+    p.cap = (p.cap + TILE - 1) / TILE * TILE;
+  }
+  size_t o = 0;
+  p.off_val = o, o += align_up((size_t)B * p.cap * sizeof(float), 256);
+  p.off_idx = o, o += align_up((size_t)B * p.cap * sizeof(int32_t), 256);
+  p.off_cnt = o, o += align_up((size_t)B * sizeof(int32_t), 256);
+  p.off_thr = o, o += align_up((size_t)B * sizeof(float), 256);
+  p.total = o;
+  return p;
+}
+
+// ---- orderable keys --------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fkey(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// Given hist[256] (LDS) find the highest bin b with  sum(hist[b..255]) >= need.
+// Returns b and the count strictly above it through *above.  All 256 threads call it.
+__device__ __forceinline__ int find_bin(int* hist, int* scan, int need, int* above, int* res) {
+  const int t = threadIdx.x;
+  scan[t] = hist[t];
+  __syncthreads();
+#pragma unroll
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = (t + off < 256) ? scan[t + off] : 0;
+    __syncthreads();
+    scan[t] += v;
+    __syncthreads();
+  }
+  const int mine = scan[t];
+  const int next = (t + 1 < 256) ? scan[t + 1] : 0;
+  if (mine >= need && next < need) {
+    res[0] = t;
+    res[1] = next;
+  }
+  __syncthreads();
+  *above = res[1];
+  return res[0];
+}
+
+// ---- step 2: per-query threshold = k-th largest of the sample scores ----------------------------
+__global__ __launch_bounds__(SEL_THREADS) void sim_threshold_kernel(const float* __restrict__ cand_val, int64_t cap,
+                                                                    int n_slots, int k, float* thr,
+                                                                    int32_t* cand_cnt) {
+  __shared__ int hist[256];
+  __shared__ int scan[256];
+  __shared__ int res[2];
+  const int q = blockIdx.x;
+  const float* v = cand_val + (int64_t)q * cap;
+  uint32_t prefix = 0;
+  int need = k;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_slots; i += SEL_THREADS) {
+      const uint32_t key = fkey(v[i]);
+      const bool match = pass == 0 ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+      if (match) atomicAdd(&hist[(key >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    int above;
+    const int b = find_bin(hist, scan, need, &above, res);
+    need -= above;
+    prefix |= (uint32_t)b << shift;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    thr[q] = fkey_inv(prefix);
+    cand_cnt[q] = n_slots;  // survivors of the filter pass are appended behind the sample block
+  }
+}
+
+// ---- step 4 / merge: exact top-k of a candidate list, sorted ------------------------------------
+// MERGE = false: entries cand_val/cand_idx[q*cap + i], i < min(cnt[q], cap)
+// MERGE = true : entries vals/idx[(g*B + q)*k + j], i = g*k + j < G*k
+template <bool MERGE>
+__global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const float* __restrict__ vals,
+                                                                  const int32_t* __restrict__ idxs,
+                                                                  const int32_t* __restrict__ cnt, int64_t cap, int G,
+                                                                  int B, int k, int kpad, int32_t idx_offset,
+                                                                  float* out_val, int32_t* out_idx) {
+  __shared__ int hist[256];
+  __shared__ int scan[256];
+  __shared__ int res[2];
+  __shared__ int n_out;
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sortbuf[];  // kpad entries
+  const int q = blockIdx.x;
+  int count;
+  if (MERGE) {
+    count = G * k;
+  } else {
+    const int c = cnt[q];
+    count = c < (int)cap ? c : (int)cap;
+  }
+  auto key_at = [&](int i) -> unsigned long long {
+    int64_t a;
+    if (MERGE) {
+      const int g = i / k, j = i - g * k;
+      a = ((int64_t)g * B + q) * k + j;
+    } else {
+      a = (int64_t)q * cap + i;
+    }
+    const int32_t id = idxs[a];
+    if (id < 0) return 0ull;  // padding entry
+    return ((unsigned long long)fkey(vals[a]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+  };
+
+  unsigned long long prefix = 0ull;
+  int need = k < count ? k : count;
+  const int want = need;
+  bool exact = false;
+  for (int pass = 0; pass < 8 && !exact; ++pass) {
+    const int shift = 56 - 8 * pass;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < count; i += SEL_THREADS) {
+      const unsigned long long key = key_at(i);
+      const bool match = pass == 0 ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+      if (match) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+    }
+    __syncthreads();
+    int above;
+    const int b = find_bin(hist, scan, need, &above, res);
+    need -= above;
+    prefix |= (unsigned long long)b << shift;
+    exact = hist[b] == need;  // the whole bin is taken: the low bits need no refinement
+    __syncthreads();
+  }
+  // gather the `want` keys >= prefix
+  if (threadIdx.x == 0) n_out = 0;
+  for (int i = threadIdx.x; i < kpad; i += SEL_THREADS) sortbuf[i] = 0ull;
+  __syncthreads();
+  for (int i = threadIdx.x; i < count; i += SEL_THREADS) {
+    const unsigned long long key = key_at(i);
+    if (key >= prefix && key != 0ull) {
+      const int p = atomicAdd(&n_out, 1);
+      if (p < kpad) sortbuf[p] = key;
+    }
+  }
+  __syncthreads();
+  // bitonic sort, descending
+  for (int size = 2; size <= kpad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (kpad >> 1); t += SEL_THREADS) {
+        const int lo = (t / stride) * (stride << 1) + (t % stride);
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = sortbuf[lo], b = sortbuf[hi];
+        if ((a < b) == desc) {
+          sortbuf[lo] = b;
+          sortbuf[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < k; i += SEL_THREADS) {
+    const unsigned long long key = sortbuf[i];
+    float v = -INFINITY;
+    int32_t id = -1;
+    if (i < want && key != 0ull) {
+      v = fkey_inv((uint32_t)(key >> 32));
+      id = (int32_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) + idx_offset;
+    }
+    out_val[(int64_t)q * k + i] = v;
+    out_idx[(int64_t)q * k + i] = id;
+  }
+}
+
+static int next_pow2(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+}  // namespace gdr
+
+extern "C" size_t gdr_sim_topk_workspace_bytes(int B, int64_t N, int d, int k) {
+  (void)d;
+  if (B <= 0 || N <= 0 || k <= 0) return 0;
+  return gdr::make_plan(B, N, k).total;
+}
+
+extern "C" int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, int d, int k, int32_t idx_offset,
+                            float* out_val, int32_t* out_idx, int32_t* status, void* workspace,
+                            size_t workspace_bytes, void* stream_) {
+  using namespace gdr;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GDR_CHECK_ARG(Q && D && out_val && out_idx && workspace, "sim_topk: null pointer");
+  GDR_CHECK_ARG(B > 0 && N > 0 && d > 0 && d % 4 == 0, "sim_topk: bad shape B=%d N=%lld d=%d", B, (long long)N, d);
+  GDR_CHECK_ARG(k >= 1 && k <= 1024 && k <= N, "sim_topk: k=%d must be in [1, min(1024, N)]", k);
+  GDR_CHECK_ARG(N < 0x7fffffffLL - 256, "sim_topk: shard too large for int32 doc ids");
+  GDR_CHECK_ARG(((uintptr_t)Q & 15) == 0 && ((uintptr_t)D & 15) == 0 && ((uintptr_t)workspace & 255) == 0,
+                "sim_topk: Q, D must be 16-byte and workspace 256-byte aligned");
+  const SimPlan p = make_plan(B, N, k);
+  if (workspace_bytes < p.total) {
+    set_error("sim_topk: workspace %zu < required %zu", workspace_bytes, p.total);
+    return GDR_ENOSPC;
+  }
+  char* ws = static_cast<char*>(workspace);
+  SimEpilogue ep{};
+  ep.cand_val = reinterpret_cast<float*>(ws + p.off_val);
+  ep.cand_idx = reinterpret_cast<int32_t*>(ws + p.off_idx);
+  ep.cand_cnt = reinterpret_cast<int32_t*>(ws + p.off_cnt);
+  float* thr = reinterpret_cast<float*>(ws + p.off_thr);
+  ep.thr = thr;
+  ep.status = status;
+  ep.cap = (int32_t)p.cap;
+  ep.tile_stride = p.stride;
+  if (status) {
+    hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), stream);
+    if (e != hipSuccess) {
+      set_error("sim_topk: memset: %s", hipGetErrorString(e));
+      return GDR_EHIP;
+    }
+  }
+  ep.mode = 1;
+  int rc = launch_sim_gemm(D, N, Q, B, d, ep, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sim_threshold_kernel, dim3(B), dim3(SEL_THREADS), 0, stream, ep.cand_val, p.cap, (int)p.n_slots,
+                     k, thr, ep.cand_cnt);
+  GDR_CHECK_LAUNCH("sim_threshold_kernel");
+  if (p.stride > 1) {
+    ep.mode = 2;
+    rc = launch_sim_gemm(D, N, Q, B, d, ep, stream);
+    if (rc) return rc;
+  }
+  const int kpad = next_pow2(k);
+  hipLaunchKernelGGL(topk_select_kernel<false>, dim3(B), dim3(SEL_THREADS), kpad * sizeof(unsigned long long), stream,
+                     ep.cand_val, ep.cand_idx, ep.cand_cnt, p.cap, 1, B, k, kpad, idx_offset, out_val, out_idx);
+  GDR_CHECK_LAUNCH("topk_select_kernel");
+  return GDR_OK;
+}
+
+extern "C" int gdr_topk_merge(const float* vals, const int32_t* idx, int G, int B, int k, float* out_val,
+                              int32_t* out_idx, void* stream_) {
+  using namespace gdr;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GDR_CHECK_ARG(vals && idx && out_val && out_idx, "topk_merge: null pointer");
+  GDR_CHECK_ARG(G > 0 && B > 0 && k >= 1 && k <= 1024, "topk_merge: bad shape G=%d B=%d k=%d", G, B, k);
+  const int kpad = next_pow2(k);
+  hipLaunchKernelGGL(topk_select_kernel<true>, dim3(B), dim3(SEL_THREADS), kpad * sizeof(unsigned long long), stream,
+                     vals, idx, (const int32_t*)nullptr, (int64_t)0, G, B, k, kpad, 0, out_val, out_idx);
+  GDR_CHECK_LAUNCH("topk_select_kernel<merge>");
+  return GDR_OK;
+}

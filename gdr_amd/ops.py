@@ -1,0 +1,161 @@
+"""Thin tensor-level wrappers over the C ABI (include/gdr_hip.h).  Inputs/outputs are torch CUDA tensors used
+purely as device buffers; all arithmetic happens in libgdr_hip.so."""
+import ctypes as C
+
+import torch
+
+from . import _ffi
+from ._ffi import check, lib, ptr, stream_ptr
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _ffi.GdrError("gdr_amd ops need CUDA (ROCm) tensors; there is no CPU path")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise _ffi.GdrError(f"expected float32 tensor, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def linear(a, w, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K].T)  — gdr_linear_f32."""
+    _need_cuda(a, w, bias, residual)
+    K = a.shape[-1]
+    a2 = _f32c(a).view(-1, K)
+    w = _f32c(w)
+    M, N = a2.shape[0], w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    res2 = None
+    if residual is not None:
+        res2 = _f32c(residual).view(-1, N)
+    check(lib().gdr_linear_f32(ptr(a2), K, ptr(w), w.shape[1], ptr(out), N, M, N, K, epilogue,
+                               ptr(_f32c(bias)) if bias is not None else None, ptr(res2), N, stream_ptr()),
+          "gdr_linear_f32")
+    return out.view(*a.shape[:-1], N)
+
+
+class Workspace:
+    """Grow-only device scratch buffer (256-byte aligned by the caching allocator)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False):
+    """Fused Q·Dᵀ + per-row top-k — gdr_sim_topk.  Returns (values fp32[B,k], indices int32[B,k])."""
+    _need_cuda(Q, D)
+    Q, D = _f32c(Q), _f32c(D)
+    B, d = Q.shape
+    N = D.shape[0]
+    if D.shape[1] != d:
+        raise _ffi.GdrError(f"sim_topk: dim mismatch {Q.shape} vs {D.shape}")
+    if k > N:
+        raise RuntimeError("selected index k out of range")          # torch.topk's message
+    need = lib().gdr_sim_topk_workspace_bytes(B, N, d, k)
+    ws = (workspace or Workspace(Q.device)).get(need)
+    vals = torch.empty((B, k), dtype=torch.float32, device=Q.device)
+    idx = torch.empty((B, k), dtype=torch.int32, device=Q.device)
+    status = torch.empty((1,), dtype=torch.int32, device=Q.device)
+    check(lib().gdr_sim_topk(ptr(Q), B, ptr(D), N, d, k, idx_offset, ptr(vals), ptr(idx), ptr(status), ptr(ws),
+                             ws.numel(), stream_ptr()), "gdr_sim_topk")
+    return (vals, idx, status) if return_status else (vals, idx)
+
+
+def topk_merge(vals, idx):
+    """[G,B,k] per-shard lists -> [B,k] — gdr_topk_merge."""
+    _need_cuda(vals, idx)
+    vals, idx = _f32c(vals), idx.contiguous()
+    G, B, k = vals.shape
+    ov = torch.empty((B, k), dtype=torch.float32, device=vals.device)
+    oi = torch.empty((B, k), dtype=torch.int32, device=vals.device)
+    check(lib().gdr_topk_merge(ptr(vals), ptr(idx), G, B, k, ptr(ov), ptr(oi), stream_ptr()), "gdr_topk_merge")
+    return ov, oi
+
+
+def rerank_topk(q, D, cand_offsets, cand_ids, beam_scores, alphas, k, func="tanh", max_cand=None):
+    """In-cluster rerank — gdr_rerank_topk.  Returns (values fp32[B,A,k], doc ids int32[B,A,k])."""
+    _need_cuda(q, D, cand_offsets, cand_ids, beam_scores)
+    q, D, beam_scores = _f32c(q), _f32c(D), _f32c(beam_scores)
+    B, R = beam_scores.shape
+    al = torch.as_tensor(alphas, dtype=torch.float32, device=q.device)
+    A = al.numel()
+    if max_cand is None:
+        o = cand_offsets.view(-1)[::R]
+        max_cand = int((o[1:] - o[:-1]).max().item())
+    ov = torch.empty((B, A, k), dtype=torch.float32, device=q.device)
+    oi = torch.empty((B, A, k), dtype=torch.int32, device=q.device)
+    check(lib().gdr_rerank_topk(ptr(q), ptr(D), q.shape[1], ptr(cand_offsets), ptr(cand_ids), ptr(beam_scores), B, R,
+                                ptr(al), A, k, 0 if func == "tanh" else 1, ptr(ov), ptr(oi), max(int(max_cand), 1),
+                                stream_ptr()), "gdr_rerank_topk")
+    return ov, oi
+
+
+def relative_bucket_table(bidirectional, num_buckets, max_distance, qlen, klen):
+    """Host table int32[qlen,klen] from the same routine the attention kernels use (no GPU needed)."""
+    buf = (C.c_int32 * (qlen * klen))()
+    check(lib().gdr_t5_relative_bucket_table(int(bidirectional), num_buckets, max_distance, qlen, klen, buf),
+          "gdr_t5_relative_bucket_table")
+    return torch.tensor(list(buf), dtype=torch.int32).view(qlen, klen)
+
+
+class T5EncoderHandle:
+    """Device-resident encoder weights + the pointer table gdr_t5_encoder_forward reads.
+    Built once from a reference-style state_dict; q/k/v are row-concatenated."""
+
+    def __init__(self, cfg, sd, device, prefix="encoder."):
+        self.cfg, self.device = cfg, device
+        keep = []
+
+        def dev(t):
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t
+
+        self.embed = dev(sd["shared.weight"] if "shared.weight" in sd else sd[prefix + "embed_tokens.weight"])
+        self.rel_bias = dev(sd[prefix + "block.0.layer.0.SelfAttention.relative_attention_bias.weight"])
+        self.final_ln = dev(sd[prefix + "final_layer_norm.weight"])
+        nl = cfg.num_layers
+        self._layers = (_ffi.GdrT5EncLayer * nl)()
+        for i in range(nl):
+            p = f"{prefix}block.{i}.layer."
+            wqkv = dev(torch.cat([sd[p + "0.SelfAttention.q.weight"], sd[p + "0.SelfAttention.k.weight"],
+                                  sd[p + "0.SelfAttention.v.weight"]], dim=0))
+            L = self._layers[i]
+            L.ln_attn = dev(sd[p + "0.layer_norm.weight"]).data_ptr()
+            L.wqkv = wqkv.data_ptr()
+            L.wo = dev(sd[p + "0.SelfAttention.o.weight"]).data_ptr()
+            L.ln_ff = dev(sd[p + "1.layer_norm.weight"]).data_ptr()
+            L.wi = dev(sd[p + "1.DenseReluDense.wi.weight"]).data_ptr()
+            L.wo_ff = dev(sd[p + "1.DenseReluDense.wo.weight"]).data_ptr()
+        self._keep = keep
+        self.dims = _ffi.GdrT5Dims(cfg.vocab_size, cfg.d_model, cfg.d_kv, cfg.d_ff, cfg.num_heads, nl,
+                                   cfg.relative_attention_num_buckets, cfg.relative_attention_max_distance,
+                                   cfg.layer_norm_epsilon)
+        self.struct = _ffi.GdrT5EncoderWeights(self.dims, self.embed.data_ptr(), self.rel_bias.data_ptr(),
+                                               self.final_ln.data_ptr(), self._layers)
+        self.ws = Workspace(device)
+
+    def forward(self, input_ids, attention_mask=None, want_pooled=True):
+        _need_cuda(input_ids, attention_mask)
+        ids = input_ids.to(torch.int64).contiguous()
+        B, L = ids.shape
+        if attention_mask is None:
+            attention_mask = torch.ones_like(ids)
+        mask = attention_mask.to(torch.int64).contiguous()
+        need = lib().gdr_t5_encoder_workspace_bytes(C.byref(self.dims), B, L)
+        ws = self.ws.get(need)
+        out = torch.empty((B, L, self.cfg.d_model), dtype=torch.float32, device=ids.device)
+        pooled = torch.empty((B, self.cfg.d_model), dtype=torch.float32, device=ids.device) if want_pooled else None
+        check(lib().gdr_t5_encoder_forward(C.byref(self.struct), ptr(ids), ptr(mask), B, L, ptr(out), ptr(pooled),
+                                           ptr(ws), ws.numel(), stream_ptr()), "gdr_t5_encoder_forward")
+        return out, pooled

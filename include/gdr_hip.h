@@ -1,0 +1,138 @@
+/*
+ * gdr_hip.h — C ABI of libgdr_hip.so, the MI355X (gfx950) implementation of GDR's inference hot path.
+ *
+ * The reference (ypw0102/GDR) has no FFI: its boundary is the Python call surface of
+ * GDR_model/main_models.py / GDR_model/transformers.  gdr_amd/modeling.py keeps
+ * that surface (generate(), get_encoder(), encode_query(), compute_similarity()) and binds the entry
+ * points below with ctypes (gdr_amd/_ffi.py); INTEGRATION.md shows the stub a reference maintainer
+ * would add.  Each entry point names the reference call site it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (tensor.data_ptr()); outputs are
+ *     pre-allocated by the caller; the library allocates nothing — scratch comes from the caller's
+ *     workspace, sized by the matching *_workspace_bytes();
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); calls are asynchronous on it and
+ *     contain no host synchronisation (hipGraph-capturable);
+ *   - return 0 on success, a negative GDR_E* code otherwise; gdr_last_error() gives the thread-local
+ *     message; no exceptions cross the ABI; no global mutable state besides that message;
+ *   - row-major fp32 unless stated; ids int64 where the reference uses LongTensor inputs, int32 for
+ *     doc ids produced on device.
+ */
+#ifndef GDR_HIP_H
+#define GDR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDR_OK 0
+#define GDR_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define GDR_ENOSPC (-2)   /* workspace too small */
+#define GDR_EHIP (-3)     /* HIP runtime error at launch */
+
+const char* gdr_last_error(void);
+int gdr_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense linear:  C[M,N] = epilogue(A[M,K] · W[N,K]^T)      (nn.Linear layout, both K-contiguous)
+ * replaces every `nn.Linear` / `torch.matmul` call site on the path:
+ *   transformers/modeling_t5.py:360-364,413 (q/k/v/o), :182-185 (wi/ReLU/wo), :1634 (adaptor_linear),
+ *   dense.py:21-23 (pooler), torch nn.TransformerDecoderLayer linears (modeling_t5.py:1241-1244).
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (bit-identical to a k-ordered fmaf chain).
+ * K % 4 == 0; lda/ldw/ldc in elements, multiples of 4.  `residual` may alias C.
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+  GDR_EPI_NONE = 0,
+  GDR_EPI_RESIDUAL = 1,       /* C = acc + residual                     (h + dropout(y), modeling_t5.py:199,452) */
+  GDR_EPI_RELU = 2,           /* C = max(acc, 0)                        (modeling_t5.py:183)                      */
+  GDR_EPI_BIAS = 3,           /* C = acc + bias[n]                                                                */
+  GDR_EPI_BIAS_RELU = 4,      /* C = max(acc + bias[n], 0)              (TransformerDecoderLayer linear1)         */
+  GDR_EPI_BIAS_RESIDUAL = 5,  /* C = acc + bias[n] + residual                                                     */
+  GDR_EPI_BIAS_GELU = 6       /* C = gelu_erf(acc + bias[n])            (BERT intermediate, modeling_bert.py)     */
+};
+int gdr_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
+                   int64_t M, int N, int K, int epilogue, const float* bias, const float* residual,
+                   int64_t ldr, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * T5 encoder forward — replaces `model.get_encoder()(input_ids, attention_mask=, return_dict=True)
+ * .last_hidden_state` (transformers/modeling_t5.py:685-821; called at generation_utils.py:410-411).
+ * Weights: pointer table built once from the reference state_dict; wqkv is the
+ * row-concatenation [q;k;v] of the three [inner,d] projection matrices.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t vocab_size, d_model, d_kv, d_ff, num_heads, num_layers;
+  int32_t rel_buckets, rel_max_distance;
+  float eps;
+} GdrT5Dims;
+
+typedef struct {
+  const float* ln_attn;   /* [d]            block.i.layer.0.layer_norm.weight              */
+  const float* wqkv;      /* [3*inner, d]   layer.0.SelfAttention.{q,k,v}.weight row-concat */
+  const float* wo;        /* [d, inner]     layer.0.SelfAttention.o.weight                 */
+  const float* ln_ff;     /* [d]            layer.1.layer_norm.weight                      */
+  const float* wi;        /* [d_ff, d]      layer.1.DenseReluDense.wi.weight               */
+  const float* wo_ff;     /* [d, d_ff]      layer.1.DenseReluDense.wo.weight               */
+} GdrT5EncLayer;
+
+typedef struct {
+  GdrT5Dims dims;
+  const float* embed;       /* [vocab, d]     shared.weight                                          */
+  const float* rel_bias;    /* [buckets, H]   encoder.block.0...relative_attention_bias.weight       */
+  const float* final_ln;    /* [d]            encoder.final_layer_norm.weight                        */
+  const GdrT5EncLayer* layers;  /* host array of num_layers entries (device pointers inside)        */
+} GdrT5EncoderWeights;
+
+size_t gdr_t5_encoder_workspace_bytes(const GdrT5Dims* dims, int B, int L);
+/* ids/mask int64[B,L]; out_hidden fp32[B,L,d]; optional out_pooled fp32[B,d] = hidden[:,0]
+ * (CLS pool, main_models.py:102-109 / dense.py:39,50) or NULL. */
+int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L,
+                           float* out_hidden, float* out_pooled, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Corpus similarity + top-k, fused: never materialises the [B,N] score matrix.
+ * replaces `compute_similarity` (dense.py:53-54, encoder.py:128-129: q @ p.T) followed by
+ * `Tensor.topk(k, largest=True, sorted=True)` (as at main_models.py:1625).
+ *   Q fp32[B,d], D fp32[N,d] (the resident corpus shard) -> out_val fp32[B,k] descending,
+ *   out_idx int32[B,k] = row in D + idx_offset.  Ties: higher score first, then lower id.
+ *   status (device int32[1], may be NULL): set to 1 if a candidate list overflowed (never observed on
+ *   non-degenerate data) — results for that query are then the top-k of a subset.
+ * d % 4 == 0, 1 <= k <= 1024, k <= N.
+ * ---------------------------------------------------------------------------------------------- */
+size_t gdr_sim_topk_workspace_bytes(int B, int64_t N, int d, int k);
+int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, int d, int k, int32_t idx_offset,
+                 float* out_val, int32_t* out_idx, int32_t* status, void* workspace, size_t workspace_bytes,
+                 void* stream);
+
+/* Merge of per-shard top-k lists after the RCCL all-gather (no reference analogue):
+ * vals/idx [G,B,k] (shard-major) -> [B,k]; same tie rule, so every rank computes identical output. */
+int gdr_topk_merge(const float* vals, const int32_t* idx, int G, int B, int k, float* out_val, int32_t* out_idx,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * In-cluster rerank — replaces main_models.py:1574-1637, block-diagonal only.
+ *   q fp32[B,d]; D fp32[N,d]; cand_offsets int32[B*R+1] CSR over the decoded clusters (query-major,
+ *   beam order) into cand_ids int32[...]; beam_scores fp32[B,R] (length-penalised);
+ *   alphas fp32[A]; out_val fp32[B,A,k], out_idx int32[B,A,k] (doc ids; -1 / -inf padding when a
+ *   query has fewer than k candidates — the reference raises there).  func: 0 tanh, 1 sigmoid.
+ *   max_cand: upper bound of any query's candidate count (host knows it from the CSR; <= 8192) — sizes
+ *   the LDS sort buffer; candidates past it are ignored.
+ * ---------------------------------------------------------------------------------------------- */
+int gdr_rerank_topk(const float* q, const float* D, int d, const int32_t* cand_offsets, const int32_t* cand_ids,
+                    const float* beam_scores, int B, int R, const float* alphas, int A, int k, int func,
+                    float* out_val, int32_t* out_idx, int max_cand, void* stream);
+
+/* T5 relative-position buckets (transformers/modeling_t5.py:242-288) for relative_position =
+ * key_pos - query_pos, written to a HOST int32[qlen*klen] table; the attention kernels use the same
+ * host routine, so tests pin it bit-exact against the reference. */
+int gdr_t5_relative_bucket_table(int bidirectional, int num_buckets, int max_distance, int qlen, int klen,
+                                 int32_t* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDR_HIP_H */
