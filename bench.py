@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — queries/sec of GDR's dense-retrieval hot path on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch of synthetic input:
+    T5-base encoder forward on `batch` tokenised queries (int64[batch,40])  ->  CLS pool  ->
+    fused Q·Dᵀ + top-100 over the resident 320 000 x 768 fp32 corpus.
+N = 1 runs BASELINE config C2 (batch 512, whole corpus on one GPU).  N > 1 (one process per GPU, launched by
+torch.distributed.run) runs C4's layout with weak scaling: every rank encodes its own 512 queries, the corpus
+is row-sharded N ways, pooled queries are all-gathered, each rank searches its shard for all 512·N queries,
+and ONE all-gather of the per-shard (score,id)[B,k] lists precedes the local merge (gdr_amd/dist.py).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fp32 MFMA GEMM that serves every
+encoder linear: algorithmic flops per launch / average launch duration, both measured live over the timed
+region with hipEvent pairs recorded by the library on the launch stream (gdr_prof_*).  `cpu_baseline` is the
+oracle ("port" of the reference's CPU path) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="queries per GPU per step")
+    ap.add_argument("--corpus", type=int, default=320000)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-recall", action="store_true")
+    return ap.parse_args()
+
+
+def host_threads():
+    """Threads the CPU baseline may really use: scheduler affinity, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(sd, cfg, ids, mask, D, k, budget_s=25.0):
+    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload: the
+    sample doubles until one pass costs >= 1/4 of the budget, then is timed (median of 3)."""
+    from oracle import t5_ref, retrieval_ref
+    torch.set_num_threads(host_threads())
+    Dt = torch.from_numpy(D)
+
+    def run(n):
+        h = t5_ref.encoder_forward(sd, cfg, torch.from_numpy(ids[:n]), torch.from_numpy(mask[:n]))
+        return retrieval_ref.sim_topk(retrieval_ref.cls_pool(h), Dt, k)
+
+    n = 8
+    run(n)                                           # warm-up (thread pool, page-in)
+    while True:
+        t0 = time.perf_counter()
+        run(n)
+        t = time.perf_counter() - t0
+        if t >= budget_s / 8 or n >= ids.shape[0]:
+            break
+        n = min(n * 2, ids.shape[0])
+    ts = [t]
+    for _ in range(2):
+        t0 = time.perf_counter()
+        run(n)
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[1]
+    return {"value": n / med, "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} of the step's queries through the whole path (encoder fp32 + Q.D^T top-{k} over "
+                      f"all {D.shape[0]} docs), torch-CPU oracle, warm-up + median of 3 ({med:.2f} s each)"}
+
+
+def recall_at(idx, gold, ks=(1, 10, 100)):
+    idx = np.asarray(idx)
+    return [float(np.mean([(gold[b] in idx[b, :k]) for b in range(idx.shape[0])])) * 100.0 for k in ks]
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        a.gpus = world
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    torch.set_grad_enabled(False)
+
+    from gdr_amd import ops, synth, _ffi
+    from gdr_amd.config import GDRConfig
+    from gdr_amd.dist import ShardedIndex, shard_bounds
+
+    cfg = GDRConfig.base()
+    sd = synth.make_state_dict(cfg, seed=1234, with_decoder=False)
+    enc = ops.T5EncoderHandle(cfg, sd, dev)
+    D = synth.make_corpus(a.corpus, cfg.d_model)
+    lo, hi = shard_bounds(a.corpus, world, rank, cluster_size=12)
+    D_dev = torch.from_numpy(D[lo:hi]).to(dev)
+    index = ShardedIndex(D_dev, lo)
+    ids_all, mask_all = synth.make_tokens(a.batch * world, L=40, seed=11)
+    ids = torch.from_numpy(ids_all[rank * a.batch:(rank + 1) * a.batch]).to(dev)
+    mask = torch.from_numpy(mask_all[rank * a.batch:(rank + 1) * a.batch]).to(dev)
+
+    def step():
+        _, pooled = enc.forward(ids, mask)
+        q_all = index.gather_queries(pooled)
+        return index.search(q_all, a.k)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    lib = _ffi.lib()
+    launches_per_step = 4 * cfg.num_layers + 4
+    _ffi.check(lib.gdr_prof_enable(launches_per_step * a.steps + 16), "gdr_prof_enable")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    n_l, ms_l, w_l = (C.c_int64 * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
+    _ffi.check(lib.gdr_prof_collect(n_l, ms_l, w_l), "gdr_prof_collect")
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_q = a.batch * world * a.steps
+    ms_per_step = dt / a.steps * 1e3
+    result = None
+    if rank == 0:
+        def cls(c):
+            if n_l[c] == 0:
+                return None
+            avg_ms = ms_l[c] / n_l[c]
+            avg_work = w_l[c] / n_l[c]
+            return {"launches": int(n_l[c]), "avg_ms": avg_ms, "gflop_per_launch": avg_work / 1e9,
+                    "tflops": avg_work / (avg_ms * 1e-3) / 1e12, "share_of_step": ms_l[c] / (dt * 1e3)}
+
+        lin, smp, flt = cls(0), cls(1), cls(2)
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("gemm_nt_f32_kernel<0>_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "queries/sec on NQ-320k (768-d)", "value": total_q / dt, "unit": "queries/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("C2" if world == 1 else "C4-layout") +
+                       f": t5-base encoder on {a.batch} queries/GPU (L=40) + fused Q.D^T top-{a.k} over a "
+                       f"{a.corpus}x{cfg.d_model} fp32 corpus" + ("" if world == 1 else f" row-sharded {world} ways, "
+                       "all-gather of queries and of per-shard top-k, local merge"),
+                       "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 40,
+                       "corpus_rows": a.corpus, "dim": cfg.d_model, "k": a.k, "corpus_resident_in_hbm": True},
+            "roofline": {"bound": "mfma", "kernel": "gdr::gemm_nt_f32_kernel<0> (every encoder linear)",
+                         "achieved": lin["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": lin["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "launches": lin["launches"], "avg_launch_ms": lin["avg_ms"],
+                         "algorithmic_gflop_per_launch": lin["gflop_per_launch"], "share_of_step": lin["share_of_step"]},
+            "kernels": {"sim_sample_gemm": smp, "sim_filter_gemm": flt},
+        }
+        if flt:
+            # similarity as a whole (both GEMM passes): flops and the corpus bytes it must stream once
+            sim_ms = (ms_l[1] + ms_l[2]) / a.steps
+            rows = hi - lo
+            result["kernels"]["sim_total"] = {
+                "ms_per_step": sim_ms, "tflops": (w_l[1] + w_l[2]) / a.steps / (sim_ms * 1e-3) / 1e12,
+                "frac_of_f32_mfma_peak": (w_l[1] + w_l[2]) / a.steps / (sim_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                "corpus_stream_gbs": rows * cfg.d_model * 4 / (sim_ms * 1e-3) / 1e9,
+                "frac_of_hbm_peak": rows * cfg.d_model * 4 / (sim_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if world == 1 and not a.no_recall:
+            from oracle import retrieval_ref
+            Q, gold = synth.make_queries(D, a.batch)
+            _, gi = ops.sim_topk(torch.from_numpy(Q).to(dev), D_dev, a.k)
+            _, ci = retrieval_ref.sim_topk(torch.from_numpy(Q), torch.from_numpy(D), a.k, block=128)
+            result["recall"] = {"k": [1, 10, 100], "gpu": recall_at(gi.cpu().numpy(), gold),
+                                "cpu_oracle": recall_at(ci.numpy(), gold),
+                                "topk_ids_identical_rows": int((gi.cpu().numpy() == ci.numpy()).all(axis=1).sum()),
+                                "rows": a.batch}
+        if world == 1 and not a.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sd, cfg, ids_all, mask_all, D, a.k)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,80 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---------------------------------------------------------------------------------------- profiler
+struct ProfState {
+  bool on = false;
+  int cap = 0, used = 0;
+  hipEvent_t* start = nullptr;
+  hipEvent_t* stop = nullptr;
+  int* cls = nullptr;
+  double* work = nullptr;
+};
+static ProfState g_prof;
+
+ProfScope::ProfScope(int c, double w, hipStream_t s) : slot(-1), stream(s) {
+  if (!g_prof.on || g_prof.used >= g_prof.cap) return;
+  slot = g_prof.used++;
+  g_prof.cls[slot] = c;
+  g_prof.work[slot] = w;
+  (void)hipEventRecord(g_prof.start[slot], stream);
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_prof.stop[slot], stream);
+}
 }  // namespace gdr
+
+extern "C" int gdr_prof_enable(int max_events) {
+  using namespace gdr;
+  if (g_prof.on || max_events <= 0) {
+    set_error("prof_enable: already enabled or bad size");
+    return GDR_EINVAL;
+  }
+  g_prof.start = new hipEvent_t[max_events];
+  g_prof.stop = new hipEvent_t[max_events];
+  g_prof.cls = new int[max_events];
+  g_prof.work = new double[max_events];
+  for (int i = 0; i < max_events; ++i) {
+    if (hipEventCreate(&g_prof.start[i]) != hipSuccess || hipEventCreate(&g_prof.stop[i]) != hipSuccess) {
+      set_error("prof_enable: hipEventCreate failed");
+      return GDR_EHIP;
+    }
+  }
+  g_prof.cap = max_events, g_prof.used = 0, g_prof.on = true;
+  return GDR_OK;
+}
+
+// Synchronises the recorded events, accumulates per class {launches, total ms, total work} into the three
+// host arrays of length 8, then disables and frees the profiler.  Returns the number of events lost to a
+// full buffer (0 = none) or a negative error code.
+extern "C" int gdr_prof_collect(int64_t* launches, double* total_ms, double* total_work) {
+  using namespace gdr;
+  if (!g_prof.on) {
+    set_error("prof_collect: profiler not enabled");
+    return GDR_EINVAL;
+  }
+  for (int c = 0; c < PROF_NCLASS; ++c) launches[c] = 0, total_ms[c] = 0.0, total_work[c] = 0.0;
+  int rc = GDR_OK;
+  for (int i = 0; i < g_prof.used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof.stop[i]) != hipSuccess ||
+        hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]) != hipSuccess) {
+      set_error("prof_collect: event query failed");
+      rc = GDR_EHIP;
+      break;
+    }
+    const int c = g_prof.cls[i];
+    launches[c] += 1, total_ms[c] += ms, total_work[c] += g_prof.work[i];
+  }
+  for (int i = 0; i < g_prof.cap; ++i) {
+    (void)hipEventDestroy(g_prof.start[i]);
+    (void)hipEventDestroy(g_prof.stop[i]);
+  }
+  delete[] g_prof.start, delete[] g_prof.stop, delete[] g_prof.cls, delete[] g_prof.work;
+  g_prof = ProfState();
+  return rc;
+}
 
 extern "C" const char* gdr_last_error(void) { return gdr::g_err; }
 extern "C" int gdr_abi_version(void) { return 1; }

@@ -36,10 +36,12 @@ struct GemmArgs {
   int64_t M;
   int N, K;
   int tiles_n;
+  int has_bias, has_residual, act;  // linear epilogue, runtime so that every linear shares one kernel
   SimEpilogue sim;
 };
 
-enum { EPI_SIM_SAMPLE = 100, EPI_SIM_FILTER = 101 };
+enum { EPI_LINEAR = 0, EPI_SIM_SAMPLE = 100, EPI_SIM_FILTER = 101 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -100,35 +102,55 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (g.K + BK - 1) / BK;
-  float4 ra[4], rb[4];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // K tail (K % 32 != 0, K % 4 == 0): loads past K re-read the row's last float4 (a valid address) and the
+  // VALUE is zeroed — never select between addresses, that demotes the loads to flat + scratch.
+  const bool ktail = (g.K % BK) != 0;
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 
-  auto gload = [&](int kt) {
-    const int k = kt * BK + lcol;
-    const bool ok = k < g.K;  // K % 4 == 0: a float4 is entirely inside or outside
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      ra[p] = ok ? *reinterpret_cast<const float4*>(a_src[p] + kt * BK) : zero4;
-      rb[p] = ok ? *reinterpret_cast<const float4*>(w_src[p] + kt * BK) : zero4;
-    }
-  };
-  auto lstore = [&](int buf) {
-    float* a = As + buf * BM * LDS_STRIDE + st_off;
-    float* b = Bs + buf * BN * LDS_STRIDE + st_off;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<float4*>(a + 32 * p * LDS_STRIDE) = ra[p];
-      *reinterpret_cast<float4*>(b + 32 * p * LDS_STRIDE) = rb[p];
-    }
-  };
+#define GDR_GLOAD(kt_)                                                                    \
+  do {                                                                                    \
+    int koff = (kt_)*BK;                                                                  \
+    bool ok = true;                                                                       \
+    if (ktail) {                                                                          \
+      ok = koff + lcol < g.K;                                                             \
+      koff = ok ? koff : g.K - 4 - lcol;                                                  \
+    }                                                                                     \
+    ra0 = *reinterpret_cast<const float4*>(a_src[0] + koff);                              \
+    ra1 = *reinterpret_cast<const float4*>(a_src[1] + koff);                              \
+    ra2 = *reinterpret_cast<const float4*>(a_src[2] + koff);                              \
+    ra3 = *reinterpret_cast<const float4*>(a_src[3] + koff);                              \
+    rb0 = *reinterpret_cast<const float4*>(w_src[0] + koff);                              \
+    rb1 = *reinterpret_cast<const float4*>(w_src[1] + koff);                              \
+    rb2 = *reinterpret_cast<const float4*>(w_src[2] + koff);                              \
+    rb3 = *reinterpret_cast<const float4*>(w_src[3] + koff);                              \
+    if (ktail && !ok) {                                                                   \
+      ra0 = ra1 = ra2 = ra3 = make_float4(0.f, 0.f, 0.f, 0.f);                            \
+      rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);                            \
+    }                                                                                     \
+  } while (0)
 
-  gload(0);
-  lstore(0);
+#define GDR_LSTORE(buf_)                                                                  \
+  do {                                                                                    \
+    float* a_ = As + (buf_)*BM * LDS_STRIDE + st_off;                                     \
+    float* b_ = Bs + (buf_)*BN * LDS_STRIDE + st_off;                                     \
+    *reinterpret_cast<float4*>(a_) = ra0;                                                 \
+    *reinterpret_cast<float4*>(a_ + 32 * LDS_STRIDE) = ra1;                               \
+    *reinterpret_cast<float4*>(a_ + 64 * LDS_STRIDE) = ra2;                               \
+    *reinterpret_cast<float4*>(a_ + 96 * LDS_STRIDE) = ra3;                               \
+    *reinterpret_cast<float4*>(b_) = rb0;                                                 \
+    *reinterpret_cast<float4*>(b_ + 32 * LDS_STRIDE) = rb1;                               \
+    *reinterpret_cast<float4*>(b_ + 64 * LDS_STRIDE) = rb2;                               \
+    *reinterpret_cast<float4*>(b_ + 96 * LDS_STRIDE) = rb3;                               \
+  } while (0)
+
+  GDR_GLOAD(0);
+  GDR_LSTORE(0);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    const bool more = kt + 1 < nk;
+    if (more) GDR_GLOAD(kt + 1);
     const float* a = As + buf * BM * LDS_STRIDE + a_rd;
     const float* b = Bs + buf * BN * LDS_STRIDE + b_rd;
 #pragma unroll
@@ -137,19 +159,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
       const float4 a1 = *reinterpret_cast<const float4*>(a + 32 * LDS_STRIDE + 8 * jj);
       const float4 b0 = *reinterpret_cast<const float4*>(b + 8 * jj);
       const float4 b1 = *reinterpret_cast<const float4*>(b + 32 * LDS_STRIDE + 8 * jj);
-      const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-      const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
-      }
+#define GDR_MFMA4(x_)                                                                            \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x_, b0.x_, acc[0][0], 0, 0, 0);            \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x_, b1.x_, acc[0][1], 0, 0, 0);            \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x_, b0.x_, acc[1][0], 0, 0, 0);            \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x_, b1.x_, acc[1][1], 0, 0, 0);
+      GDR_MFMA4(x)
+      GDR_MFMA4(y)
+      GDR_MFMA4(z)
+      GDR_MFMA4(w)
+#undef GDR_MFMA4
     }
-    if (kt + 1 < nk) lstore(buf ^ 1);
+    if (more) GDR_LSTORE(buf ^ 1);
     __syncthreads();
   }
+#undef GDR_GLOAD
+#undef GDR_LSTORE
 
   // ---- epilogue.  Accumulator map (32x32 MFMA): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
   if (EPI == EPI_SIM_SAMPLE || EPI == EPI_SIM_FILTER) {
@@ -173,7 +198,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
             v.y = m + 1 < g.M ? acc[mi][ni][4 * q4 + 1] : -INFINITY;
             v.z = m + 2 < g.M ? acc[mi][ni][4 * q4 + 2] : -INFINITY;
             v.w = m + 3 < g.M ? acc[mi][ni][4 * q4 + 3] : -INFINITY;
-            id.x = (int)m, id.y = (int)m + 1, id.z = (int)m + 2, id.w = (int)m + 3;
+            id.x = m + 0 < g.M ? (int)m : -1, id.y = m + 1 < g.M ? (int)m + 1 : -1;
+            id.z = m + 2 < g.M ? (int)m + 2 : -1, id.w = m + 3 < g.M ? (int)m + 3 : -1;  // -1 = padding slot
             *reinterpret_cast<float4*>(cv + slot_base + roff) = v;
             *reinterpret_cast<int4*>(ci + slot_base + roff) = id;
           }
@@ -211,22 +237,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
   for (int ni = 0; ni < 2; ++ni) {
     const int n = n0 + wn * 64 + ni * 32 + l31;
     if (n >= g.N) continue;
-    float bia = 0.f;
-    if (EPI == GDR_EPI_BIAS || EPI == GDR_EPI_BIAS_RELU || EPI == GDR_EPI_BIAS_RESIDUAL || EPI == GDR_EPI_BIAS_GELU)
-      bia = g.bias[n];
+    const float bia = g.has_bias ? g.bias[n] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m >= g.M) continue;
-        float v = acc[mi][ni][r];
-        if (EPI == GDR_EPI_BIAS || EPI == GDR_EPI_BIAS_RELU || EPI == GDR_EPI_BIAS_RESIDUAL ||
-            EPI == GDR_EPI_BIAS_GELU)
-          v += bia;
-        if (EPI == GDR_EPI_RESIDUAL || EPI == GDR_EPI_BIAS_RESIDUAL) v += g.residual[m * g.ldr + n];
-        if (EPI == GDR_EPI_RELU || EPI == GDR_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-        if (EPI == GDR_EPI_BIAS_GELU) v = gelu_erf(v);
+        float v = acc[mi][ni][r] + bia;
+        if (g.has_residual) v += g.residual[m * g.ldr + n];
+        if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
+        if (g.act == ACT_GELU) v = gelu_erf(v);
         g.C[m * g.ldc + n] = v;
       }
     }
@@ -268,16 +289,16 @@ int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, 
   g.M = M, g.N = N, g.K = K;
   g.tiles_n = (N + BN - 1) / BN;
   const int64_t tiles_m = (M + BM - 1) / BM;
-  switch (epilogue) {
-    case GDR_EPI_NONE: return launch<GDR_EPI_NONE>(g, tiles_m, stream);
-    case GDR_EPI_RESIDUAL: return launch<GDR_EPI_RESIDUAL>(g, tiles_m, stream);
-    case GDR_EPI_RELU: return launch<GDR_EPI_RELU>(g, tiles_m, stream);
-    case GDR_EPI_BIAS: return launch<GDR_EPI_BIAS>(g, tiles_m, stream);
-    case GDR_EPI_BIAS_RELU: return launch<GDR_EPI_BIAS_RELU>(g, tiles_m, stream);
-    case GDR_EPI_BIAS_RESIDUAL: return launch<GDR_EPI_BIAS_RESIDUAL>(g, tiles_m, stream);
-    case GDR_EPI_BIAS_GELU: return launch<GDR_EPI_BIAS_GELU>(g, tiles_m, stream);
-    default: set_error("linear: unknown epilogue %d", epilogue); return GDR_EINVAL;
+  g.has_bias = needs_bias, g.has_residual = needs_res;
+  g.act = (epilogue == GDR_EPI_RELU || epilogue == GDR_EPI_BIAS_RELU) ? ACT_RELU
+          : epilogue == GDR_EPI_BIAS_GELU                             ? ACT_GELU
+                                                                      : ACT_NONE;
+  if (epilogue < GDR_EPI_NONE || epilogue > GDR_EPI_BIAS_GELU) {
+    set_error("linear: unknown epilogue %d", epilogue);
+    return GDR_EINVAL;
   }
+  ProfScope prof(PROF_LINEAR, 2.0 * (double)M * (double)N * (double)K, stream);
+  return launch<EPI_LINEAR>(g, tiles_m, stream);
 }
 
 int launch_sim_gemm(const float* D, int64_t N, const float* Q, int B, int d, const SimEpilogue& ep,
@@ -289,7 +310,15 @@ int launch_sim_gemm(const float* D, int64_t N, const float* Q, int B, int d, con
   g.sim = ep;
   const int64_t tiles_m = (N + BM - 1) / BM;
   const int64_t n_sample_tiles = (tiles_m + ep.tile_stride - 1) / ep.tile_stride;
-  if (ep.mode == 1) return launch<EPI_SIM_SAMPLE>(g, n_sample_tiles, stream);
+  if (ep.mode == 1) {
+    int64_t rows = n_sample_tiles * BM;
+    if (rows > N) rows = N;
+    ProfScope prof(PROF_SIM_SAMPLE, 2.0 * (double)rows * (double)B * (double)d, stream);
+    return launch<EPI_SIM_SAMPLE>(g, n_sample_tiles, stream);
+  }
+  int64_t rows = (tiles_m - n_sample_tiles) * BM;
+  if (rows > N) rows = N;
+  ProfScope prof(PROF_SIM_FILTER, 2.0 * (double)rows * (double)B * (double)d, stream);
   return launch<EPI_SIM_FILTER>(g, tiles_m - n_sample_tiles, stream);
 }
 

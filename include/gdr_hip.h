@@ -36,6 +36,14 @@ extern "C" {
 const char* gdr_last_error(void);
 int gdr_abi_version(void);
 
+/* Opt-in launch profiler used by bench.py for the roofline line: while enabled, every launch of the dense
+ * kernels is bracketed by a hipEvent pair recorded on the stream it is launched on.  Process-global, not
+ * thread-safe, off by default (then no event is created or recorded).  gdr_prof_collect synchronises,
+ * fills three host arrays of length 8 indexed by kernel class {0 linear GEMM, 1 sim sample GEMM,
+ * 2 sim filter GEMM} with {launch count, total ms, total flops}, and disables the profiler again. */
+int gdr_prof_enable(int max_events);
+int gdr_prof_collect(int64_t* launches, double* total_ms, double* total_work);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense linear:  C[M,N] = epilogue(A[M,K] · W[N,K]^T)      (nn.Linear layout, both K-contiguous)
  * replaces every `nn.Linear` / `torch.matmul` call site on the path:
