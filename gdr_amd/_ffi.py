@@ -32,6 +32,24 @@ class GdrT5EncoderWeights(C.Structure):
                 ("layers", C.POINTER(GdrT5EncLayer))]
 
 
+class GdrT5DecLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln_self", "wqkv", "wo", "ln_cross", "wq_c", "wkv_c", "wo_c", "ln_ff", "wi",
+                                          "wo_ff")]
+
+
+class GdrAdaptorLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("in_w", "in_b", "out_w", "out_b", "ln1_w", "ln1_b", "cross_const", "ln2_w",
+                                          "ln2_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b", "ln3_w", "ln3_b")]
+
+
+class GdrT5DecoderWeights(C.Structure):
+    _fields_ = [("dims", GdrT5Dims), ("out_vocab", C.c_int32), ("max_out_len", C.c_int32),
+                ("adaptor_layers", C.c_int32), ("adaptor_nhead", C.c_int32), ("adaptor_ff", C.c_int32),
+                ("adaptor_eps", C.c_float), ("dec_embed", C.c_void_p), ("self_rel_bias", C.c_void_p),
+                ("cross_rel_bias", C.c_void_p), ("final_ln", C.c_void_p), ("layers", C.POINTER(GdrT5DecLayer)),
+                ("alayers", C.POINTER(GdrAdaptorLayer)), ("head_w", C.c_void_p), ("head_e", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/gdr_hip.h
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 SIGNATURES = {
@@ -47,6 +65,11 @@ SIGNATURES = {
     "gdr_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "gdr_rerank_topk": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "gdr_t5_relative_bucket_table": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
+    "gdr_t5_generate_workspace_bytes": (_sz, [C.POINTER(GdrT5DecoderWeights), _i, _i, _i, _i]),
+    "gdr_t5_generate": (_i, [C.POINTER(GdrT5DecoderWeights), _vp, _vp, _i, _i, _i, _i, C.c_double, _i, _vp, _vp, _vp,
+                             _vp, _vp, _vp, _sz, _vp]),
+    "gdr_beam_search_table_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "gdr_beam_search_table": (_i, [_vp, _i, _i, _i, _i, C.c_double, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,617 @@
+// Docid beam decode on gfx950 — device-resident replacement of the reference's generate() hot loop
+// (GDR_model/transformers/generation_utils.py:629-921 + BeamHypotheses :1052-1099, driving
+//  T5ForConditionalGeneration.forward's decode branch, transformers/modeling_t5.py:1529-1646).
+//
+// What changes relative to the reference (arithmetic per produced number is the same):
+//   * use_cache=False recomputes the whole prefix every step; here every layer's K/V rows are written once per
+//     position into a [Tmax][rows][3*width] cache and beams reach their ancestors' rows through an int32 table
+//     (`kv_rows`) that the beam-update kernel rewrites each step — no cache reordering copies, no recompute.
+//   * cross-attention K/V are projected once per QUERY (beams share them: kv_group = num_beams) instead of once
+//     per beam row per step (generation_utils.py:459-461 expands the encoder states to B*beams rows).
+//   * the adaptor's cross-attention over a single learned key (modeling_t5.py:1628-1631) is the constant
+//     out_proj(v_proj(adaptor_embeddings)) — softmax over one key is exactly 1 — precomputed at load time.
+//   * the adaptor_linear head (modeling_t5.py:1634-1639: [R*t,768]x[768,768*302] + a [R,t,768,302] broadcast add)
+//     is evaluated for the last position and its V+1 unmasked columns only: one GEMM against a re-laid weight
+//     slice [V+1][d][d] and a fused dot kernel; masked columns are exactly -1e9 either way.
+//   * beam bookkeeping (top-2R, EOS handling, BeamHypotheses.add/is_done, finalisation) runs in three small
+//     kernels per step with no host round trip; the reference syncs per candidate through .item().
+#include <math.h>
+
+#include "layers.h"
+
+namespace gdr {
+
+constexpr int PAD_ID = 0, EOS_ID = 1, START_ID = 0;
+constexpr int MAXLEN_CAP = 32;
+
+struct BeamBufs {
+  int32_t* seq[2];      // [rows][maxlen] token history, double buffered
+  float* beam_scores;   // [rows]
+  int64_t* cur_tok;     // [rows] last token of each row (embedding input of the step)
+  int32_t* parent;      // [rows] row of the previous step that each row extends
+  int32_t* anc[2];      // [rows][maxlen] row whose cache slot holds position p of this row's prefix
+  int32_t* kv_rows;     // [rows][s+1] absolute cache row = p*rows + anc
+  float* logits;        // [rows][V+1] unmasked-column logits of the step
+  float* cand_score;    // [B][2R]
+  int32_t* cand_idx;    // [B][2R]  beam*Vd + token
+  double* hyp_score;    // [B][R+1]
+  int32_t* hyp_len;     // [B][R+1]
+  int32_t* hyp_tok;     // [B][R+1][maxlen]
+  int32_t* hyp_cnt;     // [B]
+  double* hyp_worst;    // [B]
+  int32_t* done;        // [B]
+};
+
+struct BeamDims {
+  int B, R, V, Vd, maxlen, nret;
+  double lp;
+};
+
+static size_t carve(size_t& o, size_t bytes) {
+  const size_t at = o;
+  o += align_up(bytes, 256);
+  return at;
+}
+
+static size_t beam_layout(const BeamDims& bd, char* base, BeamBufs* bb) {
+  const size_t rows = (size_t)bd.B * bd.R, ml = bd.maxlen, V1 = bd.V + 1;
+  size_t o = 0;
+#define CARVE(field, type, count)                                       \
+  do {                                                                  \
+    const size_t at__ = carve(o, sizeof(type) * (count));               \
+    if (bb) bb->field = reinterpret_cast<type*>(base + at__);           \
+  } while (0)
+  CARVE(seq[0], int32_t, rows * ml);
+  CARVE(seq[1], int32_t, rows * ml);
+  CARVE(beam_scores, float, rows);
+  CARVE(cur_tok, int64_t, rows);
+  CARVE(parent, int32_t, rows);
+  CARVE(anc[0], int32_t, rows * ml);
+  CARVE(anc[1], int32_t, rows * ml);
+  CARVE(kv_rows, int32_t, rows * ml);
+  CARVE(logits, float, rows * V1);
+  CARVE(cand_score, float, (size_t)bd.B * 2 * bd.R);
+  CARVE(cand_idx, int32_t, (size_t)bd.B * 2 * bd.R);
+  CARVE(hyp_score, double, (size_t)bd.B * (bd.R + 1));
+  CARVE(hyp_len, int32_t, (size_t)bd.B * (bd.R + 1));
+  CARVE(hyp_tok, int32_t, (size_t)bd.B * (bd.R + 1) * ml);
+  CARVE(hyp_cnt, int32_t, bd.B);
+  CARVE(hyp_worst, double, bd.B);
+  CARVE(done, int32_t, bd.B);
+#undef CARVE
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------ kernels
+__global__ void beam_init_kernel(BeamBufs bb, BeamDims bd) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int rows = bd.B * bd.R;
+  if (r < rows) {
+    bb.seq[0][(size_t)r * bd.maxlen] = START_ID;
+    bb.beam_scores[r] = (r % bd.R == 0) ? 0.f : -1e9f;  // generation_utils.py:663-668
+    bb.cur_tok[r] = START_ID;
+    bb.parent[r] = r;
+    bb.anc[0][(size_t)r * bd.maxlen] = r;
+    bb.kv_rows[r] = r;  // step 0: stride 1, position 0
+  }
+  if (r < bd.B) {
+    bb.hyp_cnt[r] = 0;
+    bb.hyp_worst[r] = 1e9;  // :1062
+    bb.done[r] = 0;
+  }
+}
+
+__device__ __forceinline__ uint32_t dfkey(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dfkey_inv(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// logits[r][c] = sum_i (h[r][i] * d^-0.5) * (A[r][c*d + i] + E[c][i])      (modeling_t5.py:1575-1576,1637-1639)
+__global__ __launch_bounds__(256) void head_logits_kernel(const float* __restrict__ h, const float* __restrict__ A,
+                                                          const float* __restrict__ E, int rows, int V1, int d,
+                                                          float scale, float* __restrict__ logits) {
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (int64_t)rows * V1) return;
+  const int r = (int)(item / V1), c = (int)(item % V1), lane = threadIdx.x & 63;
+  const float4* h4 = reinterpret_cast<const float4*>(h + (size_t)r * d);
+  const float4* a4 = reinterpret_cast<const float4*>(A + ((size_t)r * V1 + c) * d);
+  const float4* e4 = reinterpret_cast<const float4*>(E + (size_t)c * d);
+  float acc = 0.f;
+  for (int i = lane; i < d / 4; i += 64) {
+    const float4 hv = h4[i], av = a4[i], ev = e4[i];
+    acc = fmaf(hv.x * scale, av.x + ev.x, acc);
+    acc = fmaf(hv.y * scale, av.y + ev.y, acc);
+    acc = fmaf(hv.z * scale, av.z + ev.z, acc);
+    acc = fmaf(hv.w * scale, av.w + ev.w, acc);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) logits[item] = acc;
+}
+
+// Teacher forcing: logits[r][c] = table[b][pos][last_token][token(pos,c)]
+__global__ void table_logits_kernel(const float* __restrict__ table, const int64_t* __restrict__ cur_tok, int rows,
+                                    int R, int V, int Vd, int maxlen, int pos, float* __restrict__ logits) {
+  const int item = blockIdx.x * blockDim.x + threadIdx.x;
+  const int V1 = V + 1;
+  if (item >= rows * V1) return;
+  const int r = item / V1, c = item % V1, b = r / R;
+  const int tok = c < V ? pos * V + 2 + c : EOS_ID;
+  logits[item] = table[(((size_t)b * maxlen + pos) * Vd + (size_t)cur_tok[r]) * Vd + tok];
+}
+
+// Per query: log_softmax of every beam's row (masked columns contribute exp(-1e9 - max) = 0 exactly), add the
+// beam score, take the 2R best of the R*(V+1) unmasked candidates, sorted (generation_utils.py:698,766-775).
+__global__ __launch_bounds__(256) void beam_topk_kernel(BeamBufs bb, BeamDims bd, int pos, int npad,
+                                                        float* __restrict__ step_scores,
+                                                        int32_t* __restrict__ step_tokens) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [npad]
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int R = bd.R, V1 = bd.V + 1;
+  float* lse_max = reinterpret_cast<float*>(keys + npad);  // [R]
+  float* lse_log = lse_max + R;                            // [R]
+  for (int j = wave; j < R; j += 4) {
+    const float* lg = bb.logits + ((size_t)b * R + j) * V1;
+    float mx = -INFINITY;
+    for (int c = lane; c < V1; c += 64) mx = fmaxf(mx, lg[c]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sm = 0.f;
+    for (int c = lane; c < V1; c += 64) sm += expf(lg[c] - mx);
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+    if (lane == 0) {
+      lse_max[j] = mx;
+      lse_log[j] = logf(sm);
+    }
+  }
+  __syncthreads();
+  const int ncand = R * V1;
+  for (int e = tid; e < npad; e += 256) {
+    unsigned long long key = 0ull;
+    if (e < ncand) {
+      const int j = e / V1, c = e - j * V1;
+      const float logp = (bb.logits[((size_t)b * R + j) * V1 + c] - lse_max[j]) - lse_log[j];
+      const float s = logp + bb.beam_scores[(size_t)b * R + j];
+      const int tok = c < bd.V ? pos * bd.V + 2 + c : EOS_ID;
+      const uint32_t flat = (uint32_t)(j * bd.Vd + tok);
+      key = ((unsigned long long)dfkey(s) << 32) | (unsigned long long)(0xFFFFFFFFu - flat);
+    }
+    keys[e] = key;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (npad >> 1); t += 256) {
+        const int lo = (t / stride) * (stride << 1) + (t % stride), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long x = keys[lo], y = keys[hi];
+        if ((x < y) == desc) {
+          keys[lo] = y;
+          keys[hi] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < 2 * R; i += 256) {
+    const unsigned long long key = keys[i];
+    const float s = dfkey_inv((uint32_t)(key >> 32));
+    const int32_t flat = (int32_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+    bb.cand_score[(size_t)b * 2 * R + i] = s;
+    bb.cand_idx[(size_t)b * 2 * R + i] = flat;
+    if (step_scores) {
+      step_scores[(size_t)b * 2 * R + i] = s;
+      step_tokens[(size_t)b * 2 * R + i] = flat;
+    }
+  }
+}
+
+// BeamHypotheses.add (generation_utils.py:1070-1084); Python-float arithmetic = double.
+__device__ void hyp_add(const BeamBufs& bb, const BeamDims& bd, int b, const int32_t* toks, int len, double sum_logp) {
+  const int cap = bd.R + 1;
+  double* sc = bb.hyp_score + (size_t)b * cap;
+  int32_t* ln = bb.hyp_len + (size_t)b * cap;
+  int32_t* tk = bb.hyp_tok + (size_t)b * cap * bd.maxlen;
+  int n = bb.hyp_cnt[b];
+  const double score = sum_logp / pow((double)len, bd.lp);
+  if (n < bd.R || score > bb.hyp_worst[b]) {
+    sc[n] = score;
+    ln[n] = len;
+    for (int i = 0; i < len; ++i) tk[(size_t)n * bd.maxlen + i] = toks[i];
+    ++n;
+    if (n > bd.R) {
+      // sorted([(s, idx)])[0] is removed, [1] gives the new worst score
+      int lo = 0;
+      for (int i = 1; i < n; ++i)
+        if (sc[i] < sc[lo]) lo = i;  // ties: lowest idx first, as tuple sort does
+      double second = INFINITY;
+      for (int i = 0; i < n; ++i)
+        if (i != lo && sc[i] < second) second = sc[i];
+      for (int i = lo; i + 1 < n; ++i) {  // del self.beams[idx] keeps list order
+        sc[i] = sc[i + 1];
+        ln[i] = ln[i + 1];
+        for (int t = 0; t < bd.maxlen; ++t) tk[(size_t)i * bd.maxlen + t] = tk[(size_t)(i + 1) * bd.maxlen + t];
+      }
+      --n;
+      bb.hyp_worst[b] = second;
+    } else {
+      bb.hyp_worst[b] = score < bb.hyp_worst[b] ? score : bb.hyp_worst[b];
+    }
+    bb.hyp_cnt[b] = n;
+  }
+}
+
+// The host loop of generation_utils.py:783-850, one thread per query.  cur = index of the current seq buffer.
+__global__ void beam_update_kernel(BeamBufs bb, BeamDims bd, int cur_len, int cur) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bd.B) return;
+  const int R = bd.R, ml = bd.maxlen;
+  const int32_t* seq_c = bb.seq[cur];
+  int32_t* seq_n = bb.seq[cur ^ 1];
+  if (bb.done[b]) {  // :786-794 padded batch entry
+    for (int j = 0; j < R; ++j) {
+      const int row = b * R + j;
+      bb.beam_scores[row] = 0.f;
+      bb.cur_tok[row] = PAD_ID;
+      bb.parent[row] = b * R;
+      for (int t = 0; t < cur_len; ++t) seq_n[(size_t)row * ml + t] = seq_c[(size_t)(b * R) * ml + t];
+      seq_n[(size_t)row * ml + cur_len] = PAD_ID;
+    }
+    return;
+  }
+  const float* cs = bb.cand_score + (size_t)b * 2 * R;
+  const int32_t* ci = bb.cand_idx + (size_t)b * 2 * R;
+  int n = 0;
+  for (int rank = 0; rank < 2 * R; ++rank) {
+    const int beam = ci[rank] / bd.Vd, tok = ci[rank] % bd.Vd;
+    const int eff = b * R + beam;
+    if (tok == EOS_ID) {
+      if (rank >= R) continue;  // :811-813
+      hyp_add(bb, bd, b, seq_c + (size_t)eff * ml, cur_len, (double)cs[rank]);
+    } else {
+      const int row = b * R + n;
+      bb.beam_scores[row] = cs[rank];
+      bb.cur_tok[row] = tok;
+      bb.parent[row] = eff;
+      for (int t = 0; t < cur_len; ++t) seq_n[(size_t)row * ml + t] = seq_c[(size_t)eff * ml + t];
+      seq_n[(size_t)row * ml + cur_len] = tok;
+      ++n;
+    }
+    if (n == R) break;
+  }
+  // :827-829  is_done(best_sum_logprobs = next_scores[b].max(), cur_len)
+  if (bb.hyp_cnt[b] >= R) {
+    const double cur_score = (double)cs[0] / pow((double)cur_len, bd.lp);
+    if (bb.hyp_worst[b] >= cur_score) bb.done[b] = 1;
+  }
+}
+
+// Rebuild the ancestor table for the position about to be processed (pos = new row length - 1).
+__global__ void anc_update_kernel(BeamBufs bb, int rows, int maxlen, int pos, int cur) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int stride = pos + 1;
+  if (e >= rows * stride) return;
+  const int r = e / stride, p = e - r * stride;
+  const int a = p < pos ? bb.anc[cur][(size_t)bb.parent[r] * maxlen + p] : r;
+  bb.anc[cur ^ 1][(size_t)r * maxlen + p] = a;
+  bb.kv_rows[(size_t)r * stride + p] = p * rows + a;
+}
+
+// :862-919 finalise open beams, pick the nret best per query, lay out tokens / EOS / PAD.
+__global__ void beam_finalize_kernel(BeamBufs bb, BeamDims bd, int final_len, int cur, int max_length,
+                                     int64_t* out_ids, int32_t* out_len, double* out_scores) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bd.B) return;
+  const int R = bd.R, ml = bd.maxlen, cap = R + 1;
+  if (!bb.done[b]) {
+    for (int j = 0; j < R; ++j) {
+      const int row = b * R + j;
+      hyp_add(bb, bd, b, bb.seq[cur] + (size_t)row * ml, final_len, (double)bb.beam_scores[row]);
+    }
+  }
+  double* sc = bb.hyp_score + (size_t)b * cap;
+  const int32_t* ln = bb.hyp_len + (size_t)b * cap;
+  const int32_t* tk = bb.hyp_tok + (size_t)b * cap * ml;
+  const int n = bb.hyp_cnt[b];
+  // sorted(beams, key=score) is stable ascending; pop() takes the last: among equal scores the later entry first
+  unsigned long long taken_lo = 0ull, taken_hi[4] = {0ull, 0ull, 0ull, 0ull};  // up to 320 entries
+  for (int j = 0; j < bd.nret; ++j) {
+    int best = -1;
+    for (int i = 0; i < n; ++i) {
+      const bool tk_ = i < 64 ? ((taken_lo >> i) & 1ull) : ((taken_hi[(i - 64) >> 6] >> ((i - 64) & 63)) & 1ull);
+      if (tk_) continue;
+      if (best < 0 || sc[i] >= sc[best]) best = i;
+    }
+    const size_t o = (size_t)b * bd.nret + j;
+    if (best < 0) {  // fewer hypotheses than requested: cannot happen when V^depth >= R (reference would raise)
+      out_len[o] = 0;
+      out_scores[o] = -INFINITY;
+      for (int t = 0; t < max_length; ++t) out_ids[o * max_length + t] = PAD_ID;
+      continue;
+    }
+    if (best < 64) taken_lo |= 1ull << best; else taken_hi[(best - 64) >> 6] |= 1ull << ((best - 64) & 63);
+    const int len = ln[best];
+    out_len[o] = len;
+    out_scores[o] = sc[best];
+    for (int t = 0; t < max_length; ++t) {
+      int64_t v = PAD_ID;
+      if (t < len) v = tk[(size_t)best * ml + t];
+      else if (t == len) v = EOS_ID;  // :915-916 (len < max_length)
+      out_ids[o * max_length + t] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ driver pieces
+static int next_pow2i(int x) {
+  int p = 64;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+static int check_beam_dims(const BeamDims& bd, int max_length) {
+  GDR_CHECK_ARG(bd.B > 0 && bd.R >= 2 && bd.R <= 256, "beam: B=%d num_beams=%d (need 2..256)", bd.B, bd.R);
+  GDR_CHECK_ARG(bd.nret >= 1 && bd.nret <= bd.R, "beam: num_return_sequences=%d must be in [1,num_beams]", bd.nret);
+  GDR_CHECK_ARG(max_length >= 2 && max_length <= MAXLEN_CAP, "beam: max_length=%d must be in [2,%d]", max_length,
+                MAXLEN_CAP);
+  GDR_CHECK_ARG(bd.V >= 1 && bd.Vd >= bd.V * (max_length - 1) + 2, "beam: decode vocab %d too small for V=%d, max_length=%d",
+                bd.Vd, bd.V, max_length);
+  GDR_CHECK_ARG(bd.R * (bd.V + 1) <= 8192, "beam: num_beams*(V+1)=%d exceeds the 8192-entry sort buffer", bd.R * (bd.V + 1));
+  GDR_CHECK_ARG(bd.lp > 0.0, "beam: length_penalty must be > 0");
+  return GDR_OK;
+}
+
+// One decode step's beam machinery after bb.logits holds the step's unmasked-column logits.
+static int beam_step(const BeamBufs& bb, const BeamDims& bd, int pos, int cur, float* step_scores,
+                     int32_t* step_tokens, hipStream_t stream) {
+  const int rows = bd.B * bd.R;
+  const int npad = next_pow2i(bd.R * (bd.V + 1));
+  const size_t lds = (size_t)npad * 8 + (size_t)bd.R * 8;
+  const size_t tr = (size_t)pos * bd.B * 2 * bd.R;
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(bd.B), dim3(256), lds, stream, bb, bd, pos, npad,
+                     step_scores ? step_scores + tr : nullptr, step_tokens ? step_tokens + tr : nullptr);
+  GDR_CHECK_LAUNCH("beam_topk_kernel");
+  hipLaunchKernelGGL(beam_update_kernel, dim3((bd.B + 63) / 64), dim3(64), 0, stream, bb, bd, pos + 1, cur);
+  GDR_CHECK_LAUNCH("beam_update_kernel");
+  const int n = rows * (pos + 2);
+  hipLaunchKernelGGL(anc_update_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, bb, rows, bd.maxlen, pos + 1, cur);
+  GDR_CHECK_LAUNCH("anc_update_kernel");
+  return GDR_OK;
+}
+
+static int beam_begin(const BeamBufs& bb, const BeamDims& bd, hipStream_t stream) {
+  const int rows = bd.B * bd.R;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_topk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) {
+      set_error("beam: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return GDR_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(beam_init_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, bb, bd);
+  GDR_CHECK_LAUNCH("beam_init_kernel");
+  return GDR_OK;
+}
+
+static int beam_end(const BeamBufs& bb, const BeamDims& bd, int max_length, int cur, int64_t* out_ids,
+                    int32_t* out_len, double* out_scores, hipStream_t stream) {
+  hipLaunchKernelGGL(beam_finalize_kernel, dim3((bd.B + 63) / 64), dim3(64), 0, stream, bb, bd, max_length, cur,
+                     max_length, out_ids, out_len, out_scores);
+  GDR_CHECK_LAUNCH("beam_finalize_kernel");
+  return GDR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ model workspace
+struct GenWs {
+  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, total;
+};
+
+static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
+  GenWs g{};
+  const GdrT5Dims& dm = w.dims;
+  const size_t rows = (size_t)bd.B * bd.R, d = dm.d_model, inner = (size_t)dm.num_heads * dm.d_kv;
+  const size_t tmax = bd.maxlen;
+  size_t o = 0;
+  g.beam = carve(o, beam_layout(bd, nullptr, nullptr));
+  g.dcache = carve(o, 4 * (size_t)dm.num_layers * tmax * rows * 3 * inner);
+  g.acache = carve(o, 4 * (size_t)w.adaptor_layers * tmax * rows * 3 * d);
+  g.crosskv = carve(o, 4 * (size_t)dm.num_layers * bd.B * L * 2 * inner);
+  g.xd = carve(o, 4 * rows * d);
+  g.xa = carve(o, 4 * rows * d);
+  g.nx = carve(o, 4 * rows * d);
+  g.ctx = carve(o, 4 * rows * (inner > d ? inner : d));
+  g.qc = carve(o, 4 * rows * inner);
+  const size_t ffw = (size_t)(dm.d_ff > w.adaptor_ff ? dm.d_ff : w.adaptor_ff);
+  g.ff = carve(o, 4 * rows * ffw);
+  g.tmp = carve(o, 4 * rows * d);
+  g.A = carve(o, 4 * rows * (size_t)(bd.V + 1) * d);
+  g.hl = carve(o, 4 * rows * d);
+  g.total = o;
+  return g;
+}
+
+}  // namespace gdr
+
+extern "C" size_t gdr_t5_generate_workspace_bytes(const GdrT5DecoderWeights* w, int B, int L, int num_beams,
+                                                  int max_length) {
+  if (!w || B <= 0 || L <= 0 || num_beams <= 0 || max_length < 2) return 0;
+  gdr::BeamDims bd{B, num_beams, w->out_vocab, w->dims.vocab_size, max_length, num_beams, 1.0};
+  return gdr::gen_ws(*w, bd, L).total;
+}
+
+extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B,
+                               int L, int num_beams, int max_length, double length_penalty,
+                               int num_return_sequences, int64_t* out_ids, int32_t* out_len, double* out_scores,
+                               float* step_scores, int32_t* step_tokens, void* workspace, size_t workspace_bytes,
+                               void* stream_) {
+  using namespace gdr;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GDR_CHECK_ARG(w && enc_hidden && enc_mask && out_ids && out_len && out_scores && workspace, "generate: null pointer");
+  const GdrT5Dims& dm = w->dims;
+  BeamDims bd{B, num_beams, w->out_vocab, dm.vocab_size, max_length, num_return_sequences, length_penalty};
+  int rc = check_beam_dims(bd, max_length);
+  if (rc) return rc;
+  GDR_CHECK_ARG(L >= 1 && L <= 128, "generate: L=%d must be in [1,128]", L);
+  GDR_CHECK_ARG(max_length <= w->max_out_len, "generate: max_length=%d > max_output_length=%d of the head", max_length,
+                w->max_out_len);
+  GDR_CHECK_ARG(dm.d_model % 4 == 0 && dm.d_kv % 4 == 0 && dm.d_model % w->adaptor_nhead == 0 &&
+                    (dm.d_model / w->adaptor_nhead) % 4 == 0,
+                "generate: unsupported dims");
+  GDR_CHECK_ARG(w->dec_embed && w->self_rel_bias && w->cross_rel_bias && w->final_ln && w->layers && w->alayers &&
+                    w->head_w && w->head_e,
+                "generate: null weight pointer");
+  const GenWs g = gen_ws(*w, bd, L);
+  if (workspace_bytes < g.total) {
+    set_error("generate: workspace %zu < required %zu", workspace_bytes, g.total);
+    return GDR_ENOSPC;
+  }
+  GDR_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "generate: workspace must be 256-byte aligned");
+  char* base = static_cast<char*>(workspace);
+  BeamBufs bb{};
+  beam_layout(bd, base + g.beam, &bb);
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+  float *dcache = F(g.dcache), *acache = F(g.acache), *crosskv = F(g.crosskv), *xd = F(g.xd), *xa = F(g.xa),
+        *nx = F(g.nx), *ctx = F(g.ctx), *qc = F(g.qc), *ff = F(g.ff), *tmp = F(g.tmp), *A = F(g.A), *hl = F(g.hl);
+  const int d = dm.d_model, H = dm.num_heads, dk = dm.d_kv, inner = H * dk;
+  const int rows = B * num_beams, V1 = bd.V + 1;
+  const int aH = w->adaptor_nhead, ahd = d / aH, aff = w->adaptor_ff;
+  const size_t dslab = (size_t)rows * 3 * inner;  // one position of one decoder layer's cache
+  const size_t aslab = (size_t)rows * 3 * d;
+  const size_t dlayer = (size_t)max_length * dslab, alayer = (size_t)max_length * aslab;
+  const size_t ckv_layer = (size_t)B * L * 2 * inner;
+
+#define GDR_TRY(x)        \
+  do {                    \
+    if ((rc = (x))) return rc; \
+  } while (0)
+
+  GDR_TRY(beam_begin(bb, bd, stream));
+  // cross-attention K/V once per query and layer (modeling_t5.py:365-368 recomputes them per beam row per step)
+  for (int l = 0; l < dm.num_layers; ++l)
+    GDR_TRY(launch_linear_f32(enc_hidden, d, w->layers[l].wkv_c, d, crosskv + l * ckv_layer, 2 * inner, (int64_t)B * L,
+                              2 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0, stream));
+
+  const BucketLut lut_uni = make_bucket_lut(dm.rel_buckets, dm.rel_max_distance);
+  const BucketLut lut_bi = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
+  int cur = 0;
+  for (int s = 0; s + 1 < max_length; ++s) {  // position s, cur_len = s + 1 (generation_utils.py:676)
+    GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows, d, dm.vocab_size, xd, stream));
+    GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows, d, dm.vocab_size, xa, stream));
+    // ---------------- T5 decoder stack (modeling_t5.py:498-584, 685-821)
+    for (int l = 0; l < dm.num_layers; ++l) {
+      const GdrT5DecLayer& ly = w->layers[l];
+      float* cache = dcache + l * dlayer;
+      float* slot = cache + s * dslab;
+      GDR_TRY(launch_rmsnorm(xd, ly.ln_self, nx, rows, d, dm.eps, nullptr, 1, stream));
+      GDR_TRY(launch_linear_f32(nx, d, ly.wqkv, d, slot, 3 * inner, rows, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0,
+                                stream));
+      AttnArgs at{};
+      at.q = slot, at.k = cache + inner, at.v = cache + 2 * inner, at.out = ctx;
+      at.ldq = at.ldk = at.ldv = 3 * inner, at.ldo = inner;
+      at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
+      at.B = rows, at.H = H, at.dk = dk, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s, at.scale = 1.0f;
+      at.rel_bias = w->self_rel_bias, at.bidirectional = 0, at.num_buckets = dm.rel_buckets, at.lut = lut_uni;
+      at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 0;
+      at.kv_rows = bb.kv_rows, at.kv_group = 1;
+      GDR_TRY(launch_attention(at, stream));
+      GDR_TRY(launch_linear_f32(ctx, inner, ly.wo, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, stream));
+      // cross attention over the encoder states of the row's query
+      GDR_TRY(launch_rmsnorm(xd, ly.ln_cross, nx, rows, d, dm.eps, nullptr, 1, stream));
+      GDR_TRY(launch_linear_f32(nx, d, ly.wq_c, d, qc, inner, rows, inner, d, GDR_EPI_NONE, nullptr, nullptr, 0, stream));
+      AttnArgs ca{};
+      const float* ckv = crosskv + l * ckv_layer;
+      ca.q = qc, ca.k = ckv, ca.v = ckv + inner, ca.out = ctx;
+      ca.ldq = inner, ca.ldk = ca.ldv = 2 * inner, ca.ldo = inner;
+      ca.q_bstride = 1, ca.k_bstride = L, ca.o_bstride = 1;
+      ca.B = rows, ca.H = H, ca.dk = dk, ca.Lq = 1, ca.Lk = L, ca.q_pos0 = s, ca.scale = 1.0f;
+      ca.rel_bias = w->cross_rel_bias, ca.bidirectional = 1, ca.num_buckets = dm.rel_buckets, ca.lut = lut_bi;
+      ca.key_mask = enc_mask, ca.mask_bstride = L, ca.causal = 0, ca.causal_neg_inf = 0;
+      ca.kv_rows = nullptr, ca.kv_group = num_beams;
+      GDR_TRY(launch_attention(ca, stream));
+      GDR_TRY(launch_linear_f32(ctx, inner, ly.wo_c, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, stream));
+      GDR_TRY(launch_rmsnorm(xd, ly.ln_ff, nx, rows, d, dm.eps, nullptr, 1, stream));
+      GDR_TRY(launch_linear_f32(nx, d, ly.wi, d, ff, dm.d_ff, rows, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0, stream));
+      GDR_TRY(launch_linear_f32(ff, dm.d_ff, ly.wo_ff, dm.d_ff, xd, d, rows, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, xd, d,
+                                stream));
+    }
+    GDR_TRY(launch_rmsnorm(xd, w->final_ln, hl, rows, d, dm.eps, nullptr, 1, stream));
+    // ---------------- adaptor: post-LN nn.TransformerDecoder over decode_embeddings(ids) (modeling_t5.py:1615-1633)
+    for (int l = 0; l < w->adaptor_layers; ++l) {
+      const GdrAdaptorLayer& al = w->alayers[l];
+      float* cache = acache + l * alayer;
+      float* slot = cache + s * aslab;
+      GDR_TRY(launch_linear_f32(xa, d, al.in_w, d, slot, 3 * d, rows, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0, stream));
+      AttnArgs at{};
+      at.q = slot, at.k = cache + d, at.v = cache + 2 * d, at.out = ctx;
+      at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
+      at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
+      at.B = rows, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
+      at.scale = 1.0f / sqrtf((float)ahd);
+      at.rel_bias = nullptr, at.bidirectional = 0, at.num_buckets = 0, at.lut = lut_uni;
+      at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
+      at.kv_rows = bb.kv_rows, at.kv_group = 1;
+      GDR_TRY(launch_attention(at, stream));
+      GDR_TRY(launch_linear_f32(ctx, d, al.out_w, d, tmp, d, rows, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d, stream));
+      GDR_TRY(launch_layernorm(tmp, al.ln1_w, al.ln1_b, xa, rows, d, w->adaptor_eps, nullptr, stream));
+      GDR_TRY(launch_layernorm(xa, al.ln2_w, al.ln2_b, tmp, rows, d, w->adaptor_eps, al.cross_const, stream));
+      GDR_TRY(launch_linear_f32(tmp, d, al.lin1_w, d, ff, aff, rows, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0, stream));
+      GDR_TRY(launch_linear_f32(ff, aff, al.lin2_w, aff, xa, d, rows, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d, stream));
+      GDR_TRY(launch_layernorm(xa, al.ln3_w, al.ln3_b, xa, rows, d, w->adaptor_eps, nullptr, stream));
+    }
+    // ---------------- head: last position, unmasked columns only (modeling_t5.py:1634-1646)
+    const float* hw = w->head_w + (size_t)s * V1 * d * d;
+    const float* he = w->head_e + (size_t)s * V1 * d;
+    GDR_TRY(launch_linear_f32(xa, d, hw, d, A, (int64_t)V1 * d, rows, V1 * d, d, GDR_EPI_NONE, nullptr, nullptr, 0, stream));
+    {
+      const int64_t items = (int64_t)rows * V1;
+      hipLaunchKernelGGL(head_logits_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, hl, A, he, rows, V1, d,
+                         1.0f / sqrtf((float)d), bb.logits);
+      GDR_CHECK_LAUNCH("head_logits_kernel");
+    }
+    GDR_TRY(beam_step(bb, bd, s, cur, step_scores, step_tokens, stream));
+    cur ^= 1;
+  }
+  return beam_end(bb, bd, max_length, cur, out_ids, out_len, out_scores, stream);
+#undef GDR_TRY
+}
+
+extern "C" size_t gdr_beam_search_table_workspace_bytes(int B, int num_beams, int max_length, int out_vocab) {
+  if (B <= 0 || num_beams <= 0 || max_length < 2) return 0;
+  gdr::BeamDims bd{B, num_beams, out_vocab, out_vocab * max_length + 2, max_length, num_beams, 1.0};
+  return gdr::beam_layout(bd, nullptr, nullptr);
+}
+
+extern "C" int gdr_beam_search_table(const float* table, int B, int out_vocab, int num_beams, int max_length,
+                                     double length_penalty, int num_return_sequences, int64_t* out_ids,
+                                     int32_t* out_len, double* out_scores, void* workspace, size_t workspace_bytes,
+                                     void* stream_) {
+  using namespace gdr;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GDR_CHECK_ARG(table && out_ids && out_len && out_scores && workspace, "beam_search_table: null pointer");
+  BeamDims bd{B, num_beams, out_vocab, out_vocab * max_length + 2, max_length, num_return_sequences, length_penalty};
+  int rc = check_beam_dims(bd, max_length);
+  if (rc) return rc;
+  const size_t need = beam_layout(bd, nullptr, nullptr);
+  if (workspace_bytes < need) {
+    set_error("beam_search_table: workspace %zu < required %zu", workspace_bytes, need);
+    return GDR_ENOSPC;
+  }
+  BeamBufs bb{};
+  beam_layout(bd, static_cast<char*>(workspace), &bb);
+  if ((rc = beam_begin(bb, bd, stream))) return rc;
+  const int rows = B * num_beams, V1 = out_vocab + 1;
+  int cur = 0;
+  for (int s = 0; s + 1 < max_length; ++s) {
+    const int n = rows * V1;
+    hipLaunchKernelGGL(table_logits_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, table, bb.cur_tok, rows,
+                       num_beams, out_vocab, bd.Vd, max_length, s, bb.logits);
+    GDR_CHECK_LAUNCH("table_logits_kernel");
+    if ((rc = beam_step(bb, bd, s, cur, nullptr, nullptr, stream))) return rc;
+    cur ^= 1;
+  }
+  return beam_end(bb, bd, max_length, cur, out_ids, out_len, out_scores, stream);
+}

@@ -74,6 +74,7 @@ extern "C" int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_
   at.rel_bias = w->rel_bias, at.bidirectional = 1, at.num_buckets = dm.rel_buckets;
   at.lut = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
   at.key_mask = mask, at.mask_bstride = L, at.causal = 0, at.causal_neg_inf = 0;
+  at.kv_rows = nullptr, at.kv_group = 1;
 
   for (int i = 0; i < dm.num_layers; ++i) {
     const GdrT5EncLayer& ly = w->layers[i];

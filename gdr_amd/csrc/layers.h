@@ -29,6 +29,9 @@ struct AttnArgs {
   int64_t mask_bstride;        // elements between batch entries of key_mask
   int causal;                  // key j allowed iff j <= q_pos0 + i  -> adds -1e9 otherwise (neg_inf: -inf)
   int causal_neg_inf;          // nn.Transformer masks use -inf (modeling_t5.py:1622-1627)
+  // decode-time K/V sources (defaults: kv_rows = null, kv_group = 1)
+  const int32_t* kv_rows;      // int32 [B, Lk]: absolute row of key j of batch entry b in k/v (beam-ancestor cache)
+  int kv_group;                // batch entries sharing one K/V block: K/V batch index = b / kv_group (beams of a query)
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 
@@ -39,7 +42,8 @@ int launch_embed(const float* table, const int64_t* ids, int64_t rows, int d, in
 int launch_rmsnorm(const float* x, const float* w, float* y, int64_t rows, int d, float eps, float* pooled,
                    int pool_every, hipStream_t stream);
 // y = (x - mean) / sqrt(var + eps) * w + b   (torch.nn.LayerNorm; BERT / nn.TransformerDecoderLayer)
+// optional addv [d]: y = LN(x + addv)  (the adaptor's constant single-key cross-attention output)
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int d, float eps,
-                     hipStream_t stream);
+                     const float* addv, hipStream_t stream);
 
 }  // namespace gdr

@@ -102,21 +102,31 @@ int launch_rmsnorm(const float* x, const float* w, float* y, int64_t rows, int d
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y,
-                                                        int64_t rows, int d4, float eps) {
+                                                        int64_t rows, int d4, float eps,
+                                                        const float* __restrict__ addv) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   const float4* xr = reinterpret_cast<const float4*>(x) + row * d4;
   const float inv_d = 1.0f / (float)(d4 * 4);
+  const float4* av = reinterpret_cast<const float4*>(addv);
+  auto ld = [&](int c) {
+    float4 v = xr[c];
+    if (av) {
+      const float4 t = av[c];
+      v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+    }
+    return v;
+  };
   float s = 0.f;
   for (int c = lane; c < d4; c += 64) {
-    const float4 v = xr[c];
+    const float4 v = ld(c);
     s += v.x + v.y + v.z + v.w;
   }
   const float mean = wave_sum(s) * inv_d;
   float ss = 0.f;
   for (int c = lane; c < d4; c += 64) {
-    const float4 v = xr[c];
+    const float4 v = ld(c);
     const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
     ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
   }
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const float4* wr = reinterpret_cast<const float4*>(w);
   const float4* br = reinterpret_cast<const float4*>(b);
   for (int c = lane; c < d4; c += 64) {
-    const float4 v = xr[c], g = wr[c], bb = br[c];
+    const float4 v = ld(c), g = wr[c], bb = br[c];
     float4 o;
     o.x = (v.x - mean) * rstd * g.x + bb.x, o.y = (v.y - mean) * rstd * g.y + bb.y;
     o.z = (v.z - mean) * rstd * g.z + bb.z, o.w = (v.w - mean) * rstd * g.w + bb.w;
@@ -134,11 +144,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int d, float eps,
-                     hipStream_t stream) {
+                     const float* addv, hipStream_t stream) {
   GDR_CHECK_ARG(d % 4 == 0, "layernorm: d %% 4 != 0");
   if (rows == 0) return GDR_OK;
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, b, y, rows, d / 4,
-                     eps);
+                     eps, addv);
   GDR_CHECK_LAUNCH("layernorm_kernel");
   return GDR_OK;
 }
@@ -158,9 +168,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   float* Ps = Qs + 4 * dk;     // [4][Lkp]
   float* Bs = Ps + 4 * Lkp;    // [num_buckets]
   const int tid = threadIdx.x;
+  const int kb = b / a.kv_group;
   for (int e = tid; e < Lk * c4; e += 256) {
     const int j = e / c4, c = e - j * c4;
-    const int64_t rk = (int64_t)b * a.k_bstride + j;
+    const int64_t rk = a.kv_rows ? (int64_t)a.kv_rows[(int64_t)b * Lk + j] : (int64_t)kb * a.k_bstride + j;
     *reinterpret_cast<float4*>(Ks + j * dks + 4 * c) =
         *reinterpret_cast<const float4*>(a.k + rk * a.ldk + h * dk + 4 * c);
     *reinterpret_cast<float4*>(Vs + j * dks + 4 * c) =
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
           }
           bool allowed = true;
           if (a.causal) allowed = j <= i_abs;
-          if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)b * a.mask_bstride + j] != 0);
+          if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)kb * a.mask_bstride + j] != 0);
           if (!allowed) add += masked;
           s = acc + add;
         }
@@ -265,6 +276,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   GDR_CHECK_ARG(a.Lk >= 1 && a.Lk <= 128, "attention: Lk=%d must be in [1,128]", a.Lk);
   GDR_CHECK_ARG(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0, "attention: row strides must be multiples of 4");
   GDR_CHECK_ARG(!a.rel_bias || (a.num_buckets >= 2 && a.num_buckets <= 256), "attention: bad num_buckets");
+  GDR_CHECK_ARG(a.kv_group >= 1, "attention: kv_group must be >= 1");
   if (a.B == 0 || a.Lq == 0) return GDR_OK;
   const int dks = a.dk + 4, Lkp = (a.Lk + 3) & ~3;
   const size_t lds = sizeof(float) * ((size_t)2 * a.Lk * dks + 4 * a.dk + 4 * Lkp + 256);

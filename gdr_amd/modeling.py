@@ -1,0 +1,233 @@
+"""The reference's Python call surface for the inference hot path, backed by libgdr_hip.so.
+
+Drop-in targets:
+  * `GDRModel.generate(...)`           T5ForConditionalGeneration.generate as GDR calls it
+                                       (GDR_model/main_models.py:1380-1397, main.py:171-187;
+                                        transformers/generation_utils.py:110-527)
+  * `GDRModel.get_encoder()(...)`      transformers/modeling_t5.py:1319-1320, generation_utils.py:410-411
+  * `QueryEncoder` / `EncoderModel`    GDR_model/main_models.py:79-109 (forward(query_enc=h) -> h[:,0])
+  * `DenseModel`                       GDR_model/dense.py:30-54 (encode_query / encode_passage / compute_similarity)
+  * `GDRRetriever.validation_step_i`   the two-stage retrieval of main_models.py:1337-1642 (decode -> rerank)
+There is no CPU path: every method needs CUDA (ROCm) tensors and raises if the HIP library is missing.
+"""
+import types
+
+import torch
+
+from . import _ffi, codec, ops
+from .config import GDRConfig
+
+
+class ModelOutput(dict):
+    """Minimal stand-in for transformers' BaseModelOutput: attribute + item access (file_utils.py ModelOutput)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def strip_lightning_prefix(state_dict, prefix="model."):
+    """A Lightning checkpoint's `state_dict` prefixes T5 keys with `model.` and the doc tower with `encoder.`
+    (main_models.py:794,797; main.py:121-126).  Returns the T5 part with the prefix removed."""
+    if "state_dict" in state_dict:
+        state_dict = state_dict["state_dict"]
+    if any(k.startswith(prefix + "shared.") or k.startswith(prefix + "encoder.block") for k in state_dict):
+        return {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+    return state_dict
+
+
+class _Encoder:
+    """What `model.get_encoder()` returns: callable like T5Stack.forward (modeling_t5.py:685-821)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __call__(self, input_ids=None, attention_mask=None, return_dict=True, **_ignored):
+        h, _ = self.handle.forward(input_ids, attention_mask, want_pooled=False)
+        if return_dict:
+            return ModelOutput(last_hidden_state=h, past_key_values=None, hidden_states=None, attentions=None)
+        return (h,)
+
+    forward = __call__
+
+
+class GDRModel:
+    """T5ForConditionalGeneration of the reference (GDR config: decode_embedding=2, adaptor_efficient),
+    inference only.  Construct from a reference-style state_dict (SURVEY Appendix C key names)."""
+
+    def __init__(self, cfg: GDRConfig, state_dict, device="cuda:0", with_decoder=True):
+        self.config = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _ffi.GdrError("GDRModel needs a CUDA (ROCm) device; there is no CPU path")
+        sd = strip_lightning_prefix(state_dict)
+        self.enc = ops.T5EncoderHandle(cfg, sd, self.device)
+        self.dec = ops.T5DecoderHandle(cfg, sd, self.device) if with_decoder else None
+        self.training = False
+
+    def eval(self):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    def get_encoder(self):
+        return _Encoder(self.enc)
+
+    # ------------------------------------------------------------------ generate()
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, max_length=None, num_beams=None, length_penalty=None,
+                 num_return_sequences=None, early_stopping=False, use_cache=False, do_sample=False,
+                 decode_embedding=None, decode_vocab_size=None, output_scores=False, output_encoder_embedding=False,
+                 **model_kwargs):
+        """Same kwargs / return shape as the vendored generate(): returns `(output, encoder_outputs | None)` where
+        output is `(LongTensor[B*nret, <=max_length], list[float])` with output_scores=True, else the LongTensor
+        (generation_utils.py:524-527, 918-921).  Unknown kwargs (decode_tree, decoder_index, cluster_constraint,
+        decoder_attention_mask, ...) are accepted and ignored exactly as the reference swallows them
+        (modeling_t5.py:1755)."""
+        cfg = self.config
+        if self.dec is None:
+            raise _ffi.GdrError("this GDRModel was built with with_decoder=False")
+        assert input_ids is not None, "generate() needs input_ids"
+        max_length = max_length if max_length is not None else cfg.max_output_length
+        num_beams = num_beams if num_beams is not None else 1
+        length_penalty = length_penalty if length_penalty is not None else 1.0
+        num_return_sequences = num_return_sequences if num_return_sequences is not None else 1
+        # the reference's asserts (generation_utils.py:296-324) for the arguments this path uses
+        assert isinstance(max_length, int) and max_length > 0, "`max_length` should be a strictly positive integer."
+        assert isinstance(num_beams, int) and num_beams > 0, "`num_beams` should be a strictly positive integer."
+        assert length_penalty > 0, "`length_penalty` should be strictly positive."
+        assert isinstance(num_return_sequences, int) and num_return_sequences > 0, \
+            "`num_return_sequences` should be a strictly positive integer."
+        if do_sample:
+            raise NotImplementedError("sampling is outside the GDR hot path (gen_method='greedy', main.py:299)")
+        if num_beams == 1:
+            raise NotImplementedError("GDR always decodes with num_beams = num_return_sequences > 1 (infer.sh:10-15)")
+        assert num_return_sequences <= num_beams, "num_return_sequences has to be <= num_beams for greedy beam search"
+        if decode_vocab_size is not None:
+            assert decode_vocab_size == cfg.decode_vocab_size, "decode_vocab_size does not match the loaded head"
+        assert 1 < max_length, "The context has 1 number of tokens, but `max_length` is only %d" % max_length
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        input_ids, attention_mask = input_ids.to(self.device), attention_mask.to(self.device)
+        enc_h, _ = self.enc.forward(input_ids, attention_mask, want_pooled=False)
+        ids, lens, scores = self.dec.generate(enc_h, attention_mask, num_beams, max_length, length_penalty,
+                                              num_return_sequences)
+        decoded, score_list = ops.finish_generate_output(ids, lens, scores, max_length)
+        output = (decoded, score_list) if output_scores else decoded
+        if output_encoder_embedding:
+            # the reference hands back the states already expanded per beam (generation_utils.py:459-461);
+            # callers stride them with [::num_beams] (main_models.py:1466)
+            expanded = enc_h.repeat_interleave(num_beams, dim=0)
+            return output, ModelOutput(last_hidden_state=expanded)
+        return output, None
+
+
+class EncoderModel:
+    """Query side of main_models.py:62-109: `encoder(query_enc=hidden) -> hidden[:, 0]` (CLS pool; `output` is None in
+    the reference).  The BERT/AR2 passage tower (passage=...) is SURVEY §8f "next" and not built."""
+
+    def __init__(self, output=None):
+        self.output = output
+
+    def __call__(self, passage=None, query_enc=None):
+        if passage is not None:
+            raise NotImplementedError("doc tower (DPRContextEncoder/BERT) is SURVEY §8f rank 1, not built yet")
+        return self.encode_query(query_enc)
+
+    forward = __call__
+
+    def encode_query(self, qry_hidden):
+        if qry_hidden is None:
+            return None
+        return qry_hidden[:, 0] if self.output is None else self.output(q=qry_hidden)
+
+
+class DensePooler:
+    """dense.py:10-27: rep = Linear(h[:,0]) (+ L2 normalise)."""
+
+    def __init__(self, weight_q, bias_q, weight_p=None, bias_p=None, normalize=False):
+        self.wq, self.bq = weight_q, bias_q
+        self.wp, self.bp = (weight_p if weight_p is not None else weight_q), (bias_p if bias_p is not None else bias_q)
+        self.normalize = normalize
+
+    def __call__(self, q=None, p=None):
+        if q is not None:
+            rep = ops.linear(q[:, 0].contiguous(), self.wq, epilogue=_ffi.EPI_BIAS, bias=self.bq)
+        elif p is not None:
+            rep = ops.linear(p[:, 0].contiguous(), self.wp, epilogue=_ffi.EPI_BIAS, bias=self.bp)
+        else:
+            raise ValueError
+        if self.normalize:
+            rep = torch.nn.functional.normalize(rep, dim=-1)
+        return rep
+
+
+class DenseModel:
+    """dense.py:30-54 bi-encoder contract over two callables returning `.last_hidden_state`."""
+
+    def __init__(self, lm_q, lm_p=None, pooler=None):
+        self.lm_q, self.lm_p, self.pooler = lm_q, (lm_p if lm_p is not None else lm_q), pooler
+        self._ws = None
+
+    def encode_passage(self, psg):
+        if psg is None:
+            return None
+        h = self.lm_p(**psg, return_dict=True).last_hidden_state
+        return self.pooler(p=h) if self.pooler is not None else h[:, 0]
+
+    def encode_query(self, qry):
+        if qry is None:
+            return None
+        h = self.lm_q(**qry, return_dict=True).last_hidden_state
+        return self.pooler(q=h) if self.pooler is not None else h[:, 0]
+
+    def compute_similarity(self, q_reps, p_reps):
+        """scores = q_reps @ p_reps.T (dense.py:53-54) — materialises [B,N]; prefer search() for top-k."""
+        return ops.linear(q_reps.contiguous(), p_reps.contiguous())
+
+    def search(self, q_reps, p_reps, k):
+        """compute_similarity + topk(k) fused (never writes the score matrix). Returns (values, int64 indices)."""
+        if self._ws is None:
+            self._ws = ops.Workspace(q_reps.device)
+        v, i = ops.sim_topk(q_reps.contiguous(), p_reps, k, workspace=self._ws)
+        return v, i.to(torch.int64)
+
+
+class GDRRetriever:
+    """Two-stage GDR retrieval = `T5FineTuner.validation_step_i` (main_models.py:1337-1642):
+    beam-decode cluster ids -> id_mapping lookup -> tanh(q·d) over the candidates -> + alpha*softmax(beam scores)
+    per cluster -> top-k, for every alpha in score_rate."""
+
+    def __init__(self, model: GDRModel, doc_embed, cluster_index: codec.ClusterIndex, args):
+        self.model, self.args, self.index = model, args, cluster_index
+        self.doc_embed = doc_embed                      # fp32 [N, d] resident on the GPU
+        self.encoder = EncoderModel()
+
+    @torch.no_grad()
+    def validation_step_i(self, batch, i=-1):
+        a = self.args
+        R = a.num_return_sequences
+        decode_vocab_size = a.output_vocab_size * a.max_output_length + 2
+        (outs, scores), encoder_outs = self.model.generate(
+            batch["source_ids"], attention_mask=batch["source_mask"], use_cache=False,
+            max_length=a.max_output_length, num_beams=R, length_penalty=a.length_penalty, num_return_sequences=R,
+            early_stopping=False, decode_embedding=2, decode_vocab_size=decode_vocab_size, output_scores=True,
+            output_encoder_embedding=True)
+        dec = codec.dec_2d(codec.decode_token(a, outs.cpu().numpy()), R)
+        query_embeds = self.encoder(query_enc=encoder_outs.last_hidden_state[::R]).contiguous()
+        offs, ids, max_cand = self.index.candidates(dec)
+        B = len(dec)
+        beam_scores = torch.tensor(scores, dtype=torch.float32, device=query_embeds.device).view(B, R)
+        vals, idx = ops.rerank_topk(query_embeds, self.doc_embed, offs.to(query_embeds.device),
+                                    ids.to(query_embeds.device), beam_scores, list(a.score_rate), R,
+                                    func=getattr(a, "loss_func", "tanh"), max_cand=max_cand)
+        idx_h = idx.cpu().tolist()
+        inf_index = [[[str(x) for x in idx_h[b][ai]] for ai in range(len(a.score_rate))] for b in range(B)]
+        return {"clusters": dec, "inf_result_batch_prob": scores, "inf_index_batch": inf_index,
+                "rerank_values": vals}

@@ -159,3 +159,130 @@ class T5EncoderHandle:
         check(lib().gdr_t5_encoder_forward(C.byref(self.struct), ptr(ids), ptr(mask), B, L, ptr(out), ptr(pooled),
                                            ptr(ws), ws.numel(), stream_ptr()), "gdr_t5_encoder_forward")
         return out, pooled
+
+
+class T5DecoderHandle:
+    """Device-resident decoder + adaptor + head weights and the pointer table gdr_t5_generate reads.
+    Load-time re-layouts (pure data movement / weight-only algebra, done once):
+      * q,k,v of self-attention row-concatenated; k,v of cross-attention row-concatenated;
+      * adaptor_linear.weight [d*Vd, d] (= [i, c, k], modeling_t5.py:1634-1636) sliced per decode position into
+        head_w[p][c'][i][k] for the V+1 columns that survive the positional mask (modeling_t5.py:1553-1557);
+      * the adaptor's cross-attention over its single learned key folded into cross_const (softmax of one key = 1)."""
+
+    def __init__(self, cfg, sd, device):
+        self.cfg, self.device = cfg, device
+        keep = []
+
+        def dev(t):
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t
+
+        d, V, Vd, ml = cfg.d_model, cfg.output_vocab_size, cfg.decode_vocab_size, cfg.max_output_length
+        nl, na = cfg.num_decoder_layers, cfg.adaptor_layer_num
+        self.dec_embed = dev(sd["decode_embeddings.weight"])
+        self.self_rel = dev(sd["decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"])
+        self.cross_rel = dev(sd["decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight"])
+        self.final_ln = dev(sd["decoder.final_layer_norm.weight"])
+        self._layers = (_ffi.GdrT5DecLayer * nl)()
+        for i in range(nl):
+            p = f"decoder.block.{i}.layer."
+            L = self._layers[i]
+            L.ln_self = dev(sd[p + "0.layer_norm.weight"]).data_ptr()
+            L.wqkv = dev(torch.cat([sd[p + "0.SelfAttention.q.weight"], sd[p + "0.SelfAttention.k.weight"],
+                                    sd[p + "0.SelfAttention.v.weight"]], dim=0)).data_ptr()
+            L.wo = dev(sd[p + "0.SelfAttention.o.weight"]).data_ptr()
+            L.ln_cross = dev(sd[p + "1.layer_norm.weight"]).data_ptr()
+            L.wq_c = dev(sd[p + "1.EncDecAttention.q.weight"]).data_ptr()
+            L.wkv_c = dev(torch.cat([sd[p + "1.EncDecAttention.k.weight"], sd[p + "1.EncDecAttention.v.weight"]],
+                                    dim=0)).data_ptr()
+            L.wo_c = dev(sd[p + "1.EncDecAttention.o.weight"]).data_ptr()
+            L.ln_ff = dev(sd[p + "2.layer_norm.weight"]).data_ptr()
+            L.wi = dev(sd[p + "2.DenseReluDense.wi.weight"]).data_ptr()
+            L.wo_ff = dev(sd[p + "2.DenseReluDense.wo.weight"]).data_ptr()
+        mem = dev(sd["adaptor_embeddings"]).view(1, d)
+        self._alayers = (_ffi.GdrAdaptorLayer * na)()
+        aff = None
+        for i in range(na):
+            p = f"adaptor.layers.{i}."
+            A = self._alayers[i]
+            A.in_w = dev(sd[p + "self_attn.in_proj_weight"]).data_ptr()
+            A.in_b = dev(sd[p + "self_attn.in_proj_bias"]).data_ptr()
+            A.out_w = dev(sd[p + "self_attn.out_proj.weight"]).data_ptr()
+            A.out_b = dev(sd[p + "self_attn.out_proj.bias"]).data_ptr()
+            cw, cb = dev(sd[p + "multihead_attn.in_proj_weight"]), dev(sd[p + "multihead_attn.in_proj_bias"])
+            vmem = linear(mem, cw[2 * d:], epilogue=_ffi.EPI_BIAS, bias=cb[2 * d:].contiguous())
+            cc = linear(vmem, dev(sd[p + "multihead_attn.out_proj.weight"]), epilogue=_ffi.EPI_BIAS,
+                        bias=dev(sd[p + "multihead_attn.out_proj.bias"]))
+            keep.append(cc)
+            A.cross_const = cc.data_ptr()
+            for n in ("1", "2", "3"):
+                setattr(A, f"ln{n}_w", dev(sd[p + f"norm{n}.weight"]).data_ptr())
+                setattr(A, f"ln{n}_b", dev(sd[p + f"norm{n}.bias"]).data_ptr())
+            l1 = dev(sd[p + "linear1.weight"])
+            aff = l1.shape[0]
+            A.lin1_w, A.lin1_b = l1.data_ptr(), dev(sd[p + "linear1.bias"]).data_ptr()
+            A.lin2_w, A.lin2_b = dev(sd[p + "linear2.weight"]).data_ptr(), dev(sd[p + "linear2.bias"]).data_ptr()
+        # head slices
+        P = ml - 1
+        cols = torch.tensor([[p * V + 2 + c for c in range(V)] + [1] for p in range(P)], dtype=torch.long, device=device)
+        Wfull = sd["adaptor_linear.weight"].detach().to(device=device, dtype=torch.float32)
+        W = Wfull.view(d, Vd, d)
+        self.head_w = torch.empty((P, V + 1, d, d), dtype=torch.float32, device=device)
+        for p in range(P):                                   # per position: bounded temporaries
+            self.head_w[p] = W[:, cols[p], :].permute(1, 0, 2)
+        del W, Wfull                                         # only the slices stay resident
+        self.head_e = dev(sd["lm_head.weight"])[cols].contiguous()            # [P, V+1, d]
+        self._keep = keep
+        self.dims = _ffi.GdrT5Dims(Vd, d, cfg.d_kv, cfg.d_ff, cfg.num_heads, nl, cfg.relative_attention_num_buckets,
+                                   cfg.relative_attention_max_distance, cfg.layer_norm_epsilon)
+        self.struct = _ffi.GdrT5DecoderWeights(self.dims, V, ml, na, cfg.adaptor_nhead, aff, cfg.adaptor_ln_eps,
+                                               self.dec_embed.data_ptr(), self.self_rel.data_ptr(),
+                                               self.cross_rel.data_ptr(), self.final_ln.data_ptr(), self._layers,
+                                               self._alayers, self.head_w.data_ptr(), self.head_e.data_ptr())
+        self.ws = Workspace(device)
+
+    def generate(self, enc_hidden, enc_mask, num_beams, max_length, length_penalty, num_return_sequences, trace=False):
+        """Returns (out_ids int64[B*nret,max_length], out_len int32[B*nret], out_scores float64[B*nret][, trace])."""
+        _need_cuda(enc_hidden, enc_mask)
+        enc_hidden = _f32c(enc_hidden)
+        mask = enc_mask.to(torch.int64).contiguous()
+        B, L, _ = enc_hidden.shape
+        R, nret = int(num_beams), int(num_return_sequences)
+        need = lib().gdr_t5_generate_workspace_bytes(C.byref(self.struct), B, L, R, max_length)
+        ws = self.ws.get(need)
+        dev_ = enc_hidden.device
+        ids = torch.empty((B * nret, max_length), dtype=torch.int64, device=dev_)
+        lens = torch.empty((B * nret,), dtype=torch.int32, device=dev_)
+        scores = torch.empty((B * nret,), dtype=torch.float64, device=dev_)
+        ts = tt = None
+        if trace:
+            ts = torch.empty((max_length - 1, B, 2 * R), dtype=torch.float32, device=dev_)
+            tt = torch.empty((max_length - 1, B, 2 * R), dtype=torch.int32, device=dev_)
+        check(lib().gdr_t5_generate(C.byref(self.struct), ptr(enc_hidden), ptr(mask), B, L, R, max_length,
+                                    float(length_penalty), nret, ptr(ids), ptr(lens), ptr(scores), ptr(ts), ptr(tt),
+                                    ptr(ws), ws.numel(), stream_ptr()), "gdr_t5_generate")
+        return (ids, lens, scores, ts, tt) if trace else (ids, lens, scores)
+
+
+def beam_search_table(table, out_vocab, num_beams, max_length, length_penalty, num_return_sequences=None):
+    """Device beam search driven by a logit table [B, max_length, Vd, Vd] — gdr_beam_search_table."""
+    _need_cuda(table)
+    table = _f32c(table)
+    B = table.shape[0]
+    nret = num_return_sequences or num_beams
+    need = lib().gdr_beam_search_table_workspace_bytes(B, num_beams, max_length, out_vocab)
+    ws = torch.empty(need, dtype=torch.uint8, device=table.device)
+    ids = torch.empty((B * nret, max_length), dtype=torch.int64, device=table.device)
+    lens = torch.empty((B * nret,), dtype=torch.int32, device=table.device)
+    scores = torch.empty((B * nret,), dtype=torch.float64, device=table.device)
+    check(lib().gdr_beam_search_table(ptr(table), B, out_vocab, num_beams, max_length, float(length_penalty), nret,
+                                      ptr(ids), ptr(lens), ptr(scores), ptr(ws), ws.numel(), stream_ptr()),
+          "gdr_beam_search_table")
+    return ids, lens, scores
+
+
+def finish_generate_output(ids, lens, scores, max_length):
+    """Host tail of generation_utils.py:905-919: width = min(max(len)+1, max_length); scores as Python floats."""
+    sent_max_len = min(int(lens.max().item()) + 1, max_length)
+    return ids[:, :sent_max_len].contiguous(), scores.cpu().tolist()

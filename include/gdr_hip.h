@@ -140,6 +140,82 @@ int gdr_rerank_topk(const float* q, const float* D, int d, const int32_t* cand_o
 int gdr_t5_relative_bucket_table(int bidirectional, int num_buckets, int max_distance, int qlen, int klen,
                                  int32_t* out_host);
 
+/* ------------------------------------------------------------------------------------------------
+ * Docid beam decode — replaces `_generate_beam_search` (transformers/generation_utils.py:629-921, with
+ * `BeamHypotheses` :1052-1099) driving `T5ForConditionalGeneration.forward`'s decode branch
+ * (transformers/modeling_t5.py:1529-1646) as GDR calls it (main_models.py:1380-1397): greedy beams,
+ * early_stopping=False, use_cache=False semantics, positional vocabulary mask.
+ *
+ * Device-resident: no host synchronisation between steps (the reference syncs per candidate via .item()).
+ * Same arithmetic, restructured: K/V caches addressed through a beam-ancestor table instead of
+ * recomputing the whole prefix every step; cross-attention K/V projected once per query instead of once per
+ * beam row per step; the adaptor's single-key cross-attention folded into a per-layer constant; the
+ * adaptor_linear head evaluated for the last position and its V+1 unmasked columns only.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* ln_self;   /* [d]           decoder.block.i.layer.0.layer_norm.weight              */
+  const float* wqkv;      /* [3*inner, d]  layer.0.SelfAttention.{q,k,v}.weight row-concat        */
+  const float* wo;        /* [d, inner]    layer.0.SelfAttention.o.weight                         */
+  const float* ln_cross;  /* [d]           layer.1.layer_norm.weight                              */
+  const float* wq_c;      /* [inner, d]    layer.1.EncDecAttention.q.weight                       */
+  const float* wkv_c;     /* [2*inner, d]  layer.1.EncDecAttention.{k,v}.weight row-concat        */
+  const float* wo_c;      /* [d, inner]    layer.1.EncDecAttention.o.weight                       */
+  const float* ln_ff;     /* [d]           layer.2.layer_norm.weight                              */
+  const float* wi;        /* [d_ff, d]     layer.2.DenseReluDense.wi.weight                       */
+  const float* wo_ff;     /* [d, d_ff]     layer.2.DenseReluDense.wo.weight                       */
+} GdrT5DecLayer;
+
+typedef struct {          /* one torch.nn.TransformerDecoderLayer (post-LN, ReLU), modeling_t5.py:1241-1244 */
+  const float *in_w, *in_b;        /* self_attn.in_proj_{weight[3d,d],bias[3d]}                              */
+  const float *out_w, *out_b;      /* self_attn.out_proj                                                    */
+  const float *ln1_w, *ln1_b;
+  const float* cross_const;        /* [d] = multihead_attn.out_proj(v_proj(adaptor_embeddings)): a single-key
+                                      softmax is exactly 1, so the cross-attention output is this constant  */
+  const float *ln2_w, *ln2_b;
+  const float *lin1_w, *lin1_b;    /* [aff,d],[aff] */
+  const float *lin2_w, *lin2_b;    /* [d,aff],[d]   */
+  const float *ln3_w, *ln3_b;
+} GdrAdaptorLayer;
+
+typedef struct {
+  GdrT5Dims dims;                  /* num_layers = num_decoder_layers; vocab_size = decode_vocab_size (Vd) */
+  int32_t out_vocab;               /* V  (--output_vocab_size / --kary)                                     */
+  int32_t max_out_len;             /* --max_output_length; Vd = V*max_out_len + 2                           */
+  int32_t adaptor_layers, adaptor_nhead, adaptor_ff;
+  float adaptor_eps;
+  const float* dec_embed;          /* [Vd, d]   decode_embeddings.weight (= decoder.embed_tokens = lm_head) */
+  const float* self_rel_bias;      /* [buckets,H] decoder.block.0.layer.0.SelfAttention.relative_attention_bias */
+  const float* cross_rel_bias;     /* [buckets,H] decoder.block.0.layer.1.EncDecAttention.relative_attention_bias */
+  const float* final_ln;           /* [d]       decoder.final_layer_norm.weight                              */
+  const GdrT5DecLayer* layers;     /* host array [num_layers]                                                */
+  const GdrAdaptorLayer* alayers;  /* host array [adaptor_layers]                                            */
+  /* head slices: position p in [0, max_out_len-1), local column c in [0, V] (c < V: token p*V+2+c; c == V: EOS=1)
+   *   head_w[p][c][i][k] = adaptor_linear.weight[i*Vd + token(p,c), k]      (modeling_t5.py:1634-1636)
+   *   head_e[p][c][i]    = lm_head.weight[token(p,c), i]                                                    */
+  const float* head_w;             /* [(max_out_len-1), V+1, d, d] */
+  const float* head_e;             /* [(max_out_len-1), V+1, d]    */
+} GdrT5DecoderWeights;
+
+size_t gdr_t5_generate_workspace_bytes(const GdrT5DecoderWeights* w, int B, int L, int num_beams, int max_length);
+/* enc_hidden fp32[B,L,d] (NOT beam-expanded), enc_mask int64[B,L].
+ * out_ids int64[B*nret, max_length] (hypothesis tokens incl. START, then EOS if it fits, then PAD),
+ * out_len int32[B*nret] (= len(hyp), EOS excluded), out_scores fp64[B*nret] (sum_logprobs / len^length_penalty,
+ * computed in double like the reference's Python floats).  Optional trace (NULL to skip):
+ * step_scores fp32[max_length-1, B, 2R], step_tokens int32[...] = the per-step topk(2R) (generation_utils.py:775).
+ * 2 <= num_beams <= 256, num_return_sequences <= num_beams, max_length <= max_out_len. */
+int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B, int L,
+                    int num_beams, int max_length, double length_penalty, int num_return_sequences,
+                    int64_t* out_ids, int32_t* out_len, double* out_scores, float* step_scores,
+                    int32_t* step_tokens, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same device beam search driven by a logit table instead of the model (teacher forcing):
+ * logits(prefix) = table[b, pos, last_token, :] (fp32 [B, max_length, Vd, Vd]) with the positional mask.
+ * Exercises EOS / early-done / eviction paths that random weights never reach. */
+size_t gdr_beam_search_table_workspace_bytes(int B, int num_beams, int max_length, int out_vocab);
+int gdr_beam_search_table(const float* table, int B, int out_vocab, int num_beams, int max_length,
+                          double length_penalty, int num_return_sequences, int64_t* out_ids, int32_t* out_len,
+                          double* out_scores, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

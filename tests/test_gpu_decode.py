@@ -1,0 +1,139 @@
+"""GPU parity of the docid beam decode (gdr_t5_generate / gdr_beam_search_table) and of the two-stage retrieval,
+against golden vectors made from the reference's own generate() and against the oracle."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from gdr_amd.config import GDRConfig
+from gdr_amd import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_device_beam_search_vs_reference_golden(dev, case):
+    """The reference's own `_generate_beam_search` driven by a logit table (EOS, early done, eviction, and for case b
+    2R > valid-columns garbage candidates) vs the device beam kernels on the same table."""
+    from gdr_amd import ops
+    g = golden("g5_beam_table")
+    V, maxlen, R, B, seed = [int(x) for x in g[f"{case}_meta"]]
+    Vd = V * maxlen + 2
+    table = torch.from_numpy(synth.make_logit_table(B, maxlen, Vd, float(g[f"{case}_eos_boost"]), seed)).to(dev)
+    ids, lens, scores = ops.beam_search_table(table, V, R, maxlen, 0.8)
+    dec, sc = ops.finish_generate_output(ids, lens, scores, maxlen)
+    ref_dec, ref_sc = g[f"{case}_decoded"], g[f"{case}_scores"]
+    np.testing.assert_allclose(np.array(sc), ref_sc, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(dec.cpu().numpy(), ref_dec)
+
+
+def _check_generate(g, cfg, dev, tol):
+    from gdr_amd.modeling import GDRModel
+    sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
+    model = GDRModel(cfg, sd, dev)
+    R = int(g["num_beams"])
+    ids, mask = torch.from_numpy(g["input_ids"]).to(dev), torch.from_numpy(g["attention_mask"]).to(dev)
+    (dec, scores), enc = model.generate(ids, attention_mask=mask, use_cache=False, max_length=cfg.max_output_length,
+                                        num_beams=R, length_penalty=float(g["length_penalty"]), num_return_sequences=R,
+                                        early_stopping=False, decode_embedding=2,
+                                        decode_vocab_size=cfg.decode_vocab_size, decode_tree=None, decoder_index=-1,
+                                        output_scores=True, output_encoder_embedding=True, cluster_constraint=None)
+    assert isinstance(scores, list) and isinstance(scores[0], float)
+    assert dec.dtype == torch.int64 and enc.last_hidden_state.shape[0] == ids.shape[0] * R
+    np.testing.assert_allclose(np.array(scores), g["scores"], rtol=tol, atol=tol)
+    assert np.array_equal(dec.cpu().numpy(), g["decoded"])
+    # per-step top-2R trace
+    enc_h, _ = model.enc.forward(ids, mask, want_pooled=False)
+    _, _, _, ts, tt = model.dec.generate(enc_h, mask, R, cfg.max_output_length, float(g["length_penalty"]), R, trace=True)
+    ref_s, ref_t = g["step_scores"], g["step_tokens"]
+    finite = ref_s > -1e8
+    np.testing.assert_allclose(ts.cpu().numpy()[finite], ref_s[finite], rtol=tol, atol=tol)
+    assert np.array_equal(tt.cpu().numpy()[finite], ref_t[finite])
+    return model, enc
+
+
+def test_generate_tiny_vs_reference_golden(dev):
+    g = golden("g5_generate_tiny")
+    model, enc = _check_generate(g, GDRConfig.tiny(), dev, 1e-4)
+    np.testing.assert_allclose(enc.last_hidden_state.cpu().numpy(), g["enc"], rtol=1e-4, atol=1e-4)
+    # without output_scores the first element is the bare LongTensor; without output_encoder_embedding -> None
+    ids, mask = torch.from_numpy(g["input_ids"]).to(dev), torch.from_numpy(g["attention_mask"]).to(dev)
+    out, none = model.generate(ids, attention_mask=mask, max_length=5, num_beams=4, length_penalty=0.8,
+                               num_return_sequences=4)
+    assert none is None and torch.is_tensor(out) and np.array_equal(out.cpu().numpy(), g["decoded"])
+
+
+def test_generate_base_vs_reference_golden(dev):
+    g = golden("g5_generate_base")
+    model, enc = _check_generate(g, GDRConfig.base(), dev, 2e-4)
+    np.testing.assert_allclose(enc.last_hidden_state[::int(g["num_beams"]), 0].cpu().numpy(), g["pooled"], rtol=2e-4,
+                               atol=2e-4)
+
+
+@pytest.mark.parametrize("B,R,L", [(1, 2, 3), (5, 6, 9), (2, 16, 12)])
+def test_generate_tiny_vs_oracle(dev, B, R, L):
+    """More shapes than the golden covers, incl. R=16 > V+1=7 valid columns at step 1 (garbage candidates)."""
+    from gdr_amd.modeling import GDRModel
+    from oracle import beam_ref
+    cfg = GDRConfig.tiny()
+    sd = synth.make_state_dict(cfg, seed=99)
+    ids, mask = synth.make_tokens(B, L=L, vocab_hi=cfg.vocab_size, seed=B + R, min_len=1)
+    (rd, rs), _ = beam_ref.generate(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask), R, restricted_head=True)
+    model = GDRModel(cfg, sd, dev)
+    (dec, sc), _ = model.generate(torch.from_numpy(ids).to(dev), attention_mask=torch.from_numpy(mask).to(dev),
+                                  max_length=cfg.max_output_length, num_beams=R, length_penalty=0.8,
+                                  num_return_sequences=R, output_scores=True)
+    assert np.isfinite(rs).all()
+    np.testing.assert_allclose(np.array(sc), np.array(rs), rtol=1e-4, atol=1e-4)
+    assert np.array_equal(dec.cpu().numpy(), rd.numpy())
+
+
+def test_two_stage_retrieval_vs_oracle(dev):
+    """validation_step_i end to end on a tiny model whose logits are steered to real cluster ids by the synthetic
+    corpus' CSR: decode -> id_mapping -> rerank, vs the oracle composition of the same stages."""
+    from gdr_amd import codec
+    from gdr_amd.modeling import GDRModel, GDRRetriever
+    from oracle import beam_ref, codec_ref, retrieval_ref
+    cfg = GDRConfig.tiny()
+    sd = synth.make_state_dict(cfg, seed=5)
+    V = cfg.output_vocab_size
+    N, csize = 6 ** 4 * 3, 3                                  # depth-4 ids: 1296 clusters of 3 docs
+    names, depth, offsets, members = synth.make_cluster_ids(N, cluster_size=csize, V=V)
+    assert depth == 4 == cfg.max_output_length - 1
+    # Random weights never emit EOS, so every hypothesis runs to max_length and decode_token (like the reference,
+    # main_models.py:331-335) decodes the row whole, START included: "-2-(c1-V)-(c2-V)-...".  Name the synthetic
+    # clusters in that form so that every decoded string is a real cluster and the rerank stage gets candidates.
+    names = ["-2-" + "-".join(str(int(x) - V) for x in n.split("-")) for n in names]
+    D = synth.make_corpus(N, cfg.d_model, cluster_size=csize, seed=8)
+    B, R = 3, 4
+    ids, mask = synth.make_tokens(B, L=10, vocab_hi=cfg.vocab_size, seed=12, min_len=2)
+    args = types.SimpleNamespace(num_return_sequences=R, output_vocab_size=V, max_output_length=cfg.max_output_length,
+                                 length_penalty=0.8, kary=V, position=1, score_rate=[0, 0.5, 1, 1.5, 2, 2.5, 3],
+                                 loss_func="tanh")
+    model = GDRModel(cfg, sd, dev)
+    retr = GDRRetriever(model, torch.from_numpy(D).to(dev), codec.ClusterIndex(names, offsets, members), args)
+    out = retr.validation_step_i({"source_ids": torch.from_numpy(ids).to(dev), "source_mask": torch.from_numpy(mask).to(dev)})
+    # oracle composition
+    (rd, rs), enc_x = beam_ref.generate(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask), R, restricted_head=True)
+    dec = codec_ref.dec_2d(codec_ref.decode_token(rd.numpy(), output_vocab_size=V, kary=V), R)
+    assert out["clusters"] == dec
+    look = {n: i for i, n in enumerate(names)}
+    mem_q = [[m for s in row for m in (members[offsets[look[s]]:offsets[look[s] + 1]].tolist() if s in look else [])]
+             for row in dec]
+    num_q = [[(int(offsets[look[s] + 1] - offsets[look[s]]) if s in look else 0) for s in row] for row in dec]
+    assert min(len(m) for m in mem_q) >= R
+    if True:
+        ref = retrieval_ref.rerank(enc_x[::R][:, 0], torch.from_numpy(D), mem_q, num_q,
+                                   np.array(rs, np.float32).reshape(B, R).tolist(), args.score_rate, R)
+        for b in range(B):
+            for a in range(len(args.score_rate)):
+                assert out["inf_index_batch"][b][a] == [str(x) for x in ref[b][a][1].tolist()]
