@@ -98,42 +98,40 @@ def test_generate_tiny_vs_oracle(dev, B, R, L):
 
 
 def test_two_stage_retrieval_vs_oracle(dev):
-    """validation_step_i end to end on a tiny model whose logits are steered to real cluster ids by the synthetic
-    corpus' CSR: decode -> id_mapping -> rerank, vs the oracle composition of the same stages."""
+    """validation_step_i end to end on a tiny model: decode -> id_mapping -> rerank, vs the oracle composition of
+    the same stages.  The cluster index is built from the strings the (oracle) decode produces — random weights
+    give a mix of EOS-terminated ids of every depth and full-length rows that decode_token keeps whole
+    (main_models.py:331-335) — plus filler clusters, so every decoded string has members."""
     from gdr_amd import codec
     from gdr_amd.modeling import GDRModel, GDRRetriever
     from oracle import beam_ref, codec_ref, retrieval_ref
     cfg = GDRConfig.tiny()
     sd = synth.make_state_dict(cfg, seed=5)
     V = cfg.output_vocab_size
-    N, csize = 6 ** 4 * 3, 3                                  # depth-4 ids: 1296 clusters of 3 docs
-    names, depth, offsets, members = synth.make_cluster_ids(N, cluster_size=csize, V=V)
-    assert depth == 4 == cfg.max_output_length - 1
-    # Random weights never emit EOS, so every hypothesis runs to max_length and decode_token (like the reference,
-    # main_models.py:331-335) decodes the row whole, START included: "-2-(c1-V)-(c2-V)-...".  Name the synthetic
-    # clusters in that form so that every decoded string is a real cluster and the rerank stage gets candidates.
-    names = ["-2-" + "-".join(str(int(x) - V) for x in n.split("-")) for n in names]
-    D = synth.make_corpus(N, cfg.d_model, cluster_size=csize, seed=8)
-    B, R = 3, 4
+    B, R, csize = 3, 4, 3
     ids, mask = synth.make_tokens(B, L=10, vocab_hi=cfg.vocab_size, seed=12, min_len=2)
+    (rd, rs), enc_x = beam_ref.generate(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask), R, restricted_head=True)
+    dec = codec_ref.dec_2d(codec_ref.decode_token(rd.numpy(), output_vocab_size=V, kary=V), R)
+    decoded_names = sorted({s for row in dec for s in row})
+    assert any("--" not in s for s in decoded_names) and any("--" in s for s in decoded_names), "want both kinds"
+    names = [f"filler-{i}" for i in range(5)] + decoded_names + [f"filler-{i}" for i in range(5, 9)]
+    N = len(names) * csize
+    offsets = (np.arange(len(names) + 1) * csize).astype(np.int32)
+    members = np.random.Generator(np.random.PCG64(3)).permutation(N).astype(np.int32)   # ids not in cluster order
+    D = synth.make_corpus(N, cfg.d_model, cluster_size=csize, seed=8)
     args = types.SimpleNamespace(num_return_sequences=R, output_vocab_size=V, max_output_length=cfg.max_output_length,
                                  length_penalty=0.8, kary=V, position=1, score_rate=[0, 0.5, 1, 1.5, 2, 2.5, 3],
                                  loss_func="tanh")
     model = GDRModel(cfg, sd, dev)
     retr = GDRRetriever(model, torch.from_numpy(D).to(dev), codec.ClusterIndex(names, offsets, members), args)
     out = retr.validation_step_i({"source_ids": torch.from_numpy(ids).to(dev), "source_mask": torch.from_numpy(mask).to(dev)})
-    # oracle composition
-    (rd, rs), enc_x = beam_ref.generate(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask), R, restricted_head=True)
-    dec = codec_ref.dec_2d(codec_ref.decode_token(rd.numpy(), output_vocab_size=V, kary=V), R)
     assert out["clusters"] == dec
+    np.testing.assert_allclose(np.array(out["inf_result_batch_prob"]), np.array(rs), rtol=1e-4, atol=1e-4)
     look = {n: i for i, n in enumerate(names)}
-    mem_q = [[m for s in row for m in (members[offsets[look[s]]:offsets[look[s] + 1]].tolist() if s in look else [])]
-             for row in dec]
-    num_q = [[(int(offsets[look[s] + 1] - offsets[look[s]]) if s in look else 0) for s in row] for row in dec]
-    assert min(len(m) for m in mem_q) >= R
-    if True:
-        ref = retrieval_ref.rerank(enc_x[::R][:, 0], torch.from_numpy(D), mem_q, num_q,
-                                   np.array(rs, np.float32).reshape(B, R).tolist(), args.score_rate, R)
-        for b in range(B):
-            for a in range(len(args.score_rate)):
-                assert out["inf_index_batch"][b][a] == [str(x) for x in ref[b][a][1].tolist()]
+    mem_q = [[m for s in row for m in members[offsets[look[s]]:offsets[look[s] + 1]].tolist()] for row in dec]
+    num_q = [[csize for _ in row] for row in dec]
+    ref = retrieval_ref.rerank(enc_x[::R][:, 0], torch.from_numpy(D), mem_q, num_q,
+                               np.array(rs, np.float32).reshape(B, R).tolist(), args.score_rate, R)
+    for b in range(B):
+        for a in range(len(args.score_rate)):
+            assert out["inf_index_batch"][b][a] == [str(x) for x in ref[b][a][1].tolist()]
