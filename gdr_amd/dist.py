@@ -51,8 +51,8 @@ class ShardedIndex:
         if self.world == 1:
             return v, i
         B = q_all.shape[0]
-        gv = torch.empty((self.world, B, k), dtype=v.dtype, device=v.device)
-        gi = torch.empty((self.world, B, k), dtype=i.dtype, device=i.device)
+        gv = torch.empty((self.world * B, k), dtype=v.dtype, device=v.device)     # rank-major concatenation
+        gi = torch.empty((self.world * B, k), dtype=i.dtype, device=i.device)
         dist.all_gather_into_tensor(gv, v.contiguous(), group=self.group)
         dist.all_gather_into_tensor(gi, i.contiguous(), group=self.group)
-        return self.merge(gv, gi)
+        return self.merge(gv.view(self.world, B, k), gi.view(self.world, B, k))

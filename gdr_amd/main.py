@@ -1,0 +1,209 @@
+"""Entry point that keeps the reference's command line (GDR_model/main.py:260-448, infer.sh:10-15).
+
+    python -m gdr_amd.main --mode eval --decode_embedding 2 --num_return_sequences 10 --kary 30 ...   (infer.sh flags)
+
+`--mode eval` runs the inference hot path on the MI355X: T5 encoder -> docid beam decode -> (with doc embeddings)
+in-cluster dense rerank, writes the res1 TSV `query\\tpred\\tgt\\trank` (main.py:244-247) and prints recall@k / MRR100
+(main_metrics.py:194-267).  `--mode calculate` recomputes the metrics of an existing TSV.  `--mode train` is out of
+scope and exits with a message.
+
+Every reference flag is accepted (plus `--trivia`, which infer.sh passes although the reference parser lacks it,
+SURVEY fact 6).  Because neither the authors' checkpoint, tokenizer nor TSVs ship with the reference
+(.MISSING_LARGE_BLOBS), inputs come from `--data_npz` (pre-tokenised: source_ids, source_mask, gt) and
+`--infer_ckpt` (a Lightning .ckpt / state_dict); without them `--synthetic 1` (default) builds the seeded synthetic
+NQ-320k-shaped workload of BASELINE.md.
+"""
+import argparse
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    __package__ = "gdr_amd"
+
+from . import codec, synth                      # noqa: E402
+from .config import GDRConfig                   # noqa: E402
+
+# (flag, type, default[, choices]) — names, types and defaults of main.py:262-396
+_FLAGS = [
+    ("output_dir", str, None), ("model_name_or_path", str, "t5-"), ("tokenizer_name_or_path", str, "t5-"),
+    ("encoder_name_or_path", str, "bert--uncased"), ("encoder_tokenizer_name_or_path", str, "bert--uncased"),
+    ("freeze_encoder", int, 0), ("freeze_embeds", int, 0), ("weight_decay", float, 1e-4), ("adam_epsilon", float, 1e-8),
+    ("warmup_steps", int, 0), ("num_train_epochs", int, 500), ("gradient_accumulation_steps", int, 1),
+    ("resume_from_checkpoint", str, None), ("n_val", int, -1), ("n_train", int, -1), ("n_test", int, -1),
+    ("early_stop_callback", int, 0), ("fp_16", int, 0), ("opt_level", str, "O1"), ("max_grad_norm", float, 1.0),
+    ("seed", int, 42), ("pretrain_encoder", int, 1), ("limit_val_batches", float, 1.0), ("softmax", int, 0),
+    ("aug", int, 0), ("accelerator", str, "ddp"), ("num_layers", int, 12), ("num_decoder_layers", int, 6),
+    ("d_ff", int, 3072), ("d_model", int, 1024), ("num_heads", int, 12), ("num_cls", int, 1000),
+    ("decode_embedding", int, 2), ("output_vocab_size", int, 30), ("hierarchic_decode", int, 0),
+    ("tie_word_embedding", int, 0), ("tie_decode_embedding", int, 1), ("gen_method", str, "greedy"),
+    ("length_penalty", float, 0.8), ("random_gen", int, 0), ("label_length_cutoff", int, 0),
+    ("check_val_every_n_epoch", int, 1), ("val_check_interval", float, 1.0), ("test_set", str, "dev"),
+    ("train_batch_size", int, 128), ("eval_batch_size", int, 4), ("max_input_length", int, 40),
+    ("inf_max_input_length", int, 40), ("max_output_length", int, 7), ("doc_length", int, 16),
+    ("contrastive_variant", str, ""), ("num_return_sequences", int, 100), ("n_gpu", int, 1), ("devices", int, 8),
+    ("mode", str, "train", ["train", "eval", "calculate"]), ("query_type", str, "gtq_doc"),
+    ("learning_rate", float, 2e-4), ("decoder_learning_rate", float, 1e-4), ("certain_epoch", int, None),
+    ("given_ckpt", str, ""), ("infer_ckpt", str, ""), ("model_info", str, "base", ["small", "large", "base", "3b", "11b"]),
+    ("encoder_info", str, "base", ["base", "large"]), ("id_class", str, "bert_k30_c30_1"),
+    ("ckpt_monitor", str, "recall", ["recall", "train_loss"]), ("Rdrop", float, 0), ("dropout_rate", float, 0.1),
+    ("Rdrop_only_decoder", int, 0), ("Rdrop_loss", str, "KL", ["KL", "L2"]), ("adaptor_decode", int, 1),
+    ("adaptor_efficient", int, 1), ("adaptor_layer_num", int, 4), ("test1000", int, 0), ("position", int, 1),
+    ("contrastive", int, 0), ("embedding_distillation", float, 0.0), ("weight_distillation", float, 0.0),
+    ("hard_negative", int, 0), ("aug_query", int, 0), ("aug_query_type", str, "corrupted_query"),
+    ("sample_neg_num", int, 0), ("query_tloss", int, 0), ("weight_tloss", int, 0), ("ranking_loss", int, 0),
+    ("disc_loss", int, 0), ("input_dropout", int, 1), ("denoising", int, 0), ("multiple_decoder", int, 0),
+    ("decoder_num", int, 1), ("loss_weight", int, 0), ("nq", int, 1), ("kary", int, 30), ("tree", int, 1),
+    ("ckpt_info", str, "334314test"), ("nodes", int, 1), ("docnum", int, 190727),
+    ("project_path", str, "your project path"), ("kmeans_model", str, "ar2"), ("scheduler", str, "linear"),
+    ("wandb_pro_name", str, "GDR"), ("is_train_encoder", int, 1), ("tau", float, 0.05), ("encoder_max_len", int, 128),
+    ("max_intraclass_num", int, 10), ("use_query_embed_encoder", int, 1), ("use_query_embed_decoder_special", int, 0),
+    ("use_query_embed_decoder_avg", int, 0), ("intra_rate", float, 1.0), ("train_encoder_epoch", int, 51),
+    ("stage2_train_batchsize", int, 2), ("stage2_eval_batchsize", int, 2), ("begin_val_epoch", int, 0),
+    ("doc_encoder_learning_rate", float, 2e-4), ("train_num", int, 256), ("eval_num", int, -1),
+    ("data_suffix", str, "_30_2.5"), ("loss_func", str, "tanh"), ("fusion_strategy", str, "concate"),
+    ("neg_sample_strategy", str, "random"),
+    # tolerated / added
+    ("trivia", int, 0),                      # infer.sh:15 passes it; only main_metrics.py reads it
+    ("synthetic", int, 1), ("data_npz", str, ""), ("doc_embed_npy", str, ""), ("corpus_rows", int, 320000),
+    ("n_queries", int, 512), ("res1_save_path", str, ""), ("device", str, "cuda:0"),
+]
+_SIZES = {"base": (12, 6, 3072, 768, 12, 64), "large": (24, 12, 4096, 1024, 16, 64), "small": (6, 3, 2048, 512, 8, 64)}
+
+
+def parsers_parser(argv=None):
+    parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    for f in _FLAGS:
+        kw = dict(type=f[1], default=f[2])
+        if len(f) > 3:
+            kw["choices"] = f[3]
+        parser.add_argument("--" + f[0], **kw)
+    parser.add_argument("--recall_num", type=int, nargs="+", default=[1, 5, 10, 20, 50, 100])
+    parser.add_argument("--score_rate", type=float, nargs="+", default=[0, 0.5, 1, 1.5, 2, 2.5, 3])
+    parser.add_argument("--expand", type=bool, default=True)
+    a = parser.parse_args(argv)
+    # the reference's post-processing (main.py:398-447)
+    a.dataset_name = "Self_NQ_{}_{}{}".format(a.kmeans_model, str(a.docnum), a.data_suffix)
+    a.tokenizer_name_or_path += a.model_info
+    a.model_name_or_path += a.model_info
+    k = a.encoder_tokenizer_name_or_path.split("-")
+    k[1] = a.encoder_info
+    a.encoder_tokenizer_name_or_path = a.encoder_name_or_path = "-".join(k)
+    a.gradient_accumulation_steps = max(int(8 / a.n_gpu), 1)
+    if a.mode == "train" and "doc" in a.query_type:          # main.py:412-415
+        assert a.contrastive_variant == ""
+        a.max_input_length = a.doc_length
+    if a.model_info in _SIZES:
+        a.num_layers, a.num_decoder_layers, a.d_ff, a.d_model, a.num_heads, a.d_kv = _SIZES[a.model_info]
+    if a.test1000:
+        a.n_val = a.n_train = a.n_test = 1000
+    return a
+
+
+def set_seed(seed):
+    """main_utils.py:12-18."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def _load_inputs(args, cfg):
+    """Returns dict(source_ids, source_mask, gt_cluster list[str], gt_doc list[str], index, doc_embed (np or None))."""
+    if args.data_npz:
+        z = np.load(args.data_npz, allow_pickle=False)
+        index = codec.ClusterIndex([str(x) for x in z["cluster_names"]], z["cluster_offsets"], z["cluster_members"])
+        doc = np.load(args.doc_embed_npy) if args.doc_embed_npy else None
+        return dict(source_ids=z["source_ids"], source_mask=z["source_mask"], gt_cluster=[str(x) for x in z["gt_cluster"]],
+                    gt_doc=[str(x) for x in z["gt_doc"]], index=index, doc_embed=doc)
+    N = args.corpus_rows
+    names, depth, offsets, members = synth.make_cluster_ids(N, cluster_size=12, V=args.kary)
+    D = synth.make_corpus(N, cfg.d_model)
+    ids, mask = synth.make_tokens(args.n_queries, L=args.max_input_length, seed=11)
+    _, gold = synth.make_queries(D, args.n_queries)
+    return dict(source_ids=ids, source_mask=mask, gt_cluster=[names[int(g) // 12] for g in gold],
+                gt_doc=[str(int(g)) for g in gold], index=codec.ClusterIndex(names, offsets, members), doc_embed=D)
+
+
+def inference(args):
+    """main.py:115-250 on the MI355X path: generate cluster ids per query, write res1, print recall / MRR."""
+    from .modeling import GDRModel, GDRRetriever
+    cfg = GDRConfig.from_args(args)
+    if args.infer_ckpt and os.path.exists(args.infer_ckpt):
+        sd = torch.load(args.infer_ckpt, map_location="cpu")
+    else:
+        print("[gdr_amd] no --infer_ckpt: using seeded synthetic weights (no trained checkpoint ships with the reference)")
+        sd = synth.make_state_dict(cfg, seed=1234)
+    dev = torch.device(args.device)
+    model = GDRModel(cfg, sd, dev)
+    data = _load_inputs(args, cfg)
+    R = args.num_return_sequences
+    two_stage = bool(args.is_train_encoder) and data["doc_embed"] is not None
+    retr = GDRRetriever(model, torch.from_numpy(np.ascontiguousarray(data["doc_embed"], dtype=np.float32)).to(dev),
+                        data["index"], args) if two_stage else None
+    n = data["source_ids"].shape[0] if args.n_test < 0 else min(args.n_test, data["source_ids"].shape[0])
+    rows1, rows2 = [], []
+    t_model = 0.0
+    for lo in range(0, n, args.eval_batch_size):
+        hi = min(n, lo + args.eval_batch_size)
+        ids = torch.from_numpy(data["source_ids"][lo:hi]).to(dev)
+        mask = torch.from_numpy(data["source_mask"][lo:hi]).to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if two_stage:
+            out = retr.validation_step_i({"source_ids": ids, "source_mask": mask})
+            dec = out["clusters"]
+        else:
+            outs, _ = model.generate(ids, attention_mask=mask, use_cache=False, max_length=args.max_output_length,
+                                     num_beams=R, length_penalty=args.length_penalty, num_return_sequences=R,
+                                     early_stopping=False, decode_embedding=args.decode_embedding,
+                                     decode_vocab_size=args.output_vocab_size * args.max_output_length + 2)
+            dec = codec.dec_2d(codec.decode_token(args, outs.cpu().numpy()), R)
+        torch.cuda.synchronize()
+        t_model += time.perf_counter() - t0
+        for j, pred in enumerate(dec):
+            q = "q%d" % (lo + j)
+            rows1.append((q, ",".join(pred), data["gt_cluster"][lo + j], 1))
+            if two_stage:
+                best_alpha = len(args.score_rate) // 2
+                rows2.append((q, ",".join(out["inf_index_batch"][j][best_alpha]), data["gt_doc"][lo + j], 1))
+    os.makedirs(os.path.dirname(args.res1_save_path) or ".", exist_ok=True)
+    codec.write_res1(args.res1_save_path, rows1)
+    print(f"[gdr_amd] {n} queries, beam {R}: {n / max(t_model, 1e-9):.1f} queries/s (model time only)")
+    print("cluster-id recall (stage 1):")
+    recall_value = codec.recall(args)
+    mrr_value = codec.MRR100(args)
+    if two_stage:
+        print("doc recall after in-cluster rerank (stage 2, alpha=%g):" % args.score_rate[len(args.score_rate) // 2])
+        codec.recall(rows=rows2, recall_num=args.recall_num)
+    return recall_value, mrr_value
+
+
+def calculate(args):
+    return codec.recall(args), codec.MRR100(args)
+
+
+def main(argv=None):
+    args = parsers_parser(argv)
+    set_seed(args.seed)
+    dir_path = os.path.dirname(os.path.realpath(__file__))
+    args.logs_dir = dir_path + "/logs/"
+    if not args.res1_save_path:
+        args.res1_save_path = args.logs_dir + "res1_recall{}_{}_{}.tsv".format(
+            args.num_return_sequences, time.strftime("%Y%m%d-%H%M%S"), args.ckpt_info)
+    if args.mode == "train":
+        raise SystemExit("gdr_amd implements GDR's inference hot path only; --mode train is out of scope (SURVEY §2.2)")
+    if args.mode == "eval":
+        args.recall_num = [1, 5, 10, 20, 50, 100]
+        return inference(args)
+    return calculate(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -451,8 +451,35 @@ def g_rerank(main_models):
          cluster_strs=cluster_strs, cluster_size=7)
 
 
+def g_cli():
+    """G9: the reference argparse namespace (main.py:260-448) for no flags and for infer.sh's flags (without
+    --trivia, which the reference parser rejects).  main.py itself cannot be imported (nltk / pytorch_lightning),
+    so its `parsers_parser` FunctionDef is compiled out of the file with ast and executed as is."""
+    import ast
+    import json
+    src = open(REF + "/main.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "parsers_parser"][0]
+    ns = {"argparse": argparse}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), REF + "/main.py", "exec"), ns)
+    infer = ("--decode_embedding 2 --n_gpu 1 --mode eval --query_type gtq_doc_aug_qg --adaptor_layer_num 4 "
+             "--infer_ckpt CKPT --num_return_sequences 100 --tree 1 --model_info base --train_batch_size 64 "
+             "--eval_batch_size 1 --test1000 0 --dropout_rate 0.1 --Rdrop 0.1 --adaptor_decode 1 --adaptor_efficient 1 "
+             "--aug_query 1 --aug_query_type corrupted_query --input_dropout 1 --id_class bert_k30_c30_1 --kary 30 "
+             "--output_vocab_size 30 --doc_length 64 --denoising 0 --max_output_length 10 --nq 1")
+    out = {}
+    for name, argv in (("default", []), ("infer_sh", infer.split())):
+        old = sys.argv
+        sys.argv = ["main.py"] + argv
+        try:
+            out[name] = vars(quiet(ns["parsers_parser"]))
+        finally:
+            sys.argv = old
+    save("g9_cli", default=json.dumps(out["default"], sort_keys=True), infer_sh=json.dumps(out["infer_sh"], sort_keys=True),
+         infer_argv=infer)
+
+
 FIXTURES = ["buckets", "encoder_tiny", "encoder_base", "sim_topk", "decode_logits_tiny", "generate_tiny",
-            "generate_base", "beam_table", "codec", "metrics", "rerank"]
+            "generate_base", "beam_table", "codec", "metrics", "rerank", "cli"]
 
 
 def main():

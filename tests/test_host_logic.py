@@ -116,3 +116,74 @@ def test_cluster_index_csr_matches_reference_lookup():
     # dict round trip (the reference pickles a dict of lists, main_models.py:874-889)
     idx2 = codec.ClusterIndex.from_id_mapping({n: index[n] for n in names})
     assert np.array_equal(idx2.offsets, index.offsets) and np.array_equal(idx2.members, index.members)
+
+
+def test_cli_namespace_matches_reference_parser():
+    """Same flag names, types, defaults and post-processing as GDR_model/main.py:260-448 (golden = the reference's
+    own parser run in the build container); --trivia is additionally tolerated because infer.sh passes it."""
+    import json
+    from gdr_amd.main import parsers_parser
+    g = golden("g9_cli")
+    for key, argv in (("default", []), ("infer_sh", str(g["infer_argv"]).split())):
+        ref = json.loads(str(g[key]))
+        mine = vars(parsers_parser(argv))
+        for k, v in ref.items():
+            assert k in mine, k
+            assert mine[k] == v, (key, k, mine[k], v)
+    a = parsers_parser(str(g["infer_argv"]).split() + ["--trivia", "0"])
+    assert a.trivia == 0 and a.num_return_sequences == 100 and a.d_model == 768
+
+
+def _gloo_worker(rank, world, port, tmp):
+    import os
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gdr_amd import synth
+        from gdr_amd.dist import ShardedIndex, shard_bounds
+        from oracle import retrieval_ref
+        N, d, k, B_local = 5000, 32, 20, 6
+        D = synth.make_corpus(N, d, seed=4)
+        Q, _ = synth.make_queries(D, B_local * world, seed=5)
+        lo, hi = shard_bounds(N, world, rank, cluster_size=12)
+
+        def local_topk(Qa, Ds, kk, off):                     # CPU stand-ins for the HIP ops (collective logic only)
+            v, i = retrieval_ref.sim_topk(Qa, Ds, kk)
+            return v, (i + off).to(torch.int32)
+
+        def merge(gv, gi):
+            G, B, kk = gv.shape
+            v = gv.permute(1, 0, 2).reshape(B, G * kk)
+            i = gi.permute(1, 0, 2).reshape(B, G * kk)
+            key = np.lexsort((i.numpy(), -v.numpy()), axis=1)[:, :kk]     # higher score, then lower id
+            return torch.from_numpy(np.take_along_axis(v.numpy(), key, 1)), torch.from_numpy(np.take_along_axis(i.numpy(), key, 1))
+
+        index = ShardedIndex(torch.from_numpy(D[lo:hi]), lo, local_topk=local_topk, merge=merge)
+        q_all = index.gather_queries(torch.from_numpy(Q[rank * B_local:(rank + 1) * B_local]))
+        assert torch.equal(q_all, torch.from_numpy(Q))
+        v, i = index.search(q_all, k)
+        rv, ri = retrieval_ref.sim_topk(torch.from_numpy(Q), torch.from_numpy(D), k)
+        np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([int(torch.equal(i.to(torch.int64), ri)),
+                                                             int(torch.allclose(v, rv, atol=1e-6))]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_two_ranks_gloo(tmp_path):
+    """world_size-2 run of gdr_amd/dist.py on CPU/gloo: query all-gather, per-shard top-k with id offsets, top-k
+    all-gather and merge reproduce the single-shard result on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    from gdr_amd.dist import shard_bounds
+    assert shard_bounds(100, 3, 0, 12) == (0, 36) and shard_bounds(100, 3, 2, 12) == (72, 100)
+    assert [shard_bounds(320000, 8, r, 12) for r in (0, 7)] == [(0, 40008), (280008, 320000)]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.load(tmp_path / f"ok{r}.npy").tolist() == [1, 1]
