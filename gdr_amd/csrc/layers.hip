@@ -271,6 +271,159 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ attention on MFMA
+// Full self-attention (Lq == Lk = L <= 128, dk = 64) on v_mfma_f32_32x32x2_f32, one workgroup per (batch, head),
+// one wave per 32-query tile.  Q, K, V of the head are staged once in LDS (rows zero-padded to a multiple of 32,
+// row stride 68 floats: conflict-free ds_read_b128).
+//   S^T = K · Q^T : docs^W keys take the MFMA row role, queries the column role, so a LANE OWNS ONE QUERY: its 16
+//         accumulators per key tile are that query's scores; row max / sum are lane-local plus one exchange with the
+//         partner half-wave (lane ^ 32).
+//   O^T = V^T · P^T : the probability accumulators ARE the B operand of the next MFMA (register r of lane-half h
+//         is key (r&3)+8(r>>2)+4h; the A operand reads V[that key][d] from LDS) — no LDS round trip for P.
+// Arithmetic is the reference's (scores + bias + mask, fp32 softmax, PV; modeling_t5.py:384-413), fp32 throughout.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void attention_mfma_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int DK = 64, DS = DK + 4, LP = 32 * NT, NTHR = 64 * NT;
+  float* Qs = smem;
+  float* Ks = Qs + LP * DS;
+  float* Vs = Ks + LP * DS;
+  float* Bs = Vs + LP * DS;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int L = a.Lk, tid = threadIdx.x;
+  for (int e = tid; e < LP * (DK / 4); e += NTHR) {
+    const int r = e >> 4, c = e & 15;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f), k = q, v = q;
+    if (r < L) {
+      q = *reinterpret_cast<const float4*>(a.q + ((int64_t)b * a.q_bstride + r) * a.ldq + h * DK + 4 * c);
+      k = *reinterpret_cast<const float4*>(a.k + ((int64_t)b * a.k_bstride + r) * a.ldk + h * DK + 4 * c);
+      v = *reinterpret_cast<const float4*>(a.v + ((int64_t)b * a.k_bstride + r) * a.ldv + h * DK + 4 * c);
+      q.x *= a.scale, q.y *= a.scale, q.z *= a.scale, q.w *= a.scale;
+    }
+    *reinterpret_cast<float4*>(Qs + r * DS + 4 * c) = q;
+    *reinterpret_cast<float4*>(Ks + r * DS + 4 * c) = k;
+    *reinterpret_cast<float4*>(Vs + r * DS + 4 * c) = v;
+  }
+  if (a.rel_bias && tid < a.num_buckets) Bs[tid] = a.rel_bias[tid * a.H + h];
+  __syncthreads();
+
+  const int w = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  f32x16_t st[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+  // ---- S^T tiles: A = K rows (keys), B = Q rows (queries); k index permuted inside chunks of 8 as in the GEMM core
+  const float* qrow = Qs + (32 * w + l31) * DS + 4 * hh;
+#pragma unroll
+  for (int jj = 0; jj < DK / 8; ++jj) {
+    const float4 qv = *reinterpret_cast<const float4*>(qrow + 8 * jj);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 kv = *reinterpret_cast<const float4*>(Ks + (32 * t + l31) * DS + 4 * hh + 8 * jj);
+      st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qv.x, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qv.y, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qv.z, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qv.w, st[t], 0, 0, 0);
+    }
+  }
+  // ---- bias + mask + softmax over keys (this lane's query column)
+  const int i = 32 * w + l31, i_abs = a.q_pos0 + i;
+  const int half = a.num_buckets >> 1;
+  const float masked = a.causal_neg_inf ? -INFINITY : -1e9f;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      float s = -INFINITY;
+      if (j < L) {
+        float add = 0.f;
+        if (a.rel_bias) {
+          int n = i_abs - j, bucket = 0;
+          if (a.bidirectional) {
+            if (n < 0) {
+              bucket = half;
+              n = -n;
+            }
+          } else if (n < 0) {
+            n = 0;
+          }
+          bucket += a.lut.v[n < 127 ? n : 127];
+          add = Bs[bucket];
+        }
+        bool allowed = true;
+        if (a.causal) allowed = j <= i_abs;
+        if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)b * a.mask_bstride + j] != 0);
+        if (!allowed) add += masked;
+        s = st[t][r] + add;
+      }
+      st[t][r] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = expf(st[t][r] - mx);  // padded keys: exp(-inf) = 0
+      st[t][r] = p;
+      sum += p;
+    }
+  }
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  // ---- O^T = V^T · P^T, two 32-wide d tiles; then normalise and store rows of this lane's query
+#pragma unroll
+  for (int dt = 0; dt < DK / 32; ++dt) {
+    f32x16_t o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float vv = Vs[j * DS + 32 * dt + l31];
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[t][r], o, 0, 0, 0);
+      }
+    }
+    if (i < L) {
+      float* orow = a.out + ((int64_t)b * a.o_bstride + i) * a.ldo + h * DK + 32 * dt + 4 * hh;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        float4 ov;
+        ov.x = o[4 * q4 + 0] * inv, ov.y = o[4 * q4 + 1] * inv, ov.z = o[4 * q4 + 2] * inv, ov.w = o[4 * q4 + 3] * inv;
+        *reinterpret_cast<float4*>(orow + 8 * q4) = ov;
+      }
+    }
+  }
+}
+
+template <int NT>
+static int launch_attention_mfma(const AttnArgs& a, hipStream_t stream) {
+  const size_t lds = sizeof(float) * ((size_t)3 * 32 * NT * 68 + 256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return GDR_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attention_mfma_kernel<NT>, dim3((unsigned)(a.B * a.H)), dim3(64 * NT), lds, stream, a);
+  GDR_CHECK_LAUNCH("attention_mfma_kernel");
+  return GDR_OK;
+}
+
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
   GDR_CHECK_ARG(a.dk % 4 == 0 && a.dk >= 4 && a.dk <= 256, "attention: dk=%d unsupported", a.dk);
   GDR_CHECK_ARG(a.Lk >= 1 && a.Lk <= 128, "attention: Lk=%d must be in [1,128]", a.Lk);
@@ -278,6 +431,15 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   GDR_CHECK_ARG(!a.rel_bias || (a.num_buckets >= 2 && a.num_buckets <= 256), "attention: bad num_buckets");
   GDR_CHECK_ARG(a.kv_group >= 1, "attention: kv_group must be >= 1");
   if (a.B == 0 || a.Lq == 0) return GDR_OK;
+  ProfScope prof(PROF_ATTENTION, 4.0 * a.B * a.H * (double)a.Lq * a.Lk * a.dk, stream);
+  if (a.Lq == a.Lk && !a.kv_rows && a.kv_group == 1 && a.dk == 64 && a.ldo % 4 == 0) {
+    switch ((a.Lk + 31) / 32) {
+      case 1: return launch_attention_mfma<1>(a, stream);
+      case 2: return launch_attention_mfma<2>(a, stream);
+      case 3: return launch_attention_mfma<3>(a, stream);
+      default: return launch_attention_mfma<4>(a, stream);
+    }
+  }
   const int dks = a.dk + 4, Lkp = (a.Lk + 3) & ~3;
   const size_t lds = sizeof(float) * ((size_t)2 * a.Lk * dks + 4 * a.dk + 4 * Lkp + 256);
   GDR_CHECK_ARG(lds <= 160 * 1024, "attention: Lk=%d dk=%d needs %zu B of LDS", a.Lk, a.dk, lds);

@@ -107,6 +107,21 @@ def test_encoder_tiny_vs_oracle_ragged(dev, B, L):
     torch.testing.assert_close(h.cpu(), ref, rtol=TOL, atol=TOL)
 
 
+@pytest.mark.parametrize("B,L", [(2, 1), (3, 5), (2, 31), (2, 32), (3, 33), (4, 40), (2, 64), (2, 65), (1, 100), (2, 128)])
+def test_encoder_dk64_mfma_attention_vs_oracle(dev, B, L):
+    """d_kv = 64 takes the MFMA attention kernel (one wave per 32-query tile): every tile count 1..4, ragged L,
+    padded keys and padded queries."""
+    from gdr_amd import ops
+    from oracle import t5_ref
+    cfg = GDRConfig.tiny(d_model=128, d_kv=64, num_heads=3, d_ff=256, num_layers=2)
+    sd = synth.make_state_dict(cfg, seed=31, with_decoder=False)
+    ids, mask = synth.make_tokens(B, L=L, vocab_hi=cfg.vocab_size, seed=B * 1000 + L, min_len=max(1, L // 3))
+    ref = t5_ref.encoder_forward(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask))
+    enc = ops.T5EncoderHandle(cfg, sd, dev)
+    h, _ = enc.forward(torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev))
+    torch.testing.assert_close(h.cpu(), ref, rtol=TOL, atol=TOL)
+
+
 # ------------------------------------------------------------------------------------------- sim + top-k
 def test_sim_topk_c1_vs_reference_golden(dev):
     from gdr_amd import ops
