@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdr_hip.so")
 
 GDR_OK, GDR_EINVAL, GDR_ENOSPC, GDR_EHIP = 0, -1, -2, -3
+SIM_EXHAUSTIVE = 1
 EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL, EPI_BIAS_GELU = range(7)
 
 
@@ -60,8 +61,8 @@ SIGNATURES = {
     "gdr_linear_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "gdr_t5_encoder_workspace_bytes": (_sz, [C.POINTER(GdrT5Dims), _i, _i]),
     "gdr_t5_encoder_forward": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
-    "gdr_sim_topk_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
-    "gdr_sim_topk": (_i, [_vp, _i, _vp, _i64, _i, _i, C.c_int32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gdr_sim_topk_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i]),
+    "gdr_sim_topk": (_i, [_vp, _i, _vp, _i64, _i, _i, C.c_int32, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "gdr_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "gdr_rerank_topk": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "gdr_t5_relative_bucket_table": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),

@@ -33,14 +33,14 @@ struct SimPlan {
   size_t off_val, off_idx, off_cnt, off_thr, total;
 };
 
-static SimPlan make_plan(int B, int64_t N, int k) {
+static SimPlan make_plan(int B, int64_t N, int k, bool exhaustive) {
   SimPlan p{};
   p.tiles_m = (N + TILE - 1) / TILE;
   double target = sqrt((double)k * (double)N);
   if (target < k) target = k;
   int64_t ts = (int64_t)((target + TILE - 1) / TILE);
   if (ts < 1) ts = 1;
-  if (N <= 16384 || p.tiles_m < 4 * ts) {
+  if (exhaustive || N <= 16384 || p.tiles_m < 4 * ts) {
     p.stride = 1;
   } else {
     p.stride = (int)(p.tiles_m / ts);
@@ -138,7 +138,8 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const float* _
                                                                   const int32_t* __restrict__ idxs,
                                                                   const int32_t* __restrict__ cnt, int64_t cap, int G,
                                                                   int B, int k, int kpad, int32_t idx_offset,
-                                                                  float* out_val, int32_t* out_idx) {
+                                                                  float* out_val, int32_t* out_idx,
+                                                                  int32_t* __restrict__ status) {
   __shared__ int hist[256];
   __shared__ int scan[256];
   __shared__ int res[2];
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const float* _
   } else {
     const int c = cnt[q];
     count = c < (int)cap ? c : (int)cap;
+    if (status && threadIdx.x == 0) status[q] = c > (int)cap ? 1 : 0;  // list overflowed: result is a subset's top-k
   }
   auto key_at = [&](int i) -> unsigned long long {
     int64_t a;
@@ -235,14 +237,14 @@ static int next_pow2(int x) {
 
 }  // namespace gdr
 
-extern "C" size_t gdr_sim_topk_workspace_bytes(int B, int64_t N, int d, int k) {
+extern "C" size_t gdr_sim_topk_workspace_bytes(int B, int64_t N, int d, int k, int flags) {
   (void)d;
   if (B <= 0 || N <= 0 || k <= 0) return 0;
-  return gdr::make_plan(B, N, k).total;
+  return gdr::make_plan(B, N, k, (flags & GDR_SIM_EXHAUSTIVE) != 0).total;
 }
 
 extern "C" int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, int d, int k, int32_t idx_offset,
-                            float* out_val, int32_t* out_idx, int32_t* status, void* workspace,
+                            float* out_val, int32_t* out_idx, int32_t* status, int flags, void* workspace,
                             size_t workspace_bytes, void* stream_) {
   using namespace gdr;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -252,7 +254,7 @@ extern "C" int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, in
   GDR_CHECK_ARG(N < 0x7fffffffLL - 256, "sim_topk: shard too large for int32 doc ids");
   GDR_CHECK_ARG(((uintptr_t)Q & 15) == 0 && ((uintptr_t)D & 15) == 0 && ((uintptr_t)workspace & 255) == 0,
                 "sim_topk: Q, D must be 16-byte and workspace 256-byte aligned");
-  const SimPlan p = make_plan(B, N, k);
+  const SimPlan p = make_plan(B, N, k, (flags & GDR_SIM_EXHAUSTIVE) != 0);
   if (workspace_bytes < p.total) {
     set_error("sim_topk: workspace %zu < required %zu", workspace_bytes, p.total);
     return GDR_ENOSPC;
@@ -264,16 +266,9 @@ extern "C" int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, in
   ep.cand_cnt = reinterpret_cast<int32_t*>(ws + p.off_cnt);
   float* thr = reinterpret_cast<float*>(ws + p.off_thr);
   ep.thr = thr;
-  ep.status = status;
+  ep.status = nullptr;  // overflow is reported per query by the select kernel (cnt > cap)
   ep.cap = (int32_t)p.cap;
   ep.tile_stride = p.stride;
-  if (status) {
-    hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), stream);
-    if (e != hipSuccess) {
-      set_error("sim_topk: memset: %s", hipGetErrorString(e));
-      return GDR_EHIP;
-    }
-  }
   ep.mode = 1;
   int rc = launch_sim_gemm(D, N, Q, B, d, ep, stream);
   if (rc) return rc;
@@ -287,7 +282,7 @@ extern "C" int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, in
   }
   const int kpad = next_pow2(k);
   hipLaunchKernelGGL(topk_select_kernel<false>, dim3(B), dim3(SEL_THREADS), kpad * sizeof(unsigned long long), stream,
-                     ep.cand_val, ep.cand_idx, ep.cand_cnt, p.cap, 1, B, k, kpad, idx_offset, out_val, out_idx);
+                     ep.cand_val, ep.cand_idx, ep.cand_cnt, p.cap, 1, B, k, kpad, idx_offset, out_val, out_idx, status);
   GDR_CHECK_LAUNCH("topk_select_kernel");
   return GDR_OK;
 }
@@ -300,7 +295,7 @@ extern "C" int gdr_topk_merge(const float* vals, const int32_t* idx, int G, int 
   GDR_CHECK_ARG(G > 0 && B > 0 && k >= 1 && k <= 1024, "topk_merge: bad shape G=%d B=%d k=%d", G, B, k);
   const int kpad = next_pow2(k);
   hipLaunchKernelGGL(topk_select_kernel<true>, dim3(B), dim3(SEL_THREADS), kpad * sizeof(unsigned long long), stream,
-                     vals, idx, (const int32_t*)nullptr, (int64_t)0, G, B, k, kpad, 0, out_val, out_idx);
+                     vals, idx, (const int32_t*)nullptr, (int64_t)0, G, B, k, kpad, 0, out_val, out_idx, (int32_t*)nullptr);
   GDR_CHECK_LAUNCH("topk_select_kernel<merge>");
   return GDR_OK;
 }

@@ -195,7 +195,7 @@ class DenseModel:
         """compute_similarity + topk(k) fused (never writes the score matrix). Returns (values, int64 indices)."""
         if self._ws is None:
             self._ws = ops.Workspace(q_reps.device)
-        v, i = ops.sim_topk(q_reps.contiguous(), p_reps, k, workspace=self._ws)
+        v, i = ops.sim_topk(q_reps.contiguous(), p_reps, k, workspace=self._ws, exact_on_overflow=True)
         return v, i.to(torch.int64)
 
 

@@ -51,23 +51,39 @@ class Workspace:
         return self.buf
 
 
-def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False):
-    """Fused Q·Dᵀ + per-row top-k — gdr_sim_topk.  Returns (values fp32[B,k], indices int32[B,k])."""
-    _need_cuda(Q, D)
-    Q, D = _f32c(Q), _f32c(D)
+def _sim_topk_raw(Q, D, k, idx_offset, workspace, flags):
     B, d = Q.shape
     N = D.shape[0]
-    if D.shape[1] != d:
-        raise _ffi.GdrError(f"sim_topk: dim mismatch {Q.shape} vs {D.shape}")
-    if k > N:
-        raise RuntimeError("selected index k out of range")          # torch.topk's message
-    need = lib().gdr_sim_topk_workspace_bytes(B, N, d, k)
+    need = lib().gdr_sim_topk_workspace_bytes(B, N, d, k, flags)
     ws = (workspace or Workspace(Q.device)).get(need)
     vals = torch.empty((B, k), dtype=torch.float32, device=Q.device)
     idx = torch.empty((B, k), dtype=torch.int32, device=Q.device)
-    status = torch.empty((1,), dtype=torch.int32, device=Q.device)
-    check(lib().gdr_sim_topk(ptr(Q), B, ptr(D), N, d, k, idx_offset, ptr(vals), ptr(idx), ptr(status), ptr(ws),
+    status = torch.empty((B,), dtype=torch.int32, device=Q.device)
+    check(lib().gdr_sim_topk(ptr(Q), B, ptr(D), N, d, k, idx_offset, ptr(vals), ptr(idx), ptr(status), flags, ptr(ws),
                              ws.numel(), stream_ptr()), "gdr_sim_topk")
+    return vals, idx, status
+
+
+def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_on_overflow=False):
+    """Fused Q·Dᵀ + per-row top-k — gdr_sim_topk.  Returns (values fp32[B,k], indices int32[B,k]).
+    exact_on_overflow=True reads the per-query status back (one host sync) and recomputes any query whose candidate
+    list overflowed (degenerate corpora with tens of thousands of tied docs) exhaustively, so the result is exact for
+    every input; return_status=True hands the device status tensor to the caller instead."""
+    _need_cuda(Q, D)
+    Q, D = _f32c(Q), _f32c(D)
+    if D.shape[1] != Q.shape[1]:
+        raise _ffi.GdrError(f"sim_topk: dim mismatch {Q.shape} vs {D.shape}")
+    if k > D.shape[0]:
+        raise RuntimeError("selected index k out of range")          # torch.topk's message
+    vals, idx, status = _sim_topk_raw(Q, D, k, idx_offset, workspace, 0)
+    if exact_on_overflow:
+        bad = torch.nonzero(status).flatten()
+        if bad.numel():
+            for lo in range(0, bad.numel(), 64):                     # bounded workspace: 64 queries * N * 8 B
+                rows = bad[lo:lo + 64]
+                v2, i2, _ = _sim_topk_raw(Q[rows].contiguous(), D, k, idx_offset, None, _ffi.SIM_EXHAUSTIVE)
+                vals[rows], idx[rows] = v2, i2
+            status = torch.zeros_like(status)
     return (vals, idx, status) if return_status else (vals, idx)
 
 

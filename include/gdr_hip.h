@@ -107,14 +107,17 @@ int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_t* ids, con
  * `Tensor.topk(k, largest=True, sorted=True)` (as at main_models.py:1625).
  *   Q fp32[B,d], D fp32[N,d] (the resident corpus shard) -> out_val fp32[B,k] descending,
  *   out_idx int32[B,k] = row in D + idx_offset.  Ties: higher score first, then lower id.
- *   status (device int32[1], may be NULL): set to 1 if a candidate list overflowed (never observed on
- *   non-degenerate data) — results for that query are then the top-k of a subset.
+ *   status (device int32[B], may be NULL): status[q] = 1 if query q's candidate list overflowed — only possible on
+ *   degenerate data (tens of thousands of docs tied at / above the sampled threshold, e.g. duplicated embeddings);
+ *   its result is then the top-k of a subset.  Re-running those queries with GDR_SIM_EXHAUSTIVE (every score kept,
+ *   workspace B*N*8 bytes) is exact for any input; gdr_amd.ops.sim_topk does that automatically.
  * d % 4 == 0, 1 <= k <= 1024, k <= N.
  * ---------------------------------------------------------------------------------------------- */
-size_t gdr_sim_topk_workspace_bytes(int B, int64_t N, int d, int k);
+#define GDR_SIM_EXHAUSTIVE 1
+size_t gdr_sim_topk_workspace_bytes(int B, int64_t N, int d, int k, int flags);
 int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, int d, int k, int32_t idx_offset,
-                 float* out_val, int32_t* out_idx, int32_t* status, void* workspace, size_t workspace_bytes,
-                 void* stream);
+                 float* out_val, int32_t* out_idx, int32_t* status, int flags, void* workspace,
+                 size_t workspace_bytes, void* stream);
 
 /* Merge of per-shard top-k lists after the RCCL all-gather (no reference analogue):
  * vals/idx [G,B,k] (shard-major) -> [B,k]; same tie rule, so every rank computes identical output. */

@@ -57,11 +57,11 @@ def test_argument_errors_are_reported_without_gpu():
     """Shape validation happens before any launch, so it is testable on CPU."""
     from gdr_amd import _ffi
     l = _ffi.lib()
-    rc = l.gdr_sim_topk(None, 4, None, 100, 768, 10, 0, None, None, None, None, 0, None)
+    rc = l.gdr_sim_topk(None, 4, None, 100, 768, 10, 0, None, None, None, 0, None, 0, None)
     assert rc == _ffi.GDR_EINVAL and b"null" in l.gdr_last_error()
     rc = l.gdr_linear_f32(None, 8, None, 8, None, 8, 4, 4, 8, 0, None, None, 0, None)
     assert rc == _ffi.GDR_EINVAL
-    assert l.gdr_sim_topk_workspace_bytes(512, 320000, 768, 100) > 0
+    assert 0 < l.gdr_sim_topk_workspace_bytes(512, 320000, 768, 100, 0) < l.gdr_sim_topk_workspace_bytes(512, 320000, 768, 100, 1)
 
 
 def test_product_codec_known_answers():
