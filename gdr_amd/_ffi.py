@@ -33,6 +33,18 @@ class GdrT5EncoderWeights(C.Structure):
                 ("layers", C.POINTER(GdrT5EncLayer))]
 
 
+class GdrBertLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_w", "ln1_b", "wi", "bi", "wo2", "bo2", "ln2_w",
+                                          "ln2_b")]
+
+
+class GdrBertWeights(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("d_model", C.c_int32), ("num_heads", C.c_int32), ("d_ff", C.c_int32),
+                ("num_layers", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32), ("eps", C.c_float),
+                ("word_emb", C.c_void_p), ("pos_emb", C.c_void_p), ("type_emb", C.c_void_p), ("emb_ln_w", C.c_void_p),
+                ("emb_ln_b", C.c_void_p), ("layers", C.POINTER(GdrBertLayer))]
+
+
 class GdrT5DecLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln_self", "wqkv", "wo", "ln_cross", "wq_c", "wkv_c", "wo_c", "ln_ff", "wi",
                                           "wo_ff")]
@@ -66,6 +78,8 @@ SIGNATURES = {
     "gdr_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "gdr_rerank_topk": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "gdr_t5_relative_bucket_table": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
+    "gdr_bert_encoder_workspace_bytes": (_sz, [C.POINTER(GdrBertWeights), _i, _i]),
+    "gdr_bert_encoder_forward": (_i, [C.POINTER(GdrBertWeights), _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "gdr_t5_generate_workspace_bytes": (_sz, [C.POINTER(GdrT5DecoderWeights), _i, _i, _i, _i]),
     "gdr_t5_generate": (_i, [C.POINTER(GdrT5DecoderWeights), _vp, _vp, _i, _i, _i, _i, C.c_double, _i, _vp, _vp, _vp,
                              _vp, _vp, _vp, _sz, _vp]),

@@ -129,16 +129,34 @@ class GDRModel:
 
 
 class EncoderModel:
-    """Query side of main_models.py:62-109: `encoder(query_enc=hidden) -> hidden[:, 0]` (CLS pool; `output` is None in
-    the reference).  The BERT/AR2 passage tower (passage=...) is SURVEY §8f "next" and not built."""
+    """main_models.py:62-109.  `encoder(query_enc=hidden) -> hidden[:, 0]` (CLS pool; `output` is None in the reference);
+    `encoder(passage={'input_ids','attention_mask'[, 'token_type_ids']}) -> pooler_output` of the DPR/BERT doc tower
+    (modeling_dpr.py:146-191) when built with `bert=` (an ops.BertEncoderHandle)."""
 
-    def __init__(self, output=None):
-        self.output = output
+    def __init__(self, output=None, bert=None):
+        self.output, self.bert = output, bert
+
+    @staticmethod
+    def from_state_dict(bcfg, state_dict, device, prefix="ctx_encoder.bert_model."):
+        """state_dict with the reference's doc-tower keys; a Lightning checkpoint prefixes them `encoder.model.`."""
+        sd = state_dict.get("state_dict", state_dict)
+        lp = "encoder.model."
+        if any(k.startswith(lp) for k in sd):
+            sd = {k[len(lp):]: v for k, v in sd.items() if k.startswith(lp)}
+        return EncoderModel(bert=ops.BertEncoderHandle(bcfg, sd, device, prefix))
 
     def __call__(self, passage=None, query_enc=None):
         if passage is not None:
-            raise NotImplementedError("doc tower (DPRContextEncoder/BERT) is SURVEY §8f rank 1, not built yet")
+            if self.bert is None:
+                raise _ffi.GdrError("EncoderModel was built without doc-tower weights (use EncoderModel.from_state_dict)")
+            p = {k: v.view(-1, v.size(-1)) for k, v in passage.items()}              # main_models.py:81-82
+            _, pooled = self.bert.forward(p["input_ids"], p.get("attention_mask"), p.get("token_type_ids"),
+                                          want_hidden=False)
+            return pooled
         return self.encode_query(query_enc)
+
+    def encode_passage(self, psg):
+        return None if psg is None else self(passage=psg)
 
     forward = __call__
 

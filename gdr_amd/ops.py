@@ -177,6 +177,58 @@ class T5EncoderHandle:
         return out, pooled
 
 
+class BertEncoderHandle:
+    """Device-resident doc-tower weights (DPRContextEncoder / BertModel keys) + pointer table."""
+
+    def __init__(self, bcfg, sd, device, prefix="ctx_encoder.bert_model."):
+        self.bcfg, self.device = bcfg, device
+        keep = []
+
+        def dev(t):
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t
+
+        e = prefix + "embeddings."
+        self.word, self.pos = dev(sd[e + "word_embeddings.weight"]), dev(sd[e + "position_embeddings.weight"])
+        self.type = dev(sd[e + "token_type_embeddings.weight"])
+        self.eln_w, self.eln_b = dev(sd[e + "LayerNorm.weight"]), dev(sd[e + "LayerNorm.bias"])
+        nl = bcfg["num_layers"]
+        self._layers = (_ffi.GdrBertLayer * nl)()
+        for i in range(nl):
+            p = f"{prefix}encoder.layer.{i}."
+            L = self._layers[i]
+            L.wqkv = dev(torch.cat([sd[p + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0)).data_ptr()
+            L.bqkv = dev(torch.cat([sd[p + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0)).data_ptr()
+            L.wo, L.bo = dev(sd[p + "attention.output.dense.weight"]).data_ptr(), dev(sd[p + "attention.output.dense.bias"]).data_ptr()
+            L.ln1_w = dev(sd[p + "attention.output.LayerNorm.weight"]).data_ptr()
+            L.ln1_b = dev(sd[p + "attention.output.LayerNorm.bias"]).data_ptr()
+            L.wi, L.bi = dev(sd[p + "intermediate.dense.weight"]).data_ptr(), dev(sd[p + "intermediate.dense.bias"]).data_ptr()
+            L.wo2, L.bo2 = dev(sd[p + "output.dense.weight"]).data_ptr(), dev(sd[p + "output.dense.bias"]).data_ptr()
+            L.ln2_w, L.ln2_b = dev(sd[p + "output.LayerNorm.weight"]).data_ptr(), dev(sd[p + "output.LayerNorm.bias"]).data_ptr()
+        self._keep = keep
+        self.struct = _ffi.GdrBertWeights(self.word.shape[0], bcfg["hidden_size"], bcfg["num_heads"], bcfg["d_ff"], nl,
+                                          self.pos.shape[0], self.type.shape[0], bcfg["eps"], self.word.data_ptr(),
+                                          self.pos.data_ptr(), self.type.data_ptr(), self.eln_w.data_ptr(),
+                                          self.eln_b.data_ptr(), self._layers)
+        self.ws = Workspace(device)
+
+    def forward(self, input_ids, attention_mask=None, token_type_ids=None, want_hidden=True):
+        _need_cuda(input_ids, attention_mask, token_type_ids)
+        ids = input_ids.to(torch.int64).contiguous()
+        B, L = ids.shape
+        mask = (torch.ones_like(ids) if attention_mask is None else attention_mask.to(torch.int64)).contiguous()
+        tt = None if token_type_ids is None else token_type_ids.to(torch.int64).contiguous()
+        need = lib().gdr_bert_encoder_workspace_bytes(C.byref(self.struct), B, L)
+        ws = self.ws.get(need)
+        d = self.bcfg["hidden_size"]
+        hid = torch.empty((B, L, d), dtype=torch.float32, device=ids.device) if want_hidden else None
+        pooled = torch.empty((B, d), dtype=torch.float32, device=ids.device)
+        check(lib().gdr_bert_encoder_forward(C.byref(self.struct), ptr(ids), ptr(mask), ptr(tt), B, L, ptr(hid), ptr(pooled),
+                                             ptr(ws), ws.numel(), stream_ptr()), "gdr_bert_encoder_forward")
+        return hid, pooled
+
+
 class T5DecoderHandle:
     """Device-resident decoder + adaptor + head weights and the pointer table gdr_t5_generate reads.
     Load-time re-layouts (pure data movement / weight-only algebra, done once):

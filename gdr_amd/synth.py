@@ -165,3 +165,47 @@ def make_logit_table(B: int, max_len: int, Vd: int, eos_boost: float, seed: int)
     table = g.standard_normal((B, max_len, Vd, Vd)).astype(np.float32)
     table[..., 1] += np.float32(eos_boost) * np.linspace(-1, 1, max_len)[None, :, None].astype(np.float32)
     return table
+
+
+BERT_PREFIX = "ctx_encoder.bert_model."
+
+
+def bert_config(tiny=False):
+    """DPRConfig defaults = bert-base-uncased (transformers/configuration_dpr.py:81-93), or a tiny test shape."""
+    if tiny:
+        return dict(vocab_size=96, hidden_size=128, num_heads=2, d_ff=256, num_layers=2, max_pos=160, type_vocab=2, eps=1e-12)
+    return dict(vocab_size=30522, hidden_size=768, num_heads=12, d_ff=3072, num_layers=12, max_pos=512, type_vocab=2, eps=1e-12)
+
+
+def make_bert_state_dict(bcfg, seed=4321):
+    """state_dict of the reference's doc tower `DPRContextEncoder` (keys of SURVEY Appendix C); BERT init scale 0.02,
+    with jittered LayerNorm weights / biases so that a kernel ignoring them fails parity."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    d, ff = bcfg["hidden_size"], bcfg["d_ff"]
+    sd = {}
+
+    def normal(shape, std=0.02):
+        return _t(g.standard_normal(shape, dtype=np.float32) * np.float32(std))
+
+    e = BERT_PREFIX + "embeddings."
+    sd[e + "word_embeddings.weight"] = normal((bcfg["vocab_size"], d), 0.5)
+    sd[e + "position_embeddings.weight"] = normal((bcfg["max_pos"], d), 0.2)
+    sd[e + "token_type_embeddings.weight"] = normal((bcfg["type_vocab"], d), 0.2)
+    sd[e + "LayerNorm.weight"] = _t(1.0 + 0.1 * g.standard_normal(d, dtype=np.float32))
+    sd[e + "LayerNorm.bias"] = normal((d,), 0.05)
+    for i in range(bcfg["num_layers"]):
+        p = f"{BERT_PREFIX}encoder.layer.{i}."
+        for n in ("query", "key", "value"):
+            sd[p + f"attention.self.{n}.weight"] = normal((d, d), d ** -0.5)
+            sd[p + f"attention.self.{n}.bias"] = normal((d,), 0.05)
+        sd[p + "attention.output.dense.weight"] = normal((d, d), d ** -0.5)
+        sd[p + "attention.output.dense.bias"] = normal((d,), 0.05)
+        sd[p + "attention.output.LayerNorm.weight"] = _t(1.0 + 0.1 * g.standard_normal(d, dtype=np.float32))
+        sd[p + "attention.output.LayerNorm.bias"] = normal((d,), 0.05)
+        sd[p + "intermediate.dense.weight"] = normal((ff, d), d ** -0.5)
+        sd[p + "intermediate.dense.bias"] = normal((ff,), 0.05)
+        sd[p + "output.dense.weight"] = normal((d, ff), ff ** -0.5)
+        sd[p + "output.dense.bias"] = normal((d,), 0.05)
+        sd[p + "output.LayerNorm.weight"] = _t(1.0 + 0.1 * g.standard_normal(d, dtype=np.float32))
+        sd[p + "output.LayerNorm.bias"] = normal((d,), 0.05)
+    return sd

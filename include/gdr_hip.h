@@ -144,6 +144,33 @@ int gdr_t5_relative_bucket_table(int bidirectional, int num_buckets, int max_dis
                                  int32_t* out_host);
 
 /* ------------------------------------------------------------------------------------------------
+ * Doc tower — replaces `EncoderModel.forward(passage=...)` (main_models.py:79-89) = DPRContextEncoder
+ * (transformers/modeling_dpr.py:146-191) over BertModel (transformers/modeling_bert.py); pooled = hidden[:,0].
+ * Producer of the corpus matrix D (Data_process/NQ_dataset/bert/bert.py:69-71).  L <= 128 (encoder_max_len).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *wqkv, *bqkv;      /* [3d,d],[3d]  attention.self.{query,key,value} row-concat   */
+  const float *wo, *bo;          /* attention.output.dense                                       */
+  const float *ln1_w, *ln1_b;    /* attention.output.LayerNorm                                   */
+  const float *wi, *bi;          /* intermediate.dense (GeLU, erf form)                          */
+  const float *wo2, *bo2;        /* output.dense                                                 */
+  const float *ln2_w, *ln2_b;    /* output.LayerNorm                                             */
+} GdrBertLayer;
+
+typedef struct {
+  int32_t vocab_size, d_model, num_heads, d_ff, num_layers, max_pos, type_vocab;
+  float eps;
+  const float *word_emb, *pos_emb, *type_emb, *emb_ln_w, *emb_ln_b;
+  const GdrBertLayer* layers;    /* host array [num_layers] */
+} GdrBertWeights;
+
+size_t gdr_bert_encoder_workspace_bytes(const GdrBertWeights* w, int B, int L);
+/* ids/mask int64[B,L], token_type_ids int64[B,L] or NULL (zeros); out_hidden fp32[B,L,d] and/or out_pooled fp32[B,d]. */
+int gdr_bert_encoder_forward(const GdrBertWeights* w, const int64_t* ids, const int64_t* mask,
+                             const int64_t* token_type_ids, int B, int L, float* out_hidden, float* out_pooled,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Docid beam decode — replaces `_generate_beam_search` (transformers/generation_utils.py:629-921, with
  * `BeamHypotheses` :1052-1099) driving `T5ForConditionalGeneration.forward`'s decode branch
  * (transformers/modeling_t5.py:1529-1646) as GDR calls it (main_models.py:1380-1397): greedy beams,

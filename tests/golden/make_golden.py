@@ -451,6 +451,36 @@ def g_rerank(main_models):
          cluster_strs=cluster_strs, cluster_size=7)
 
 
+def g_doc_tower():
+    """G10: the doc tower `DPRContextEncoder(DPRConfig(...))` (modeling_dpr.py:146-191 over modeling_bert.py), tiny shape
+    with ragged padding, and bert-base shape B=2, L=128 (pooled + a few rows)."""
+    from transformers.configuration_dpr import DPRConfig
+    from transformers.modeling_dpr import DPRContextEncoder
+    out = {}
+    for name, tiny, B, L in (("tiny", True, 5, 37), ("base", False, 2, 128)):
+        bc = synth.bert_config(tiny)
+        cfg = DPRConfig(vocab_size=bc["vocab_size"], hidden_size=bc["hidden_size"], num_hidden_layers=bc["num_layers"],
+                        num_attention_heads=bc["num_heads"], intermediate_size=bc["d_ff"],
+                        max_position_embeddings=bc["max_pos"], type_vocab_size=bc["type_vocab"], projection_dim=0)
+        m = DPRContextEncoder(cfg)
+        sd = synth.make_bert_state_dict(bc, seed=4321)
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all(("pooler" in k or "position_ids" in k) for k in missing), (missing, unexpected)
+        m.eval()
+        ids, mask = synth.make_tokens(B, L=L, vocab_hi=bc["vocab_size"], seed=17, min_len=3)
+        with torch.no_grad():
+            o = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), return_dict=True,
+                  output_hidden_states=True)
+            last = o.hidden_states[-1]
+        out[name + "_ids"], out[name + "_mask"] = ids, mask
+        out[name + "_pooled"] = o.pooler_output
+        if tiny:
+            out[name + "_hidden"] = last
+        else:
+            out[name + "_rows"] = last[:, [1, 64, 127]]
+    save("g10_doc_tower", seed=4321, **out)
+
+
 def g_cli():
     """G9: the reference argparse namespace (main.py:260-448) for no flags and for infer.sh's flags (without
     --trivia, which the reference parser rejects).  main.py itself cannot be imported (nltk / pytorch_lightning),
@@ -479,7 +509,7 @@ def g_cli():
 
 
 FIXTURES = ["buckets", "encoder_tiny", "encoder_base", "sim_topk", "decode_logits_tiny", "generate_tiny",
-            "generate_base", "beam_table", "codec", "metrics", "rerank", "cli"]
+            "generate_base", "beam_table", "codec", "metrics", "rerank", "cli", "doc_tower"]
 
 
 def main():

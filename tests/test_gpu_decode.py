@@ -135,3 +135,21 @@ def test_two_stage_retrieval_vs_oracle(dev):
     for b in range(B):
         for a in range(len(args.score_rate)):
             assert out["inf_index_batch"][b][a] == [str(x) for x in ref[b][a][1].tolist()]
+
+
+def test_doc_tower_vs_reference_golden(dev):
+    """DPRContextEncoder / BERT doc tower: tiny with ragged padding, and bert-base shape L=128."""
+    from gdr_amd.modeling import EncoderModel
+    g = golden("g10_doc_tower")
+    for name, tiny, tol in (("tiny", True, 1e-4), ("base", False, 2e-4)):
+        bc = synth.bert_config(tiny)
+        sd = synth.make_bert_state_dict(bc, seed=int(g["seed"]))
+        enc = EncoderModel.from_state_dict(bc, {"encoder.model." + k: v for k, v in sd.items()}, dev)   # Lightning prefix
+        ids, mask = torch.from_numpy(g[name + "_ids"]).to(dev), torch.from_numpy(g[name + "_mask"]).to(dev)
+        pooled = enc(passage={"input_ids": ids, "attention_mask": mask})
+        np.testing.assert_allclose(pooled.cpu().numpy(), g[name + "_pooled"], rtol=tol, atol=tol)
+        hid, _ = enc.bert.forward(ids, mask)
+        if tiny:
+            np.testing.assert_allclose(hid.cpu().numpy(), g["tiny_hidden"], rtol=tol, atol=tol)
+        else:
+            np.testing.assert_allclose(hid[:, [1, 64, 127]].cpu().numpy(), g["base_rows"], rtol=tol, atol=tol)

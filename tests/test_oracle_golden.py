@@ -183,3 +183,17 @@ def test_rerank_matches_reference():
     for b in range(B):
         for a in range(len(g["alphas"])):
             assert out[b][a][1].tolist() == g["pred"][b, a].tolist()
+
+
+def test_doc_tower_matches_reference():
+    from oracle import bert_ref
+    g = golden("g10_doc_tower")
+    for name, tiny in (("tiny", True), ("base", False)):
+        bc = synth.bert_config(tiny)
+        sd = synth.make_bert_state_dict(bc, seed=int(g["seed"]))
+        h, pooled = bert_ref.bert_forward(sd, bc, torch.from_numpy(g[name + "_ids"]), torch.from_numpy(g[name + "_mask"]))
+        np.testing.assert_allclose(pooled.numpy(), g[name + "_pooled"], rtol=2e-5, atol=2e-5)
+        if tiny:
+            np.testing.assert_allclose(h.numpy(), g["tiny_hidden"], rtol=2e-5, atol=2e-5)
+        else:
+            np.testing.assert_allclose(h[:, [1, 64, 127]].numpy(), g["base_rows"], rtol=2e-5, atol=2e-5)
