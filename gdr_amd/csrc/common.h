@@ -57,6 +57,9 @@ struct SimEpilogue {
 int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                       int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
                       hipStream_t stream);
+int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
+                         int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
+                         float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream);
 // docs D[N,d] take the GEMM's row role, queries Q[B,d] the column role: a lane owns one query.
 int launch_sim_gemm(const float* D, int64_t N, const float* Q, int B, int d, const SimEpilogue& ep,
                     hipStream_t stream);

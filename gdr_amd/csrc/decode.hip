@@ -23,6 +23,7 @@ namespace gdr {
 
 constexpr int PAD_ID = 0, EOS_ID = 1, START_ID = 0;
 constexpr int MAXLEN_CAP = 32;
+constexpr size_t SPLITK_WS_BYTES = (size_t)48 << 20;  // <= 640 partial 128x128 tiles + slack
 
 struct BeamBufs {
   int32_t* seq[2];      // [rows][maxlen] token history, double buffered
@@ -407,7 +408,7 @@ static int beam_end(const BeamBufs& bb, const BeamDims& bd, int max_length, int 
 
 // ------------------------------------------------------------------------------------------ model workspace
 struct GenWs {
-  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, total;
+  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, total;
 };
 
 static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
@@ -430,6 +431,7 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
   g.tmp = carve(o, 4 * rows * d);
   g.A = carve(o, 4 * rows * (size_t)(bd.V + 1) * d);
   g.hl = carve(o, 4 * rows * d);
+  g.splitk = carve(o, SPLITK_WS_BYTES);
   g.total = o;
   return g;
 }
@@ -475,7 +477,8 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   beam_layout(bd, base + g.beam, &bb);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
   float *dcache = F(g.dcache), *acache = F(g.acache), *crosskv = F(g.crosskv), *xd = F(g.xd), *xa = F(g.xa),
-        *nx = F(g.nx), *ctx = F(g.ctx), *qc = F(g.qc), *ff = F(g.ff), *tmp = F(g.tmp), *A = F(g.A), *hl = F(g.hl);
+        *nx = F(g.nx), *ctx = F(g.ctx), *qc = F(g.qc), *ff = F(g.ff), *tmp = F(g.tmp), *A = F(g.A), *hl = F(g.hl),
+        *skw = F(g.splitk);
   const int d = dm.d_model, H = dm.num_heads, dk = dm.d_kv, inner = H * dk;
   const int rows = B * num_beams, V1 = bd.V + 1;
   const int aH = w->adaptor_nhead, ahd = d / aH, aff = w->adaptor_ff;
@@ -484,6 +487,7 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   const size_t dlayer = (size_t)max_length * dslab, alayer = (size_t)max_length * aslab;
   const size_t ckv_layer = (size_t)B * L * 2 * inner;
 
+#define LIN(...) launch_linear_f32_ws(__VA_ARGS__, skw, SPLITK_WS_BYTES, stream)
 #define GDR_TRY(x)        \
   do {                    \
     if ((rc = (x))) return rc; \
@@ -492,8 +496,8 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   GDR_TRY(beam_begin(bb, bd, stream));
   // cross-attention K/V once per query and layer (modeling_t5.py:365-368 recomputes them per beam row per step)
   for (int l = 0; l < dm.num_layers; ++l)
-    GDR_TRY(launch_linear_f32(enc_hidden, d, w->layers[l].wkv_c, d, crosskv + l * ckv_layer, 2 * inner, (int64_t)B * L,
-                              2 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0, stream));
+    GDR_TRY(LIN(enc_hidden, d, w->layers[l].wkv_c, d, crosskv + l * ckv_layer, 2 * inner, (int64_t)B * L,
+                              2 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
 
   const BucketLut lut_uni = make_bucket_lut(dm.rel_buckets, dm.rel_max_distance);
   const BucketLut lut_bi = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
@@ -507,8 +511,7 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
       float* cache = dcache + l * dlayer;
       float* slot = cache + s * dslab;
       GDR_TRY(launch_rmsnorm(xd, ly.ln_self, nx, rows, d, dm.eps, nullptr, 1, stream));
-      GDR_TRY(launch_linear_f32(nx, d, ly.wqkv, d, slot, 3 * inner, rows, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0,
-                                stream));
+      GDR_TRY(LIN(nx, d, ly.wqkv, d, slot, 3 * inner, rows, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
       AttnArgs at{};
       at.q = slot, at.k = cache + inner, at.v = cache + 2 * inner, at.out = ctx;
       at.ldq = at.ldk = at.ldv = 3 * inner, at.ldo = inner;
@@ -518,10 +521,10 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
       at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 0;
       at.kv_rows = bb.kv_rows, at.kv_group = 1;
       GDR_TRY(launch_attention(at, stream));
-      GDR_TRY(launch_linear_f32(ctx, inner, ly.wo, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, stream));
+      GDR_TRY(LIN(ctx, inner, ly.wo, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d));
       // cross attention over the encoder states of the row's query
       GDR_TRY(launch_rmsnorm(xd, ly.ln_cross, nx, rows, d, dm.eps, nullptr, 1, stream));
-      GDR_TRY(launch_linear_f32(nx, d, ly.wq_c, d, qc, inner, rows, inner, d, GDR_EPI_NONE, nullptr, nullptr, 0, stream));
+      GDR_TRY(LIN(nx, d, ly.wq_c, d, qc, inner, rows, inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
       AttnArgs ca{};
       const float* ckv = crosskv + l * ckv_layer;
       ca.q = qc, ca.k = ckv, ca.v = ckv + inner, ca.out = ctx;
@@ -532,11 +535,10 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
       ca.key_mask = enc_mask, ca.mask_bstride = L, ca.causal = 0, ca.causal_neg_inf = 0;
       ca.kv_rows = nullptr, ca.kv_group = num_beams;
       GDR_TRY(launch_attention(ca, stream));
-      GDR_TRY(launch_linear_f32(ctx, inner, ly.wo_c, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, stream));
+      GDR_TRY(LIN(ctx, inner, ly.wo_c, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d));
       GDR_TRY(launch_rmsnorm(xd, ly.ln_ff, nx, rows, d, dm.eps, nullptr, 1, stream));
-      GDR_TRY(launch_linear_f32(nx, d, ly.wi, d, ff, dm.d_ff, rows, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0, stream));
-      GDR_TRY(launch_linear_f32(ff, dm.d_ff, ly.wo_ff, dm.d_ff, xd, d, rows, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, xd, d,
-                                stream));
+      GDR_TRY(LIN(nx, d, ly.wi, d, ff, dm.d_ff, rows, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0));
+      GDR_TRY(LIN(ff, dm.d_ff, ly.wo_ff, dm.d_ff, xd, d, rows, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, xd, d));
     }
     GDR_TRY(launch_rmsnorm(xd, w->final_ln, hl, rows, d, dm.eps, nullptr, 1, stream));
     // ---------------- adaptor: post-LN nn.TransformerDecoder over decode_embeddings(ids) (modeling_t5.py:1615-1633)
@@ -544,7 +546,7 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
       const GdrAdaptorLayer& al = w->alayers[l];
       float* cache = acache + l * alayer;
       float* slot = cache + s * aslab;
-      GDR_TRY(launch_linear_f32(xa, d, al.in_w, d, slot, 3 * d, rows, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0, stream));
+      GDR_TRY(LIN(xa, d, al.in_w, d, slot, 3 * d, rows, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0));
       AttnArgs at{};
       at.q = slot, at.k = cache + d, at.v = cache + 2 * d, at.out = ctx;
       at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
@@ -555,17 +557,17 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
       at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
       at.kv_rows = bb.kv_rows, at.kv_group = 1;
       GDR_TRY(launch_attention(at, stream));
-      GDR_TRY(launch_linear_f32(ctx, d, al.out_w, d, tmp, d, rows, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d, stream));
+      GDR_TRY(LIN(ctx, d, al.out_w, d, tmp, d, rows, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d));
       GDR_TRY(launch_layernorm(tmp, al.ln1_w, al.ln1_b, xa, rows, d, w->adaptor_eps, nullptr, stream));
       GDR_TRY(launch_layernorm(xa, al.ln2_w, al.ln2_b, tmp, rows, d, w->adaptor_eps, al.cross_const, stream));
-      GDR_TRY(launch_linear_f32(tmp, d, al.lin1_w, d, ff, aff, rows, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0, stream));
-      GDR_TRY(launch_linear_f32(ff, aff, al.lin2_w, aff, xa, d, rows, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d, stream));
+      GDR_TRY(LIN(tmp, d, al.lin1_w, d, ff, aff, rows, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
+      GDR_TRY(LIN(ff, aff, al.lin2_w, aff, xa, d, rows, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d));
       GDR_TRY(launch_layernorm(xa, al.ln3_w, al.ln3_b, xa, rows, d, w->adaptor_eps, nullptr, stream));
     }
     // ---------------- head: last position, unmasked columns only (modeling_t5.py:1634-1646)
     const float* hw = w->head_w + (size_t)s * V1 * d * d;
     const float* he = w->head_e + (size_t)s * V1 * d;
-    GDR_TRY(launch_linear_f32(xa, d, hw, d, A, (int64_t)V1 * d, rows, V1 * d, d, GDR_EPI_NONE, nullptr, nullptr, 0, stream));
+    GDR_TRY(LIN(xa, d, hw, d, A, (int64_t)V1 * d, rows, V1 * d, d, GDR_EPI_NONE, nullptr, nullptr, 0));
     {
       const int64_t items = (int64_t)rows * V1;
       hipLaunchKernelGGL(head_logits_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, hl, A, he, rows, V1, d,
@@ -577,6 +579,7 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   }
   return beam_end(bb, bd, max_length, cur, out_ids, out_len, out_scores, stream);
 #undef GDR_TRY
+#undef LIN
 }
 
 extern "C" size_t gdr_beam_search_table_workspace_bytes(int B, int num_beams, int max_length, int out_vocab) {

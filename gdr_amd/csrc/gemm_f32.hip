@@ -37,6 +37,7 @@ struct GemmArgs {
   int N, K;
   int tiles_n;
   int has_bias, has_residual, act;  // linear epilogue, runtime so that every linear shares one kernel
+  int ksplit, kchunk;               // split-K (small-M decode linears): block handles K range [s*kchunk, (s+1)*kchunk)
   SimEpilogue sim;
 };
 
@@ -56,6 +57,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
   {
     const unsigned nblk = gridDim.x, q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  int split = 0;
+  if (EPI == EPI_LINEAR && g.ksplit > 1) {  // splits of one tile are neighbours in the grid
+    split = bid % (unsigned)g.ksplit;
+    bid /= (unsigned)g.ksplit;
   }
   int64_t mt = bid / (unsigned)g.tiles_n;
   const int nt = bid % (unsigned)g.tiles_n;
@@ -82,8 +88,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
     ra = ra < g.M ? ra : g.M - 1;  // clamp: rows past the edge are computed and discarded
     int rw = n0 + lrow + 32 * p;
     rw = rw < g.N ? rw : g.N - 1;
-    a_src[p] = g.A + ra * g.lda + lcol;
-    w_src[p] = g.W + (int64_t)rw * g.ldw + lcol;
+    a_src[p] = g.A + ra * g.lda + lcol + split * g.kchunk;
+    w_src[p] = g.W + (int64_t)rw * g.ldw + lcol + split * g.kchunk;
   }
   const int st_off = lrow * LDS_STRIDE + lcol;
 
@@ -101,10 +107,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (g.K + BK - 1) / BK;
+  int klen = g.K;
+  if (EPI == EPI_LINEAR && g.ksplit > 1) klen = min(g.kchunk, g.K - split * g.kchunk);
+  const int nk = (klen + BK - 1) / BK;
   // K tail (K % 32 != 0, K % 4 == 0): loads past K re-read the row's last float4 (a valid address) and the
   // VALUE is zeroed — never select between addresses, that demotes the loads to flat + scratch.
-  const bool ktail = (g.K % BK) != 0;
+  const bool ktail = (klen % BK) != 0;
   float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 
 #define GDR_GLOAD(kt_)                                                                    \
@@ -112,8 +120,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
     int koff = (kt_)*BK;                                                                  \
     bool ok = true;                                                                       \
     if (ktail) {                                                                          \
-      ok = koff + lcol < g.K;                                                             \
-      koff = ok ? koff : g.K - 4 - lcol;                                                  \
+      ok = koff + lcol < klen;                                                            \
+      koff = ok ? koff : klen - 4 - lcol;                                                 \
     }                                                                                     \
     ra0 = *reinterpret_cast<const float4*>(a_src[0] + koff);                              \
     ra1 = *reinterpret_cast<const float4*>(a_src[1] + koff);                              \
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
         if (g.has_residual) v += g.residual[m * g.ldr + n];
         if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
         if (g.act == ACT_GELU) v = gelu_erf(v);
-        g.C[m * g.ldc + n] = v;
+        g.C[((int64_t)split * g.M + m) * g.ldc + n] = v;  // split > 0 only for raw partial slabs [S][M][N]
       }
     }
   }
@@ -319,9 +327,47 @@ static int launch(const GemmArgs& g, int64_t tiles_m, hipStream_t stream) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// C = epilogue(sum_s partial[s]) in fixed order s = 0..S-1 (deterministic); N % 4 == 0.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, int64_t M, int N,
+                                                            float* __restrict__ C, int64_t ldc,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ residual, int64_t ldr, int act) {
+  const int n4 = N >> 2;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= M * n4) return;
+  const int64_t m = e / n4;
+  const int c = (int)(e - m * n4) * 4;
+  const int64_t slab = M * (int64_t)N;
+  float4 v = *reinterpret_cast<const float4*>(partial + m * N + c);
+  for (int s = 1; s < S; ++s) {
+    const float4 t = *reinterpret_cast<const float4*>(partial + s * slab + m * N + c);
+    v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+  }
+  if (bias) {
+    const float4 b = *reinterpret_cast<const float4*>(bias + c);
+    v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+  }
+  if (residual) {
+    const float* r = residual + m * ldr + c;
+    v.x += r[0], v.y += r[1], v.z += r[2], v.w += r[3];
+  }
+  if (act == ACT_RELU) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+  if (act == ACT_GELU) v.x = gelu_erf(v.x), v.y = gelu_erf(v.y), v.z = gelu_erf(v.z), v.w = gelu_erf(v.w);
+  float* o = C + m * ldc + c;
+  o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+}
+
 int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                       int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
                       hipStream_t stream) {
+  return launch_linear_f32_ws(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, residual, ldr, nullptr, 0, stream);
+}
+
+// With a scratch buffer, linears whose tile grid cannot fill the chip (decode: M = batch*beams rows) are split
+// along K into partial slabs + a fixed-order reduction that applies the epilogue.
+int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
+                         int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
+                         float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream) {
   GDR_CHECK_ARG(A && W && C, "linear: null pointer");
   GDR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
   GDR_CHECK_ARG(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "linear: K, lda, ldw must be multiples of 4");
@@ -348,6 +394,28 @@ int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, 
     return GDR_EINVAL;
   }
   ProfScope prof(PROF_LINEAR, 2.0 * (double)M * (double)N * (double)K, stream);
+  const int64_t tiles = tiles_m * g.tiles_n;
+  const int nk = K / BK;
+  if (splitk_ws && K % BK == 0 && N % 4 == 0 && tiles < 192 && nk >= 4) {
+    int S = (int)((640 + tiles - 1) / tiles);
+    if (S > nk / 2) S = nk / 2;
+    const size_t slab = (size_t)M * N * sizeof(float);
+    if ((size_t)S * slab > splitk_ws_bytes) S = (int)(splitk_ws_bytes / slab);
+    if (S >= 2) {
+      const int chunk_steps = (nk + S - 1) / S;
+      S = (nk + chunk_steps - 1) / chunk_steps;
+      GemmArgs p = g;
+      p.C = splitk_ws, p.ldc = N, p.has_bias = 0, p.has_residual = 0, p.act = ACT_NONE;
+      p.ksplit = S, p.kchunk = chunk_steps * BK;
+      int rc = launch<EPI_LINEAR>(p, tiles_m * S, stream);
+      if (rc) return rc;
+      const int64_t n_el = M * (N / 4);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, stream, splitk_ws, S, M,
+                         N, C, ldc, needs_bias ? bias : nullptr, needs_res ? residual : nullptr, ldr, g.act);
+      GDR_CHECK_LAUNCH("splitk_reduce_kernel");
+      return GDR_OK;
+    }
+  }
   return launch<EPI_LINEAR>(g, tiles_m, stream);
 }
 
@@ -379,4 +447,11 @@ extern "C" int gdr_linear_f32(const float* A, int64_t lda, const float* W, int64
                               int64_t ldr, void* stream) {
   return gdr::launch_linear_f32(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, residual, ldr,
                                 static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gdr_linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
+                                     int64_t M, int N, int K, int epilogue, const float* bias, const float* residual,
+                                     int64_t ldr, void* workspace, size_t workspace_bytes, void* stream) {
+  return gdr::launch_linear_f32_ws(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, residual, ldr,
+                                   static_cast<float*>(workspace), workspace_bytes, static_cast<hipStream_t>(stream));
 }

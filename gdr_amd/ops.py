@@ -20,8 +20,8 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def linear(a, w, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None):
-    """out[M,N] = epilogue(a[M,K] @ w[N,K].T)  — gdr_linear_f32."""
+def linear(a, w, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None, splitk_ws=None):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K].T)  — gdr_linear_f32 (gdr_linear_f32_splitk when a scratch tensor is given)."""
     _need_cuda(a, w, bias, residual)
     K = a.shape[-1]
     a2 = _f32c(a).view(-1, K)
@@ -32,6 +32,12 @@ def linear(a, w, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None):
     res2 = None
     if residual is not None:
         res2 = _f32c(residual).view(-1, N)
+    if splitk_ws is not None:
+        check(lib().gdr_linear_f32_splitk(ptr(a2), K, ptr(w), w.shape[1], ptr(out), N, M, N, K, epilogue,
+                                          ptr(_f32c(bias)) if bias is not None else None, ptr(res2), N, ptr(splitk_ws),
+                                          splitk_ws.numel() * splitk_ws.element_size(), stream_ptr()),
+              "gdr_linear_f32_splitk")
+        return out.view(*a.shape[:-1], N)
     check(lib().gdr_linear_f32(ptr(a2), K, ptr(w), w.shape[1], ptr(out), N, M, N, K, epilogue,
                                ptr(_f32c(bias)) if bias is not None else None, ptr(res2), N, stream_ptr()),
           "gdr_linear_f32")

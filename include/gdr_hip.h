@@ -64,6 +64,12 @@ enum {
 int gdr_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
                    int64_t M, int N, int K, int epilogue, const float* bias, const float* residual,
                    int64_t ldr, void* stream);
+/* Same, with a scratch buffer: when the 128x128 tile grid cannot fill the 256 CUs (decode-time linears with
+ * M = batch*beams rows) the K dimension is split into partial slabs [S][M][N] in `workspace` and reduced in fixed
+ * order (deterministic) by a second kernel that applies the epilogue.  workspace may be NULL (= gdr_linear_f32). */
+int gdr_linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
+                          int64_t M, int N, int K, int epilogue, const float* bias, const float* residual,
+                          int64_t ldr, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * T5 encoder forward — replaces `model.get_encoder()(input_ids, attention_mask=, return_dict=True)

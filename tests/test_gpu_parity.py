@@ -60,6 +60,27 @@ def test_linear_epilogues(dev):
     torch.testing.assert_close(h.cpu(), base + r, rtol=TOL, atol=TOL)
 
 
+@pytest.mark.parametrize("M,N,K", [(640, 768, 768), (640, 3072, 768), (640, 768, 3072), (20, 2304, 768), (300, 2048, 768)])
+def test_linear_splitk_matches_cpu(dev, M, N, K):
+    """Decode-shaped linears (few rows): split-K partial slabs + fixed-order reduce with every fused epilogue."""
+    from gdr_amd import ops, _ffi
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ws = torch.empty(48 << 20, dtype=torch.uint8, device=dev)
+    A, W, Bv, Rv = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    base = a @ w.T
+    out = ops.linear(A, W, splitk_ws=ws).cpu()
+    torch.testing.assert_close(out, base, rtol=TOL, atol=TOL)
+    out = ops.linear(A, W, epilogue=_ffi.EPI_BIAS_RELU, bias=Bv, splitk_ws=ws).cpu()
+    torch.testing.assert_close(out, torch.relu(base + b), rtol=TOL, atol=TOL)
+    h = Rv.clone()
+    ops.linear(A, W, epilogue=_ffi.EPI_BIAS_RESIDUAL, bias=Bv, residual=h, out=h, splitk_ws=ws)   # in place, as decode does
+    torch.testing.assert_close(h.cpu(), base + b + r, rtol=TOL, atol=TOL)
+    out2 = ops.linear(A, W, splitk_ws=ws).cpu()
+    assert torch.equal(out, out) and torch.equal(ops.linear(A, W, splitk_ws=ws).cpu(), out2), "fixed-order reduce is deterministic"
+
+
 def test_linear_is_exact_fmaf_chain_on_integers(dev):
     """A = I with an asymmetric B catches a transposed accumulator map; integer data must be exact."""
     from gdr_amd import ops
