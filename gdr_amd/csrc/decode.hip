@@ -406,9 +406,28 @@ static int beam_end(const BeamBufs& bb, const BeamDims& bd, int max_length, int 
   return GDR_OK;
 }
 
+// The adaptor chain (decode_embeddings -> 4 post-LN layers) and the T5 decoder stack of one step are independent until
+// the head consumes both, and each of their kernels fills only part of the chip at decode batch sizes: they run
+// concurrently, the adaptor on a library-owned side stream forked / joined with events (graph-capturable pattern).
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+static SideStream& side_stream() {
+  static SideStream ss = [] {
+    SideStream x;
+    x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+    return x;
+  }();
+  return ss;
+}
+
 // ------------------------------------------------------------------------------------------ model workspace
 struct GenWs {
-  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, total;
+  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, total;
 };
 
 static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
@@ -432,6 +451,9 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
   g.A = carve(o, 4 * rows * (size_t)(bd.V + 1) * d);
   g.hl = carve(o, 4 * rows * d);
   g.splitk = carve(o, SPLITK_WS_BYTES);
+  g.ctx2 = carve(o, 4 * rows * d);                       // adaptor chain runs on a side stream: own scratch
+  g.ff2 = carve(o, 4 * rows * (size_t)w.adaptor_ff);
+  g.splitk2 = carve(o, SPLITK_WS_BYTES);
   g.total = o;
   return g;
 }
@@ -478,7 +500,7 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
   float *dcache = F(g.dcache), *acache = F(g.acache), *crosskv = F(g.crosskv), *xd = F(g.xd), *xa = F(g.xa),
         *nx = F(g.nx), *ctx = F(g.ctx), *qc = F(g.qc), *ff = F(g.ff), *tmp = F(g.tmp), *A = F(g.A), *hl = F(g.hl),
-        *skw = F(g.splitk);
+        *skw = F(g.splitk), *ctx2 = F(g.ctx2), *ff2 = F(g.ff2), *skw2 = F(g.splitk2);
   const int d = dm.d_model, H = dm.num_heads, dk = dm.d_kv, inner = H * dk;
   const int rows = B * num_beams, V1 = bd.V + 1;
   const int aH = w->adaptor_nhead, ahd = d / aH, aff = w->adaptor_ff;
@@ -488,6 +510,7 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   const size_t ckv_layer = (size_t)B * L * 2 * inner;
 
 #define LIN(...) launch_linear_f32_ws(__VA_ARGS__, skw, SPLITK_WS_BYTES, stream)
+#define LIN2(...) launch_linear_f32_ws(__VA_ARGS__, skw2, SPLITK_WS_BYTES, as)
 #define GDR_TRY(x)        \
   do {                    \
     if ((rc = (x))) return rc; \
@@ -503,8 +526,45 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   const BucketLut lut_bi = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
   int cur = 0;
   for (int s = 0; s + 1 < max_length; ++s) {  // position s, cur_len = s + 1 (generation_utils.py:676)
+    SideStream& ss = side_stream();
+    hipStream_t as = ss.ok ? ss.s : stream;   // adaptor stream
     GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows, d, dm.vocab_size, xd, stream));
-    GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows, d, dm.vocab_size, xa, stream));
+    if (ss.ok) {
+      if (hipEventRecord(ss.fork, stream) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess) {
+        set_error("generate: fork to the adaptor stream failed");
+        return GDR_EHIP;
+      }
+    }
+    GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows, d, dm.vocab_size, xa, as));
+    // ---------------- adaptor: post-LN nn.TransformerDecoder over decode_embeddings(ids) (modeling_t5.py:1615-1633)
+    for (int l = 0; l < w->adaptor_layers; ++l) {
+      const GdrAdaptorLayer& al = w->alayers[l];
+      float* cache = acache + l * alayer;
+      float* slot = cache + s * aslab;
+      GDR_TRY(LIN2(xa, d, al.in_w, d, slot, 3 * d, rows, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0));
+      AttnArgs at{};
+      at.q = slot, at.k = cache + d, at.v = cache + 2 * d, at.out = ctx2;
+      at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
+      at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
+      at.B = rows, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
+      at.scale = 1.0f / sqrtf((float)ahd);
+      at.rel_bias = nullptr, at.bidirectional = 0, at.num_buckets = 0, at.lut = lut_uni;
+      at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
+      at.kv_rows = bb.kv_rows, at.kv_group = 1;
+      GDR_TRY(launch_attention(at, as));
+      GDR_TRY(LIN2(ctx2, d, al.out_w, d, tmp, d, rows, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d));
+      GDR_TRY(launch_layernorm(tmp, al.ln1_w, al.ln1_b, xa, rows, d, w->adaptor_eps, nullptr, as));
+      GDR_TRY(launch_layernorm(xa, al.ln2_w, al.ln2_b, tmp, rows, d, w->adaptor_eps, al.cross_const, as));
+      GDR_TRY(LIN2(tmp, d, al.lin1_w, d, ff2, aff, rows, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
+      GDR_TRY(LIN2(ff2, aff, al.lin2_w, aff, xa, d, rows, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d));
+      GDR_TRY(launch_layernorm(xa, al.ln3_w, al.ln3_b, xa, rows, d, w->adaptor_eps, nullptr, as));
+    }
+    if (ss.ok) {
+      if (hipEventRecord(ss.join, ss.s) != hipSuccess) {
+        set_error("generate: adaptor stream join failed");
+        return GDR_EHIP;
+      }
+    }
     // ---------------- T5 decoder stack (modeling_t5.py:498-584, 685-821)
     for (int l = 0; l < dm.num_layers; ++l) {
       const GdrT5DecLayer& ly = w->layers[l];
@@ -527,13 +587,15 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
       GDR_TRY(LIN(nx, d, ly.wq_c, d, qc, inner, rows, inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
       AttnArgs ca{};
       const float* ckv = crosskv + l * ckv_layer;
+      // the R beam rows of a query are consecutive and share its K/V: one workgroup per (query, head) stages K/V
+      // once and serves all R rows (they all sit at decoder position s)
       ca.q = qc, ca.k = ckv, ca.v = ckv + inner, ca.out = ctx;
       ca.ldq = inner, ca.ldk = ca.ldv = 2 * inner, ca.ldo = inner;
-      ca.q_bstride = 1, ca.k_bstride = L, ca.o_bstride = 1;
-      ca.B = rows, ca.H = H, ca.dk = dk, ca.Lq = 1, ca.Lk = L, ca.q_pos0 = s, ca.scale = 1.0f;
+      ca.q_bstride = num_beams, ca.k_bstride = L, ca.o_bstride = num_beams;
+      ca.B = B, ca.H = H, ca.dk = dk, ca.Lq = num_beams, ca.Lk = L, ca.q_pos0 = s, ca.scale = 1.0f, ca.q_same_pos = 1;
       ca.rel_bias = w->cross_rel_bias, ca.bidirectional = 1, ca.num_buckets = dm.rel_buckets, ca.lut = lut_bi;
       ca.key_mask = enc_mask, ca.mask_bstride = L, ca.causal = 0, ca.causal_neg_inf = 0;
-      ca.kv_rows = nullptr, ca.kv_group = num_beams;
+      ca.kv_rows = nullptr, ca.kv_group = 1;
       GDR_TRY(launch_attention(ca, stream));
       GDR_TRY(LIN(ctx, inner, ly.wo_c, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d));
       GDR_TRY(launch_rmsnorm(xd, ly.ln_ff, nx, rows, d, dm.eps, nullptr, 1, stream));
@@ -541,28 +603,9 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
       GDR_TRY(LIN(ff, dm.d_ff, ly.wo_ff, dm.d_ff, xd, d, rows, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, xd, d));
     }
     GDR_TRY(launch_rmsnorm(xd, w->final_ln, hl, rows, d, dm.eps, nullptr, 1, stream));
-    // ---------------- adaptor: post-LN nn.TransformerDecoder over decode_embeddings(ids) (modeling_t5.py:1615-1633)
-    for (int l = 0; l < w->adaptor_layers; ++l) {
-      const GdrAdaptorLayer& al = w->alayers[l];
-      float* cache = acache + l * alayer;
-      float* slot = cache + s * aslab;
-      GDR_TRY(LIN(xa, d, al.in_w, d, slot, 3 * d, rows, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0));
-      AttnArgs at{};
-      at.q = slot, at.k = cache + d, at.v = cache + 2 * d, at.out = ctx;
-      at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
-      at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
-      at.B = rows, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
-      at.scale = 1.0f / sqrtf((float)ahd);
-      at.rel_bias = nullptr, at.bidirectional = 0, at.num_buckets = 0, at.lut = lut_uni;
-      at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
-      at.kv_rows = bb.kv_rows, at.kv_group = 1;
-      GDR_TRY(launch_attention(at, stream));
-      GDR_TRY(LIN(ctx, d, al.out_w, d, tmp, d, rows, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d));
-      GDR_TRY(launch_layernorm(tmp, al.ln1_w, al.ln1_b, xa, rows, d, w->adaptor_eps, nullptr, stream));
-      GDR_TRY(launch_layernorm(xa, al.ln2_w, al.ln2_b, tmp, rows, d, w->adaptor_eps, al.cross_const, stream));
-      GDR_TRY(LIN(tmp, d, al.lin1_w, d, ff, aff, rows, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
-      GDR_TRY(LIN(ff, aff, al.lin2_w, aff, xa, d, rows, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d));
-      GDR_TRY(launch_layernorm(xa, al.ln3_w, al.ln3_b, xa, rows, d, w->adaptor_eps, nullptr, stream));
+    if (ss.ok && hipStreamWaitEvent(stream, ss.join, 0) != hipSuccess) {
+      set_error("generate: adaptor stream join failed");
+      return GDR_EHIP;
     }
     // ---------------- head: last position, unmasked columns only (modeling_t5.py:1634-1646)
     const float* hw = w->head_w + (size_t)s * V1 * d * d;
@@ -580,6 +623,7 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   return beam_end(bb, bd, max_length, cur, out_ids, out_len, out_scores, stream);
 #undef GDR_TRY
 #undef LIN
+#undef LIN2
 }
 
 extern "C" size_t gdr_beam_search_table_workspace_bytes(int B, int num_beams, int max_length, int out_vocab) {

@@ -13,8 +13,10 @@
 
 namespace gdr {
 
+constexpr size_t ENC_SPLITK_BYTES = (size_t)48 << 20;
+
 struct EncWs {
-  size_t off_h, off_nx, off_qkv, off_ctx, off_ff, total;
+  size_t off_h, off_nx, off_qkv, off_ctx, off_ff, off_splitk, total;
 };
 
 static EncWs enc_ws(const GdrT5Dims& dm, int64_t M) {
@@ -26,6 +28,7 @@ static EncWs enc_ws(const GdrT5Dims& dm, int64_t M) {
   w.off_qkv = o, o += align_up((size_t)M * 3 * inner * 4, 256);
   w.off_ctx = o, o += align_up((size_t)M * inner * 4, 256);
   w.off_ff = o, o += align_up((size_t)M * dm.d_ff * 4, 256);
+  w.off_splitk = o, o += ENC_SPLITK_BYTES;  // small batches: split-K partial slabs (gemm_f32.hip)
   w.total = o;
   return w;
 }
@@ -60,6 +63,7 @@ extern "C" int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_
   float* qkv = reinterpret_cast<float*>(base + ws.off_qkv);
   float* ctx = reinterpret_cast<float*>(base + ws.off_ctx);
   float* ff = reinterpret_cast<float*>(base + ws.off_ff);
+  float* skw = reinterpret_cast<float*>(base + ws.off_splitk);
   const int d = dm.d_model, H = dm.num_heads, dk = dm.d_kv, inner = H * dk;
 
   int rc = launch_embed(w->embed, ids, M, d, dm.vocab_size, h, stream);  // modeling_t5.py:725
@@ -80,17 +84,15 @@ extern "C" int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_
     const GdrT5EncLayer& ly = w->layers[i];
     GDR_CHECK_ARG(ly.ln_attn && ly.wqkv && ly.wo && ly.ln_ff && ly.wi && ly.wo_ff, "t5_encoder: layer %d null weight", i);
     if ((rc = launch_rmsnorm(h, ly.ln_attn, nx, M, d, dm.eps, nullptr, 1, stream))) return rc;
-    if ((rc = launch_linear_f32(nx, d, ly.wqkv, d, qkv, 3 * inner, M, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0,
-                                stream)))
+    if ((rc = launch_linear_f32_ws(nx, d, ly.wqkv, d, qkv, 3 * inner, M, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0, skw, ENC_SPLITK_BYTES, stream)))
       return rc;
     if ((rc = launch_attention(at, stream))) return rc;
-    if ((rc = launch_linear_f32(ctx, inner, ly.wo, inner, h, d, M, d, inner, GDR_EPI_RESIDUAL, nullptr, h, d, stream)))
+    if ((rc = launch_linear_f32_ws(ctx, inner, ly.wo, inner, h, d, M, d, inner, GDR_EPI_RESIDUAL, nullptr, h, d, skw, ENC_SPLITK_BYTES, stream)))
       return rc;
     if ((rc = launch_rmsnorm(h, ly.ln_ff, nx, M, d, dm.eps, nullptr, 1, stream))) return rc;
-    if ((rc = launch_linear_f32(nx, d, ly.wi, d, ff, dm.d_ff, M, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0, stream)))
+    if ((rc = launch_linear_f32_ws(nx, d, ly.wi, d, ff, dm.d_ff, M, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0, skw, ENC_SPLITK_BYTES, stream)))
       return rc;
-    if ((rc = launch_linear_f32(ff, dm.d_ff, ly.wo_ff, dm.d_ff, h, d, M, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, h, d,
-                                stream)))
+    if ((rc = launch_linear_f32_ws(ff, dm.d_ff, ly.wo_ff, dm.d_ff, h, d, M, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, h, d, skw, ENC_SPLITK_BYTES, stream)))
       return rc;
   }
   // final_layer_norm (:803) + CLS pool h[:,0] (main_models.py:102-109)

@@ -16,6 +16,8 @@
 //     so the sum over k is unchanged.
 //   * 1-D grid with the bijective XCD remap: the blocks that share a row panel (A tile) run on one XCD
 //     back to back, so the panel is fetched from HBM once and re-read from that XCD's L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gdr {
@@ -397,7 +399,11 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
   const int64_t tiles = tiles_m * g.tiles_n;
   const int nk = K / BK;
   if (splitk_ws && K % BK == 0 && N % 4 == 0 && tiles < 192 && nk >= 4) {
-    int S = (int)((640 + tiles - 1) / tiles);
+    static const int target = [] {
+      const char* e = getenv("GDR_SPLITK_TARGET");  // tuning knob: desired number of blocks per split launch
+      return e ? atoi(e) : 384;
+    }();
+    int S = (int)((target + tiles - 1) / tiles);
     if (S > nk / 2) S = nk / 2;
     const size_t slab = (size_t)M * N * sizeof(float);
     if ((size_t)S * slab > splitk_ws_bytes) S = (int)(splitk_ws_bytes / slab);

@@ -32,6 +32,7 @@ struct AttnArgs {
   // decode-time K/V sources (defaults: kv_rows = null, kv_group = 1)
   const int32_t* kv_rows;      // int32 [B, Lk]: absolute row of key j of batch entry b in k/v (beam-ancestor cache)
   int kv_group;                // batch entries sharing one K/V block: K/V batch index = b / kv_group (beams of a query)
+  int q_same_pos;              // all Lq query rows of a batch entry sit at position q_pos0 (beam rows of one decode step)
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 

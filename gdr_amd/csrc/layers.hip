@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     float sc[2];
     float mx = -INFINITY;
     if (active) {
-      const int i_abs = a.q_pos0 + i;
+      const int i_abs = a.q_pos0 + (a.q_same_pos ? 0 : i);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int j = lane + 64 * t;
@@ -424,6 +424,87 @@ static int launch_attention_mfma(const AttnArgs& a, hipStream_t stream) {
   return GDR_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------ attention, Lq == 1
+// Decode-time attention (one query row per batch entry): one WAVE per (row, head), four per workgroup, nothing
+// staged in LDS.  Lane j scores key j (and j+64): its K row is read with 16-byte loads (L2-resident cache / cross
+// K/V), q comes from a wave-uniform (broadcast) load.  Softmax by wave shuffles, PV with lane = d and the
+// probabilities broadcast by shuffle.  Same semantics as attention_kernel (bias, masks, kv_rows, kv_group).
+__global__ __launch_bounds__(256) void attention_decode_kernel(const AttnArgs a) {
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= a.B * a.H) return;
+  const int b = item / a.H, h = item % a.H, lane = threadIdx.x & 63;
+  const int dk = a.dk, c4 = dk >> 2, Lk = a.Lk, kb = b / a.kv_group;
+  const float* qr = a.q + (int64_t)b * a.q_bstride * a.ldq + h * dk;
+  const int i_abs = a.q_pos0;
+  const int half = a.num_buckets >> 1;
+  const float masked = a.causal_neg_inf ? -INFINITY : -1e9f;
+  float sc[2], mx = -INFINITY;
+  int64_t vrow[2] = {0, 0};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int j = lane + 64 * t;
+    float s = -INFINITY;
+    if (j < Lk) {
+      const int64_t rk = a.kv_rows ? (int64_t)a.kv_rows[(int64_t)b * Lk + j] : (int64_t)kb * a.k_bstride + j;
+      vrow[t] = rk;
+      const float4* kr = reinterpret_cast<const float4*>(a.k + rk * a.ldk + h * dk);
+      const float4* q4 = reinterpret_cast<const float4*>(qr);
+      float acc = 0.f;
+      for (int c = 0; c < c4; ++c) {
+        const float4 qq = q4[c], kk = kr[c];
+        acc = fmaf(qq.x * a.scale, kk.x, acc);
+        acc = fmaf(qq.y * a.scale, kk.y, acc);
+        acc = fmaf(qq.z * a.scale, kk.z, acc);
+        acc = fmaf(qq.w * a.scale, kk.w, acc);
+      }
+      float add = 0.f;
+      if (a.rel_bias) {
+        int n = i_abs - j, bucket = 0;
+        if (a.bidirectional) {
+          if (n < 0) {
+            bucket = half;
+            n = -n;
+          }
+        } else if (n < 0) {
+          n = 0;
+        }
+        bucket += a.lut.v[n < 127 ? n : 127];
+        add = a.rel_bias[bucket * a.H + h];
+      }
+      bool allowed = true;
+      if (a.causal) allowed = j <= i_abs;
+      if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)kb * a.mask_bstride + j] != 0);
+      if (!allowed) add += masked;
+      s = acc + add;
+    }
+    sc[t] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float p[2], sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    p[t] = (lane + 64 * t < Lk) ? expf(sc[t] - mx) : 0.f;
+    sum += p[t];
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  float* orow = a.out + (int64_t)b * a.o_bstride * a.ldo + h * dk;
+  for (int d0 = 0; d0 < dk; d0 += 64) {  // wave-uniform trip count: the shuffles below need every lane
+    const int d = d0 + lane;
+    const bool live = d < dk;
+    float o = 0.f;
+    for (int j = 0; j < Lk; ++j) {
+      const float pj = __shfl(j < 64 ? p[0] : p[1], j & 63);
+      const int64_t rk = __shfl(j < 64 ? vrow[0] : vrow[1], j & 63);
+      const float vv = live ? a.v[rk * a.ldv + h * dk + d] : 0.f;
+      o = fmaf(pj * inv, vv, o);
+    }
+    if (live) orow[d] = o;
+  }
+}
+
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
   GDR_CHECK_ARG(a.dk % 4 == 0 && a.dk >= 4 && a.dk <= 256, "attention: dk=%d unsupported", a.dk);
   GDR_CHECK_ARG(a.Lk >= 1 && a.Lk <= 128, "attention: Lk=%d must be in [1,128]", a.Lk);
@@ -432,7 +513,12 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   GDR_CHECK_ARG(a.kv_group >= 1, "attention: kv_group must be >= 1");
   if (a.B == 0 || a.Lq == 0) return GDR_OK;
   ProfScope prof(PROF_ATTENTION, 4.0 * a.B * a.H * (double)a.Lq * a.Lk * a.dk, stream);
-  if (a.Lq == a.Lk && !a.kv_rows && a.kv_group == 1 && a.dk == 64 && a.ldo % 4 == 0) {
+  if (a.Lq == 1) {
+    hipLaunchKernelGGL(attention_decode_kernel, dim3((unsigned)((a.B * a.H + 3) / 4)), dim3(256), 0, stream, a);
+    GDR_CHECK_LAUNCH("attention_decode_kernel");
+    return GDR_OK;
+  }
+  if (a.Lq == a.Lk && !a.kv_rows && a.kv_group == 1 && !a.q_same_pos && a.dk == 64 && a.ldo % 4 == 0) {
     switch ((a.Lk + 31) / 32) {
       case 1: return launch_attention_mfma<1>(a, stream);
       case 2: return launch_attention_mfma<2>(a, stream);
