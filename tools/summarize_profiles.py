@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of a bench run (gpurun_out/...) into the committed summaries under profiles/.
+usage: summarize_profiles.py TAG STATS_CSV FETCH_COUNTER_CSV WRITE_COUNTER_CSV BENCH_JSON"""
+import collections
+import csv
+import json
+import shutil
+import sys
+
+tag, stats, fetch, write, bench = sys.argv[1:6]
+shutil.copy(stats, f"profiles/{tag}_bench_kernel_stats.csv")
+shutil.copy(bench, f"profiles/{tag}_bench_n1.json")
+
+
+def agg(path):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        d[(r["Kernel_Name"], r["Grid_Size"])].append(float(r["Counter_Value"]))
+    return d
+
+
+f, w = agg(fetch), agg(write)
+rows, tot = [], collections.defaultdict(lambda: [0, 0.0, 0.0])
+for k in f:
+    fv = sum(f[k]) / len(f[k])
+    wv = sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
+    fb, wb = fv * 1024 * 2, wv * 1024
+    rows.append((k[0], k[1], len(f[k]), fv, fb, wb))
+    t = tot[k[0]]
+    t[0] += len(f[k]); t[1] += fb * len(f[k]); t[2] += wb * len(f[k])
+with open(f"profiles/{tag}_bench_pmc_hbm.md", "w") as o:
+    o.write(f"# {tag} — HBM-side traffic per launch (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes)\n\n"
+            "Commands (each counter in its own run, kernel-trace only, as gpurun requires):\n\n"
+            "    cd /tmp && export TMPDIR=/tmp\n"
+            "    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-recall\n"
+            "    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-recall\n"
+            "    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-recall\n\n"
+            "Correction per MI355X_MICROARCH.md §HBM: FETCH_SIZE is in KiB and reads exactly half of a wide coalesced stream on gfx950 "
+            "-> bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 is exact for 16-B/lane stores.  FETCH counts L2 misses "
+            "(Infinity-Cache hits included), so it bounds HBM reads from above.\n\n"
+            "| kernel | grid (threads) | launches | FETCH_SIZE avg (KiB) | read MB/launch (x2) | write MB/launch |\n|---|---|---|---|---|---|\n")
+    for r in rows:
+        o.write(f"| `{r[0][:70]}` | {r[1]} | {r[2]} | {r[3]:.0f} | {r[4] / 1e6:.1f} | {r[5] / 1e6:.1f} |\n")
+    o.write("\nPer kernel name (all shapes averaged, as `roofline.traffic` in bench.py reports it):\n\n"
+            "| kernel | launches | bytes/launch (read+write) |\n|---|---|---|\n")
+    out = {}
+    for k, t in tot.items():
+        o.write(f"| `{k[:70]}` | {t[0]} | {(t[1] + t[2]) / t[0] / 1e6:.1f} MB |\n")
+        out[k] = (t[1] + t[2]) / t[0]
+    o.write("\nAlgorithmic bytes of the linear GEMM, averaged over its four call shapes per layer (A + W + C (+ residual)): "
+            "290 MB/launch.  The excess is the W panel (7-9.4 MB) cycling through one XCD's 4 MiB L2 under the n-fastest tile "
+            "order and being re-read through the Infinity Cache; the kernel is MFMA-bound, so this costs energy rather than time "
+            "(an m-fastest supertile order was measured in tools/gemm_lab.hip: +3-5 % on the old loop, 0 % on the current one).\n")
+key = [k for k in out if "gemm_nt_f32_kernel<0>" in k][0]
+json.dump({"gemm_nt_f32_kernel<0>_bytes_per_launch": out[key], "source": f"profiles/{tag}_bench_pmc_hbm.md"},
+          open("profiles/traffic.json", "w"), indent=1)
+print(open(f"profiles/{tag}_bench_kernel_stats.csv").read()[:1500])
