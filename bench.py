@@ -138,7 +138,7 @@ def main():
     for _ in range(a.warmup):
         step()
     lib = _ffi.lib()
-    launches_per_step = 5 * cfg.num_layers + 8          # 4 linears + 1 attention per layer, 2 similarity GEMMs
+    launches_per_step = 13 * cfg.num_layers + 8         # per layer: 4 linears x (main + tail + reduce) + attention
     _ffi.check(lib.gdr_prof_enable(launches_per_step * a.steps + 16), "gdr_prof_enable")
     fence()
     t0 = time.perf_counter()
@@ -165,7 +165,7 @@ def main():
             return {"launches": int(n_l[c]), "avg_ms": avg_ms, "gflop_per_launch": avg_work / 1e9,
                     "tflops": avg_work / (avg_ms * 1e-3) / 1e12, "share_of_step": ms_l[c] / (dt * 1e3)}
 
-        lin, smp, flt, att = cls(0), cls(1), cls(2), cls(3)
+        lin, smp, flt, att, red = cls(0), cls(1), cls(2), cls(3), cls(7)
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -188,7 +188,7 @@ def main():
                          "frac": lin["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "launches": lin["launches"], "avg_launch_ms": lin["avg_ms"],
                          "algorithmic_gflop_per_launch": lin["gflop_per_launch"], "share_of_step": lin["share_of_step"]},
-            "kernels": {"sim_sample_gemm": smp, "sim_filter_gemm": flt, "attention": att},
+            "kernels": {"sim_sample_gemm": smp, "sim_filter_gemm": flt, "attention": att, "splitk_reduce": red},
         }
         if flt:
             # similarity as a whole (both GEMM passes): flops and the corpus bytes it must stream once

@@ -33,7 +33,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // ---- opt-in launch profiler (gdr_prof_* in include/gdr_hip.h): hipEvent pairs around the launches of one
 // kernel class, recorded on the stream the kernel runs on.  Off by default: no events, no state touched.
 enum ProfClass { PROF_LINEAR = 0, PROF_SIM_SAMPLE = 1, PROF_SIM_FILTER = 2, PROF_ATTENTION = 3, PROF_NORM = 4,
-                 PROF_SELECT = 5, PROF_RERANK = 6, PROF_NCLASS = 8 };
+                 PROF_SELECT = 5, PROF_RERANK = 6, PROF_REDUCE = 7, PROF_NCLASS = 8 };
 struct ProfScope {
   int slot;
   hipStream_t stream;

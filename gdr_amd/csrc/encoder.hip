@@ -13,7 +13,7 @@
 
 namespace gdr {
 
-constexpr size_t ENC_SPLITK_BYTES = (size_t)48 << 20;
+constexpr size_t ENC_SPLITK_BYTES = (size_t)112 << 20;  // <= 384 tail tiles x 4 splits x 64 KiB + slack
 
 struct EncWs {
   size_t off_h, off_nx, off_qkv, off_ctx, off_ff, off_splitk, total;

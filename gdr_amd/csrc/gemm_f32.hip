@@ -39,7 +39,9 @@ struct GemmArgs {
   int N, K;
   int tiles_n;
   int has_bias, has_residual, act;  // linear epilogue, runtime so that every linear shares one kernel
-  int ksplit, kchunk;               // split-K (small-M decode linears): block handles K range [s*kchunk, (s+1)*kchunk)
+  int ksplit, kchunk;               // split-K: block handles K range [s*kchunk, (s+1)*kchunk) of its tile and stores a raw
+                                    // 128x128 partial at C[(local_tile*ksplit + s)][128][128] (C = scratch)
+  int tile_base;                    // first linear tile index of this launch (tail launches start past the full rounds)
   SimEpilogue sim;
 };
 
@@ -65,6 +67,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
     split = bid % (unsigned)g.ksplit;
     bid /= (unsigned)g.ksplit;
   }
+  const unsigned local_tile = bid;
+  if (EPI == EPI_LINEAR) bid += (unsigned)g.tile_base;
   int64_t mt = bid / (unsigned)g.tiles_n;
   const int nt = bid % (unsigned)g.tiles_n;
   int64_t slot_base = 0;
@@ -293,6 +297,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
     return;
   }
 
+  if (EPI == EPI_LINEAR && g.ksplit > 1) {  // raw partial tile, unconditional (the scratch holds whole tiles)
+    float* slab = g.C + ((int64_t)local_tile * g.ksplit + split) * (BM * BN);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          slab[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + wn * 64 + ni * 32 + l31] = acc[mi][ni][r];
+    return;
+  }
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int n = n0 + wn * 64 + ni * 32 + l31;
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
         if (g.has_residual) v += g.residual[m * g.ldr + n];
         if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
         if (g.act == ACT_GELU) v = gelu_erf(v);
-        g.C[((int64_t)split * g.M + m) * g.ldc + n] = v;  // split > 0 only for raw partial slabs [S][M][N]
+        g.C[m * g.ldc + n] = v;
       }
     }
   }
@@ -329,34 +344,35 @@ static int launch(const GemmArgs& g, int64_t tiles_m, hipStream_t stream) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// C = epilogue(sum_s partial[s]) in fixed order s = 0..S-1 (deterministic); N % 4 == 0.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, int64_t M, int N,
-                                                            float* __restrict__ C, int64_t ldc,
-                                                            const float* __restrict__ bias,
+// C tile = epilogue(sum_s partial[tile][s]) in fixed order s = 0..S-1 (deterministic).  16 blocks per 128x128 tile.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, int tile_base,
+                                                            int tiles_n, int64_t M, int N, float* __restrict__ C,
+                                                            int64_t ldc, const float* __restrict__ bias,
                                                             const float* __restrict__ residual, int64_t ldr, int act) {
-  const int n4 = N >> 2;
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= M * n4) return;
-  const int64_t m = e / n4;
-  const int c = (int)(e - m * n4) * 4;
-  const int64_t slab = M * (int64_t)N;
-  float4 v = *reinterpret_cast<const float4*>(partial + m * N + c);
+  const int local_tile = blockIdx.x >> 4;
+  const int e = ((blockIdx.x & 15) << 8) + threadIdx.x;  // float4 index inside the tile: 128 rows x 32 float4
+  const int r = e >> 5, c = (e & 31) << 2;
+  const int tile = local_tile + tile_base;
+  const int64_t m = (int64_t)(tile / tiles_n) * BM + r;
+  const int n = (tile % tiles_n) * BN + c;
+  if (m >= M || n >= N) return;
+  const float* p = partial + (int64_t)local_tile * S * (BM * BN) + r * BN + c;
+  float4 v = *reinterpret_cast<const float4*>(p);
   for (int s = 1; s < S; ++s) {
-    const float4 t = *reinterpret_cast<const float4*>(partial + s * slab + m * N + c);
+    const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)s * (BM * BN));
     v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
   }
-  if (bias) {
-    const float4 b = *reinterpret_cast<const float4*>(bias + c);
-    v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+  float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (n + q >= N) break;
+    float x = o[q];
+    if (bias) x += bias[n + q];
+    if (residual) x += residual[m * ldr + n + q];
+    if (act == ACT_RELU) x = fmaxf(x, 0.f);
+    if (act == ACT_GELU) x = gelu_erf(x);
+    C[m * ldc + n + q] = x;
   }
-  if (residual) {
-    const float* r = residual + m * ldr + c;
-    v.x += r[0], v.y += r[1], v.z += r[2], v.w += r[3];
-  }
-  if (act == ACT_RELU) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
-  if (act == ACT_GELU) v.x = gelu_erf(v.x), v.y = gelu_erf(v.y), v.z = gelu_erf(v.z), v.w = gelu_erf(v.w);
-  float* o = C + m * ldc + c;
-  o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
 }
 
 int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
@@ -395,33 +411,69 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
     set_error("linear: unknown epilogue %d", epilogue);
     return GDR_EINVAL;
   }
-  ProfScope prof(PROF_LINEAR, 2.0 * (double)M * (double)N * (double)K, stream);
+  const double flops = 2.0 * (double)M * (double)N * (double)K;  // profiler: attributed per kernel launch, by tile share
   const int64_t tiles = tiles_m * g.tiles_n;
   const int nk = K / BK;
-  if (splitk_ws && K % BK == 0 && N % 4 == 0 && tiles < 192 && nk >= 4) {
-    static const int target = [] {
-      const char* e = getenv("GDR_SPLITK_TARGET");  // tuning knob: desired number of blocks per split launch
-      return e ? atoi(e) : 384;
-    }();
-    int S = (int)((target + tiles - 1) / tiles);
-    if (S > nk / 2) S = nk / 2;
-    const size_t slab = (size_t)M * N * sizeof(float);
-    if ((size_t)S * slab > splitk_ws_bytes) S = (int)(splitk_ws_bytes / slab);
-    if (S >= 2) {
-      const int chunk_steps = (nk + S - 1) / S;
-      S = (nk + chunk_steps - 1) / chunk_steps;
-      GemmArgs p = g;
-      p.C = splitk_ws, p.ldc = N, p.has_bias = 0, p.has_residual = 0, p.act = ACT_NONE;
-      p.ksplit = S, p.kchunk = chunk_steps * BK;
-      int rc = launch<EPI_LINEAR>(p, tiles_m * S, stream);
-      if (rc) return rc;
-      const int64_t n_el = M * (N / 4);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, stream, splitk_ws, S, M,
-                         N, C, ldc, needs_bias ? bias : nullptr, needs_res ? residual : nullptr, ldr, g.act);
-      GDR_CHECK_LAUNCH("splitk_reduce_kernel");
-      return GDR_OK;
+  constexpr int64_t SLOTS = 512;                      // 256 CUs x 2 resident workgroups
+  const size_t tile_bytes = (size_t)BM * BN * sizeof(float);
+  auto split_launch = [&](int64_t first_tile, int64_t n_tiles, int S) -> int {
+    const int chunk_steps = (nk + S - 1) / S;
+    S = (nk + chunk_steps - 1) / chunk_steps;
+    GemmArgs p = g;
+    p.C = splitk_ws, p.has_bias = 0, p.has_residual = 0, p.act = ACT_NONE;
+    p.ksplit = S, p.kchunk = chunk_steps * BK, p.tile_base = (int)first_tile;
+    const int64_t blocks = n_tiles * S;
+    {
+      ProfScope prof(PROF_LINEAR, flops * (double)n_tiles / (double)tiles, stream);
+      hipLaunchKernelGGL(gemm_nt_f32_kernel<EPI_LINEAR>, dim3((unsigned)blocks), dim3(GEMM_THREADS), 0, stream, p);
+    }
+    GDR_CHECK_LAUNCH("gemm_nt_f32_kernel(split)");
+    ProfScope prof_r(PROF_REDUCE, 0.0, stream);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(n_tiles * 16)), dim3(256), 0, stream, splitk_ws, S,
+                       (int)first_tile, g.tiles_n, M, N, C, ldc, needs_bias ? bias : nullptr,
+                       needs_res ? residual : nullptr, ldr, g.act);
+    GDR_CHECK_LAUNCH("splitk_reduce_kernel");
+    return GDR_OK;
+  };
+  if (splitk_ws && K % BK == 0 && tiles < 0x7fffffff / 64) {
+    if (tiles < 192 && nk >= 4) {
+      // (a) the grid cannot fill the chip (decode: M = batch*beams rows): split every tile along K
+      static const int target = [] {
+        const char* e = getenv("GDR_SPLITK_TARGET");  // tuning knob: desired number of blocks per split launch
+        return e ? atoi(e) : 384;
+      }();
+      int S = (int)((target + tiles - 1) / tiles);
+      if (S > nk / 2) S = nk / 2;
+      if ((size_t)S * tiles * tile_bytes > splitk_ws_bytes) S = (int)(splitk_ws_bytes / (tiles * tile_bytes));
+      if (S >= 2) return split_launch(0, tiles, S);
+    } else if (tiles > SLOTS && nk >= 8) {
+      // (b) wave quantisation experiment, OFF by default (GDR_TAIL_SPLIT=1 enables): run the full 512-tile rounds as
+      // usual and the last partial round split along K.  Measured on the bench shapes: the GEMM kernels get 0.4 %
+      // faster, the extra reduce launches cost 1.2 % — a net loss, because a CU left with one resident workgroup in
+      // the last round already runs it at twice the speed (it no longer shares its SIMDs).
+      static const bool tail_on = [] {
+        const char* e = getenv("GDR_TAIL_SPLIT");
+        return e ? atoi(e) != 0 : false;
+      }();
+      const int64_t rem = tiles % SLOTS;
+      if (tail_on && rem > 0 && rem <= (SLOTS * 3) / 4) {
+        int S = (int)((2 * SLOTS) / rem);
+        if (S > 4) S = 4;
+        if (S > nk / 4) S = nk / 4;
+        if ((size_t)S * rem * tile_bytes > splitk_ws_bytes) S = (int)(splitk_ws_bytes / (rem * tile_bytes));
+        if (S >= 2) {
+          {
+            ProfScope prof(PROF_LINEAR, flops * (double)(tiles - rem) / (double)tiles, stream);
+            hipLaunchKernelGGL(gemm_nt_f32_kernel<EPI_LINEAR>, dim3((unsigned)(tiles - rem)), dim3(GEMM_THREADS), 0, stream,
+                               g);
+          }
+          GDR_CHECK_LAUNCH("gemm_nt_f32_kernel");
+          return split_launch(tiles - rem, rem, S);
+        }
+      }
     }
   }
+  ProfScope prof(PROF_LINEAR, flops, stream);
   return launch<EPI_LINEAR>(g, tiles_m, stream);
 }
 
