@@ -104,7 +104,8 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     torch.set_grad_enabled(False)
@@ -131,7 +132,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -148,7 +149,7 @@ def main():
     dt = time.perf_counter() - t0
     n_l, ms_l, w_l = (C.c_int64 * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
     _ffi.check(lib.gdr_prof_collect(n_l, ms_l, w_l), "gdr_prof_collect")
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -214,7 +215,7 @@ def main():
             result["cpu_baseline"] = None
         print(json.dumps(result))
         sys.stdout.flush()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -33,12 +33,13 @@ class ShardedIndex:
             local_topk = local_topk or (lambda Q, D, k, off: ops.sim_topk(Q, D, k, idx_offset=off, workspace=ws))
             merge = merge or ops.topk_merge
         self.local_topk, self.merge = local_topk, merge
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.distributed = dist.is_initialized()      # a 1-rank group still runs the collectives (exercises RCCL)
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.rank = dist.get_rank(group) if self.distributed else 0
 
     def gather_queries(self, q_local):
         """[B_local,d] per rank -> [world*B_local,d], rank-major (every rank contributes the same count)."""
-        if self.world == 1:
+        if not self.distributed:
             return q_local
         out = torch.empty((self.world * q_local.shape[0], q_local.shape[1]), dtype=q_local.dtype,
                           device=q_local.device)
@@ -48,7 +49,7 @@ class ShardedIndex:
     def search(self, q_all, k):
         """q_all [B,d] identical on every rank -> (values [B,k], global doc ids int32 [B,k]), identical on every rank."""
         v, i = self.local_topk(q_all, self.D, k, self.lo)
-        if self.world == 1:
+        if not self.distributed:
             return v, i
         B = q_all.shape[0]
         gv = torch.empty((self.world * B, k), dtype=v.dtype, device=v.device)     # rank-major concatenation
