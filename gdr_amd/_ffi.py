@@ -45,6 +45,10 @@ class GdrBertWeights(C.Structure):
                 ("emb_ln_b", C.c_void_p), ("layers", C.POINTER(GdrBertLayer))]
 
 
+class GdrTrie(C.Structure):
+    _fields_ = [("child", C.c_void_p), ("eos_ok", C.c_void_p), ("n_nodes", C.c_int32)]
+
+
 class GdrT5DecLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln_self", "wqkv", "wo", "ln_cross", "wq_c", "wkv_c", "wo_c", "ln_ff", "wi",
                                           "wo_ff")]
@@ -82,10 +86,11 @@ SIGNATURES = {
     "gdr_bert_encoder_workspace_bytes": (_sz, [C.POINTER(GdrBertWeights), _i, _i]),
     "gdr_bert_encoder_forward": (_i, [C.POINTER(GdrBertWeights), _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "gdr_t5_generate_workspace_bytes": (_sz, [C.POINTER(GdrT5DecoderWeights), _i, _i, _i, _i]),
-    "gdr_t5_generate": (_i, [C.POINTER(GdrT5DecoderWeights), _vp, _vp, _i, _i, _i, _i, C.c_double, _i, _vp, _vp, _vp,
-                             _vp, _vp, _vp, _sz, _vp]),
+    "gdr_t5_generate": (_i, [C.POINTER(GdrT5DecoderWeights), _vp, _vp, _i, _i, _i, _i, C.c_double, _i, C.POINTER(GdrTrie),
+                             _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gdr_beam_search_table_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "gdr_beam_search_table": (_i, [_vp, _i, _i, _i, _i, C.c_double, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gdr_beam_search_table": (_i, [_vp, _i, _i, _i, _i, C.c_double, _i, C.POINTER(GdrTrie), _vp, _vp, _vp, _vp, _sz,
+                                   _vp]),
 }
 
 _lib = None

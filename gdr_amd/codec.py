@@ -96,6 +96,41 @@ class ClusterIndex:
         return torch.from_numpy(np.asarray(offs, dtype=np.int32)), torch.from_numpy(ids.astype(np.int32)), max_cand
 
 
+class Trie:
+    """Prefix tree over docid token sequences = the reference's TreeBuilder / Node (main_models.py:112-151), flattened:
+    child int32[n_nodes, V] (next node for digit c at the node's depth, -1 if absent), eos_ok int32[n_nodes]."""
+
+    def __init__(self, child, eos_ok, V):
+        self.child, self.eos_ok, self.V = child, eos_ok, V
+
+    @staticmethod
+    def from_sequences(seqs, V):
+        """seqs: token lists without START, with trailing EOS(1); a PAD(0) ends a sequence (TreeBuilder.add :135-151).
+        Tokens carry their positional offset: token = depth*V + c + 2 (encode_single_newid with --position 1)."""
+        child, eos = [[-1] * V], [0]
+        for seq in seqs:
+            cur = 0
+            for depth, tok in enumerate(int(t) for t in seq):
+                if tok == 0:
+                    break
+                if tok == 1:
+                    eos[cur] = 1
+                    break                     # nothing follows EOS in an encoded id
+                c = tok - (depth * V + 2)
+                if not 0 <= c < V:
+                    raise ValueError(f"token {tok} is not a digit of depth {depth} for V={V}")
+                if child[cur][c] < 0:
+                    child[cur][c] = len(child)
+                    child.append([-1] * V)
+                    eos.append(0)
+                cur = child[cur][c]
+        return Trie(np.asarray(child, dtype=np.int32), np.asarray(eos, dtype=np.int32), V)
+
+    @staticmethod
+    def from_docids(docids, V):
+        return Trie.from_sequences([encode_single_newid(s, kary=V) for s in docids], V)
+
+
 # ------------------------------------------------------------------------------------------ metrics / res1 TSV
 def write_res1(path, rows):
     """rows: (query, pred_csv, gt_csv, rank) — the reference's res1 TSV (main.py:244-247)."""

@@ -32,6 +32,7 @@ struct BeamBufs {
   int32_t* parent;      // [rows] row of the previous step that each row extends
   int32_t* anc[2];      // [rows][maxlen] row whose cache slot holds position p of this row's prefix
   int32_t* kv_rows;     // [rows][s+1] absolute cache row = p*rows + anc
+  int32_t* node[2];     // [rows] trie node reached by the row's prefix (-1: left the tree), double buffered
   float* logits;        // [rows][V+1] unmasked-column logits of the step
   float* cand_score;    // [B][2R]
   int32_t* cand_idx;    // [B][2R]  beam*Vd + token
@@ -46,6 +47,10 @@ struct BeamBufs {
 struct BeamDims {
   int B, R, V, Vd, maxlen, nret;
   double lp;
+  // optional trie constraint (generation_utils_previous.py:714-729): child[node*V + c] = next node or -1 for the digit
+  // c of the node's depth, eos_ok[node] = 1 if EOS is a child.  null = the shipped behaviour (positional mask only).
+  const int32_t* trie_child;
+  const int32_t* trie_eos;
 };
 
 static size_t carve(size_t& o, size_t bytes) {
@@ -70,6 +75,8 @@ static size_t beam_layout(const BeamDims& bd, char* base, BeamBufs* bb) {
   CARVE(anc[0], int32_t, rows * ml);
   CARVE(anc[1], int32_t, rows * ml);
   CARVE(kv_rows, int32_t, rows * ml);
+  CARVE(node[0], int32_t, rows);
+  CARVE(node[1], int32_t, rows);
   CARVE(logits, float, rows * V1);
   CARVE(cand_score, float, (size_t)bd.B * 2 * bd.R);
   CARVE(cand_idx, int32_t, (size_t)bd.B * 2 * bd.R);
@@ -94,6 +101,7 @@ __global__ void beam_init_kernel(BeamBufs bb, BeamDims bd) {
     bb.parent[r] = r;
     bb.anc[0][(size_t)r * bd.maxlen] = r;
     bb.kv_rows[r] = r;  // step 0: stride 1, position 0
+    bb.node[0][r] = 0;  // trie root
   }
   if (r < bd.B) {
     bb.hyp_cnt[r] = 0;
@@ -145,7 +153,7 @@ __global__ void table_logits_kernel(const float* __restrict__ table, const int64
 
 // Per query: log_softmax of every beam's row (masked columns contribute exp(-1e9 - max) = 0 exactly), add the
 // beam score, take the 2R best of the R*(V+1) unmasked candidates, sorted (generation_utils.py:698,766-775).
-__global__ __launch_bounds__(256) void beam_topk_kernel(BeamBufs bb, BeamDims bd, int pos, int npad,
+__global__ __launch_bounds__(256) void beam_topk_kernel(BeamBufs bb, BeamDims bd, int pos, int npad, int cur,
                                                         float* __restrict__ step_scores,
                                                         int32_t* __restrict__ step_tokens) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [npad]
@@ -173,7 +181,12 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(BeamBufs bb, BeamDims bd
     if (e < ncand) {
       const int j = e / V1, c = e - j * V1;
       const float logp = (bb.logits[((size_t)b * R + j) * V1 + c] - lse_max[j]) - lse_log[j];
-      const float s = logp + bb.beam_scores[(size_t)b * R + j];
+      float s = logp + bb.beam_scores[(size_t)b * R + j];
+      if (bd.trie_child) {  // scores += mask(-inf on tokens that are not children of the prefix' node)
+        const int nd = bb.node[cur][(size_t)b * R + j];
+        const bool ok = c < bd.V ? (nd >= 0 && bd.trie_child[(size_t)nd * bd.V + c] >= 0) : (nd < 0 || bd.trie_eos[nd] != 0);
+        if (!ok) s = -INFINITY;
+      }
       const int tok = c < bd.V ? pos * bd.V + 2 + c : EOS_ID;
       const uint32_t flat = (uint32_t)(j * bd.Vd + tok);
       key = ((unsigned long long)dfkey(s) << 32) | (unsigned long long)(0xFFFFFFFFu - flat);
@@ -256,6 +269,7 @@ __global__ void beam_update_kernel(BeamBufs bb, BeamDims bd, int cur_len, int cu
       bb.beam_scores[row] = 0.f;
       bb.cur_tok[row] = PAD_ID;
       bb.parent[row] = b * R;
+      bb.node[cur ^ 1][row] = -1;
       for (int t = 0; t < cur_len; ++t) seq_n[(size_t)row * ml + t] = seq_c[(size_t)(b * R) * ml + t];
       seq_n[(size_t)row * ml + cur_len] = PAD_ID;
     }
@@ -275,6 +289,10 @@ __global__ void beam_update_kernel(BeamBufs bb, BeamDims bd, int cur_len, int cu
       bb.beam_scores[row] = cs[rank];
       bb.cur_tok[row] = tok;
       bb.parent[row] = eff;
+      if (bd.trie_child) {
+        const int nd = bb.node[cur][eff], c = tok - ((cur_len - 1) * bd.V + 2);
+        bb.node[cur ^ 1][row] = (nd >= 0 && c >= 0 && c < bd.V) ? bd.trie_child[(size_t)nd * bd.V + c] : -1;
+      }
       for (int t = 0; t < cur_len; ++t) seq_n[(size_t)row * ml + t] = seq_c[(size_t)eff * ml + t];
       seq_n[(size_t)row * ml + cur_len] = tok;
       ++n;
@@ -370,7 +388,7 @@ static int beam_step(const BeamBufs& bb, const BeamDims& bd, int pos, int cur, f
   const int npad = next_pow2i(bd.R * (bd.V + 1));
   const size_t lds = (size_t)npad * 8 + (size_t)bd.R * 8;
   const size_t tr = (size_t)pos * bd.B * 2 * bd.R;
-  hipLaunchKernelGGL(beam_topk_kernel, dim3(bd.B), dim3(256), lds, stream, bb, bd, pos, npad,
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(bd.B), dim3(256), lds, stream, bb, bd, pos, npad, cur,
                      step_scores ? step_scores + tr : nullptr, step_tokens ? step_tokens + tr : nullptr);
   GDR_CHECK_LAUNCH("beam_topk_kernel");
   hipLaunchKernelGGL(beam_update_kernel, dim3((bd.B + 63) / 64), dim3(64), 0, stream, bb, bd, pos + 1, cur);
@@ -463,20 +481,22 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
 extern "C" size_t gdr_t5_generate_workspace_bytes(const GdrT5DecoderWeights* w, int B, int L, int num_beams,
                                                   int max_length) {
   if (!w || B <= 0 || L <= 0 || num_beams <= 0 || max_length < 2) return 0;
-  gdr::BeamDims bd{B, num_beams, w->out_vocab, w->dims.vocab_size, max_length, num_beams, 1.0};
+  gdr::BeamDims bd{B, num_beams, w->out_vocab, w->dims.vocab_size, max_length, num_beams, 1.0, nullptr, nullptr};
   return gdr::gen_ws(*w, bd, L).total;
 }
 
 extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B,
                                int L, int num_beams, int max_length, double length_penalty,
-                               int num_return_sequences, int64_t* out_ids, int32_t* out_len, double* out_scores,
-                               float* step_scores, int32_t* step_tokens, void* workspace, size_t workspace_bytes,
-                               void* stream_) {
+                               int num_return_sequences, const GdrTrie* trie, int64_t* out_ids, int32_t* out_len,
+                               double* out_scores, float* step_scores, int32_t* step_tokens, void* workspace,
+                               size_t workspace_bytes, void* stream_) {
   using namespace gdr;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GDR_CHECK_ARG(w && enc_hidden && enc_mask && out_ids && out_len && out_scores && workspace, "generate: null pointer");
   const GdrT5Dims& dm = w->dims;
-  BeamDims bd{B, num_beams, w->out_vocab, dm.vocab_size, max_length, num_return_sequences, length_penalty};
+  BeamDims bd{B, num_beams, w->out_vocab, dm.vocab_size, max_length, num_return_sequences, length_penalty,
+              trie ? trie->child : nullptr, trie ? trie->eos_ok : nullptr};
+  GDR_CHECK_ARG(!trie || (trie->child && trie->eos_ok && trie->n_nodes > 0), "generate: bad trie");
   int rc = check_beam_dims(bd, max_length);
   if (rc) return rc;
   GDR_CHECK_ARG(L >= 1 && L <= 128, "generate: L=%d must be in [1,128]", L);
@@ -628,18 +648,20 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
 
 extern "C" size_t gdr_beam_search_table_workspace_bytes(int B, int num_beams, int max_length, int out_vocab) {
   if (B <= 0 || num_beams <= 0 || max_length < 2) return 0;
-  gdr::BeamDims bd{B, num_beams, out_vocab, out_vocab * max_length + 2, max_length, num_beams, 1.0};
+  gdr::BeamDims bd{B, num_beams, out_vocab, out_vocab * max_length + 2, max_length, num_beams, 1.0, nullptr, nullptr};
   return gdr::beam_layout(bd, nullptr, nullptr);
 }
 
 extern "C" int gdr_beam_search_table(const float* table, int B, int out_vocab, int num_beams, int max_length,
-                                     double length_penalty, int num_return_sequences, int64_t* out_ids,
-                                     int32_t* out_len, double* out_scores, void* workspace, size_t workspace_bytes,
-                                     void* stream_) {
+                                     double length_penalty, int num_return_sequences, const GdrTrie* trie,
+                                     int64_t* out_ids, int32_t* out_len, double* out_scores, void* workspace,
+                                     size_t workspace_bytes, void* stream_) {
   using namespace gdr;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GDR_CHECK_ARG(table && out_ids && out_len && out_scores && workspace, "beam_search_table: null pointer");
-  BeamDims bd{B, num_beams, out_vocab, out_vocab * max_length + 2, max_length, num_return_sequences, length_penalty};
+  BeamDims bd{B, num_beams, out_vocab, out_vocab * max_length + 2, max_length, num_return_sequences, length_penalty,
+              trie ? trie->child : nullptr, trie ? trie->eos_ok : nullptr};
+  GDR_CHECK_ARG(!trie || (trie->child && trie->eos_ok && trie->n_nodes > 0), "beam_search_table: bad trie");
   int rc = check_beam_dims(bd, max_length);
   if (rc) return rc;
   const size_t need = beam_layout(bd, nullptr, nullptr);

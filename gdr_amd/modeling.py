@@ -60,7 +60,9 @@ class GDRModel:
     """T5ForConditionalGeneration of the reference (GDR config: decode_embedding=2, adaptor_efficient),
     inference only.  Construct from a reference-style state_dict (SURVEY Appendix C key names)."""
 
-    def __init__(self, cfg: GDRConfig, state_dict, device="cuda:0", with_decoder=True):
+    def __init__(self, cfg: GDRConfig, state_dict, device="cuda:0", with_decoder=True, trie=None):
+        """trie: optional codec.Trie — enables the NCI trie constraint of the reference's earlier
+        generation_utils_previous.py:714-729 (the shipped generate() ignores `decode_tree`)."""
         self.config = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -68,6 +70,7 @@ class GDRModel:
         sd = strip_lightning_prefix(state_dict)
         self.enc = ops.T5EncoderHandle(cfg, sd, self.device)
         self.dec = ops.T5DecoderHandle(cfg, sd, self.device) if with_decoder else None
+        self.trie = ops.DeviceTrie(trie, self.device) if trie is not None else None
         self.training = False
 
     def eval(self):
@@ -117,7 +120,7 @@ class GDRModel:
         input_ids, attention_mask = input_ids.to(self.device), attention_mask.to(self.device)
         enc_h, _ = self.enc.forward(input_ids, attention_mask, want_pooled=False)
         ids, lens, scores = self.dec.generate(enc_h, attention_mask, num_beams, max_length, length_penalty,
-                                              num_return_sequences)
+                                              num_return_sequences, trie=self.trie)
         decoded, score_list = ops.finish_generate_output(ids, lens, scores, max_length)
         output = (decoded, score_list) if output_scores else decoded
         if output_encoder_embedding:

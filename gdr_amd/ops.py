@@ -316,7 +316,8 @@ class T5DecoderHandle:
                                                self._alayers, self.head_w.data_ptr(), self.head_e.data_ptr())
         self.ws = Workspace(device)
 
-    def generate(self, enc_hidden, enc_mask, num_beams, max_length, length_penalty, num_return_sequences, trace=False):
+    def generate(self, enc_hidden, enc_mask, num_beams, max_length, length_penalty, num_return_sequences, trace=False,
+                 trie=None):
         """Returns (out_ids int64[B*nret,max_length], out_len int32[B*nret], out_scores float64[B*nret][, trace])."""
         _need_cuda(enc_hidden, enc_mask)
         enc_hidden = _f32c(enc_hidden)
@@ -334,12 +335,25 @@ class T5DecoderHandle:
             ts = torch.empty((max_length - 1, B, 2 * R), dtype=torch.float32, device=dev_)
             tt = torch.empty((max_length - 1, B, 2 * R), dtype=torch.int32, device=dev_)
         check(lib().gdr_t5_generate(C.byref(self.struct), ptr(enc_hidden), ptr(mask), B, L, R, max_length,
-                                    float(length_penalty), nret, ptr(ids), ptr(lens), ptr(scores), ptr(ts), ptr(tt),
+                                    float(length_penalty), nret, trie.struct_ref() if trie is not None else None,
+                                    ptr(ids), ptr(lens), ptr(scores), ptr(ts), ptr(tt),
                                     ptr(ws), ws.numel(), stream_ptr()), "gdr_t5_generate")
         return (ids, lens, scores, ts, tt) if trace else (ids, lens, scores)
 
 
-def beam_search_table(table, out_vocab, num_beams, max_length, length_penalty, num_return_sequences=None):
+class DeviceTrie:
+    """codec.Trie arrays resident on the GPU + the GdrTrie struct."""
+
+    def __init__(self, trie, device):
+        self.child = torch.from_numpy(trie.child).to(device).contiguous()
+        self.eos_ok = torch.from_numpy(trie.eos_ok).to(device).contiguous()
+        self.struct = _ffi.GdrTrie(self.child.data_ptr(), self.eos_ok.data_ptr(), self.child.shape[0])
+
+    def struct_ref(self):
+        return C.byref(self.struct)
+
+
+def beam_search_table(table, out_vocab, num_beams, max_length, length_penalty, num_return_sequences=None, trie=None):
     """Device beam search driven by a logit table [B, max_length, Vd, Vd] — gdr_beam_search_table."""
     _need_cuda(table)
     table = _f32c(table)
@@ -351,6 +365,7 @@ def beam_search_table(table, out_vocab, num_beams, max_length, length_penalty, n
     lens = torch.empty((B * nret,), dtype=torch.int32, device=table.device)
     scores = torch.empty((B * nret,), dtype=torch.float64, device=table.device)
     check(lib().gdr_beam_search_table(ptr(table), B, out_vocab, num_beams, max_length, float(length_penalty), nret,
+                                      trie.struct_ref() if trie is not None else None,
                                       ptr(ids), ptr(lens), ptr(scores), ptr(ws), ws.numel(), stream_ptr()),
           "gdr_beam_search_table")
     return ids, lens, scores

@@ -232,6 +232,18 @@ typedef struct {
   const float* head_e;             /* [(max_out_len-1), V+1, d]    */
 } GdrT5DecoderWeights;
 
+/* Optional trie constraint = the NCI semantics of the reference's earlier, un-imported generation_utils_previous.py:
+ * 714-729 (`--tree 1`; the shipped generation_utils.py has the block commented out): after log_softmax,
+ * -inf on every token that is not a child of the trie node reached by the beam's prefix (trie = TreeBuilder of
+ * main_models.py:112-151 over the docids); a prefix that left the tree may only emit EOS.  Flattened for the device:
+ * child[node*V + c] = next node (or -1) for digit c at the node's depth, eos_ok[node] = 1 if EOS is a child;
+ * node 0 is the root.  Pass NULL for the shipped behaviour (positional vocabulary mask only). */
+typedef struct {
+  const int32_t* child;   /* device int32 [n_nodes, V] */
+  const int32_t* eos_ok;  /* device int32 [n_nodes]    */
+  int32_t n_nodes;
+} GdrTrie;
+
 size_t gdr_t5_generate_workspace_bytes(const GdrT5DecoderWeights* w, int B, int L, int num_beams, int max_length);
 /* enc_hidden fp32[B,L,d] (NOT beam-expanded), enc_mask int64[B,L].
  * out_ids int64[B*nret, max_length] (hypothesis tokens incl. START, then EOS if it fits, then PAD),
@@ -241,7 +253,7 @@ size_t gdr_t5_generate_workspace_bytes(const GdrT5DecoderWeights* w, int B, int 
  * 2 <= num_beams <= 256, num_return_sequences <= num_beams, max_length <= max_out_len. */
 int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B, int L,
                     int num_beams, int max_length, double length_penalty, int num_return_sequences,
-                    int64_t* out_ids, int32_t* out_len, double* out_scores, float* step_scores,
+                    const GdrTrie* trie, int64_t* out_ids, int32_t* out_len, double* out_scores, float* step_scores,
                     int32_t* step_tokens, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same device beam search driven by a logit table instead of the model (teacher forcing):
@@ -249,8 +261,8 @@ int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const
  * Exercises EOS / early-done / eviction paths that random weights never reach. */
 size_t gdr_beam_search_table_workspace_bytes(int B, int num_beams, int max_length, int out_vocab);
 int gdr_beam_search_table(const float* table, int B, int out_vocab, int num_beams, int max_length,
-                          double length_penalty, int num_return_sequences, int64_t* out_ids, int32_t* out_len,
-                          double* out_scores, void* workspace, size_t workspace_bytes, void* stream);
+                          double length_penalty, int num_return_sequences, const GdrTrie* trie, int64_t* out_ids,
+                          int32_t* out_len, double* out_scores, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

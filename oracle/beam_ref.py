@@ -39,9 +39,39 @@ class BeamHypotheses:
         return self.worst_score >= cur_score
 
 
+def trie_mask(input_ids, decode_tree, vocab_size):
+    """The trie constraint of the un-imported earlier generation_utils_previous.py:714-729 (NCI semantics, `--tree 1`):
+    -inf on every token that is not a child of the node reached by the row's prefix; a prefix that left the tree may
+    only emit EOS.  `decode_tree` is a nested dict {token: subtree} (the reference's Node.children)."""
+    mask = torch.full((input_ids.shape[0], vocab_size), float("-inf"))
+    for i in range(input_ids.shape[0]):
+        cur = decode_tree
+        for value in input_ids[i, 1:].tolist():
+            if value not in cur:
+                nxt = [1]
+                break
+            cur = cur[value]
+        else:
+            nxt = list(cur.keys())
+        mask[i, nxt] = 0
+    return mask
+
+
+def build_trie(seqs):
+    """TreeBuilder.add (main_models.py:135-151) as nested dicts: seqs are token lists with trailing EOS(1), PAD(0) ends."""
+    root = {}
+    for seq in seqs:
+        cur = root
+        for tok in seq:
+            if tok == 0:
+                break
+            cur = cur.setdefault(tok, {})
+    return root
+
+
 def beam_search(step_fn, batch_size, num_beams, vocab_size, max_length, length_penalty,
                 num_return_sequences=None, eos_token_id=1, pad_token_id=0, start_token_id=0,
-                trace=None):
+                trace=None, decode_tree=None):
     """step_fn(seq int64[B*R, cur_len]) -> next-token logits fp32[B*R, vocab_size] (last position,
     positional mask already applied).  Returns (decoded int64[B*nret, <=max_length], scores list[float]).
     ``trace`` (a list) receives per step (top_scores[B,2R], top_tokens[B,2R]) for golden comparison."""
@@ -57,6 +87,8 @@ def beam_search(step_fn, batch_size, num_beams, vocab_size, max_length, length_p
     while cur_len < max_length:                                           # :676
         logits = step_fn(input_ids)
         scores = F.log_softmax(logits, dim=-1)                            # :698
+        if decode_tree is not None:                                       # generation_utils_previous.py:714-729
+            scores = scores + trie_mask(input_ids, decode_tree, vocab_size)
         next_scores = (scores + beam_scores[:, None]).view(batch_size, R * vocab_size)
         next_scores, next_tokens = torch.topk(next_scores, 2 * R, dim=1, largest=True, sorted=True)  # :775
         if trace is not None:

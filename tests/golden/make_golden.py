@@ -481,6 +481,78 @@ def g_doc_tower():
     save("g10_doc_tower", seed=4321, **out)
 
 
+def g_beam_trie():
+    """G11: trie-constrained beam search — the reference's earlier `generation_utils_previous.GenerationMixin`
+    (un-imported by the shipped code; :714-729 hold the active constraint) with a trie built by the reference's own
+    TreeBuilder (main_models.py:112-151), driven by a logit table."""
+    import main_models
+    from transformers.generation_utils_previous import GenerationMixin as PrevMixin
+    from transformers.modeling_outputs import Seq2SeqLMOutput, BaseModelOutput
+    from transformers.configuration_t5 import T5Config
+
+    class Fake(torch.nn.Module, PrevMixin):
+        def __init__(self, table, V, Vd):
+            super().__init__()
+            self.table, self.V, self.Vd = table, V, Vd
+            self.config = T5Config(is_encoder_decoder=True, decoder_start_token_id=0, pad_token_id=0, eos_token_id=1,
+                                   vocab_size=Vd)
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def get_encoder(self):
+            return lambda i, attention_mask=None, return_dict=True: BaseModelOutput(
+                last_hidden_state=i[:, :, None].float().repeat(1, 1, 4))
+
+        def get_output_embeddings(self):
+            return self.p
+
+        def prepare_inputs_for_generation(self, input_ids, past, attention_mask, use_cache, encoder_outputs, **kw):
+            return {"decoder_input_ids": input_ids, "encoder_outputs": encoder_outputs}
+
+        def adjust_logits_during_generation(self, logits, **kwargs):
+            return logits
+
+        def forward(self, decoder_input_ids=None, encoder_outputs=None, return_dict=True, **_kw):
+            R, t = decoder_input_ids.shape
+            b = (encoder_outputs.last_hidden_state[:, 0, 0]).long()
+            lg = self.table[b, t - 1, decoder_input_ids[:, -1]]
+            mask = torch.full((self.Vd,), -1e9)
+            mask[(t - 1) * self.V + 2:(t - 1) * self.V + self.V + 2] = 0
+            mask[1] = 0
+            return Seq2SeqLMOutput(logits=(lg + mask)[:, None, :].expand(R, t, self.Vd))
+
+    cases = {}
+    for name, (V, maxlen, R, B, n_ids, seed) in {"a": (6, 6, 4, 4, 60, 31), "b": (6, 6, 10, 3, 25, 32),
+                                                 "c": (30, 10, 10, 3, 4000, 33)}.items():
+        Vd = V * maxlen + 2
+        g = np.random.Generator(np.random.PCG64(seed))
+        depth_hi = maxlen - 2
+        ids = set()
+        while len(ids) < n_ids:
+            depth = int(g.integers(2, depth_hi + 1))
+            ids.add("-".join(str(int(x)) for x in g.integers(0, V, size=depth)))
+        ids = sorted(ids)
+        args = types.SimpleNamespace(kary=V, position=1)
+        tb = main_models.TreeBuilder()
+        seqs = np.zeros((len(ids), maxlen), dtype=np.int64)
+        for i, s_ in enumerate(ids):
+            toks = main_models.encode_single_newid(args, s_)
+            seqs[i, :len(toks)] = toks
+            tb.add(seqs[i].tolist(), i)
+        table = synth.make_logit_table(B, maxlen, Vd, 1.5, seed)
+        fake = Fake(torch.from_numpy(table), V, Vd)
+        qids = torch.arange(B).view(B, 1).repeat(1, 3)
+        with torch.no_grad():
+            (outs, scores), _ = quiet(fake.generate, qids, attention_mask=torch.ones_like(qids), use_cache=False,
+                                      max_length=maxlen, num_beams=R, length_penalty=0.8, num_return_sequences=R,
+                                      early_stopping=False, decode_embedding=2, decode_vocab_size=Vd,
+                                      decode_tree=tb.build(), output_scores=True, output_encoder_embedding=True)
+        cases[f"{name}_seqs"] = seqs
+        cases[f"{name}_decoded"] = outs.numpy()
+        cases[f"{name}_scores"] = np.array(scores, np.float64)
+        cases[f"{name}_meta"] = np.array([V, maxlen, R, B, seed])
+    save("g11_beam_trie", **cases)
+
+
 def g_cli():
     """G9: the reference argparse namespace (main.py:260-448) for no flags and for infer.sh's flags (without
     --trivia, which the reference parser rejects).  main.py itself cannot be imported (nltk / pytorch_lightning),
@@ -509,7 +581,7 @@ def g_cli():
 
 
 FIXTURES = ["buckets", "encoder_tiny", "encoder_base", "sim_topk", "decode_logits_tiny", "generate_tiny",
-            "generate_base", "beam_table", "codec", "metrics", "rerank", "cli", "doc_tower"]
+            "generate_base", "beam_table", "codec", "metrics", "rerank", "cli", "doc_tower", "beam_trie"]
 
 
 def main():

@@ -153,3 +153,49 @@ def test_doc_tower_vs_reference_golden(dev):
             np.testing.assert_allclose(hid.cpu().numpy(), g["tiny_hidden"], rtol=tol, atol=tol)
         else:
             np.testing.assert_allclose(hid[:, [1, 64, 127]].cpu().numpy(), g["base_rows"], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_trie_constrained_beam_vs_reference_golden(dev, case):
+    """Opt-in trie mode on the device beam kernels vs the reference's generation_utils_previous."""
+    from gdr_amd import codec, ops
+    g = golden("g11_beam_trie")
+    V, maxlen, R, B, seed = [int(x) for x in g[f"{case}_meta"]]
+    Vd = V * maxlen + 2
+    table = torch.from_numpy(synth.make_logit_table(B, maxlen, Vd, 1.5, seed)).to(dev)
+    trie = ops.DeviceTrie(codec.Trie.from_sequences(g[f"{case}_seqs"].tolist(), V), dev)
+    ids, lens, scores = ops.beam_search_table(table, V, R, maxlen, 0.8, trie=trie)
+    dec, sc = ops.finish_generate_output(ids, lens, scores, maxlen)
+    np.testing.assert_allclose(np.array(sc), g[f"{case}_scores"], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(dec.cpu().numpy(), g[f"{case}_decoded"])
+
+
+def test_generate_with_trie_only_returns_corpus_docids(dev):
+    """Full model + trie: every hypothesis is a docid of the corpus (random weights otherwise wander off it), and the
+    result equals the oracle's trie-constrained beam search."""
+    from gdr_amd import codec
+    from gdr_amd.modeling import GDRModel
+    from oracle import beam_ref, t5_ref
+    cfg = GDRConfig.tiny()
+    sd = synth.make_state_dict(cfg, seed=5)
+    V = cfg.output_vocab_size
+    g = np.random.Generator(np.random.PCG64(1))
+    docids = sorted({"-".join(str(int(x)) for x in g.integers(0, V, size=int(g.integers(2, 4)))) for _ in range(40)})
+    trie = codec.Trie.from_docids(docids, V)
+    ids, mask = synth.make_tokens(3, L=9, vocab_hi=cfg.vocab_size, seed=21, min_len=2)
+    model = GDRModel(cfg, sd, dev, trie=trie)
+    R = 4
+    (dec, sc), _ = model.generate(torch.from_numpy(ids).to(dev), attention_mask=torch.from_numpy(mask).to(dev),
+                                  max_length=cfg.max_output_length, num_beams=R, length_penalty=0.8,
+                                  num_return_sequences=R, output_scores=True)
+    got = codec.decode_token(dec.cpu().numpy(), kary=V, output_vocab_size=V)
+    assert all(s in set(docids) for s in got), got
+    # oracle with the same constraint
+    tree = beam_ref.build_trie([codec.encode_single_newid(s, kary=V) for s in docids])
+    enc = t5_ref.encoder_forward(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask))
+    idx = torch.arange(3).repeat_interleave(R)
+    enc_x, mask_x = enc[idx], torch.from_numpy(mask)[idx]
+    step = lambda seq: t5_ref.decode_logits(sd, cfg, seq, enc_x, mask_x, restricted=True)
+    rd, rs = beam_ref.beam_search(step, 3, R, cfg.decode_vocab_size, cfg.max_output_length, 0.8, decode_tree=tree)
+    np.testing.assert_allclose(np.array(sc), np.array(rs), rtol=1e-4, atol=1e-4)
+    assert np.array_equal(dec.cpu().numpy(), rd.numpy())

@@ -187,3 +187,26 @@ def test_sharded_search_two_ranks_gloo(tmp_path):
     mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert np.load(tmp_path / f"ok{r}.npy").tolist() == [1, 1]
+
+
+def test_trie_flattening_matches_reference_treebuilder_semantics():
+    """codec.Trie (flat arrays for the device) encodes exactly the nested children of TreeBuilder.add
+    (main_models.py:135-151) for the docid sequences of the reference-made fixture."""
+    from gdr_amd import codec
+    from oracle import beam_ref
+    g = golden("g11_beam_trie")
+    for case in "abc":
+        V = int(g[f"{case}_meta"][0])
+        seqs = g[f"{case}_seqs"].tolist()
+        t = codec.Trie.from_sequences(seqs, V)
+        nested = beam_ref.build_trie(seqs)
+
+        def walk(node_dict, node, depth):
+            kids = {tok for tok in node_dict}
+            flat = {depth * V + 2 + c for c in range(V) if t.child[node, c] >= 0} | ({1} if t.eos_ok[node] else set())
+            assert kids == flat, (case, depth, kids, flat)
+            for tok, sub in node_dict.items():
+                if tok != 1:
+                    walk(sub, int(t.child[node, tok - (depth * V + 2)]), depth + 1)
+
+        walk(nested, 0, 0)

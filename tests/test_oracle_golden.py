@@ -197,3 +197,27 @@ def test_doc_tower_matches_reference():
             np.testing.assert_allclose(h.numpy(), g["tiny_hidden"], rtol=2e-5, atol=2e-5)
         else:
             np.testing.assert_allclose(h[:, [1, 64, 127]].numpy(), g["base_rows"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_trie_constrained_beam_matches_reference(case):
+    """The trie mode of generation_utils_previous.py:714-729 (restated in beam_ref.trie_mask)."""
+    g = golden("g11_beam_trie")
+    V, maxlen, R, B, seed = [int(x) for x in g[f"{case}_meta"]]
+    Vd = V * maxlen + 2
+    table = torch.from_numpy(synth.make_logit_table(B, maxlen, Vd, 1.5, seed))
+    qid = torch.arange(B).repeat_interleave(R)
+    tree = beam_ref.build_trie(g[f"{case}_seqs"].tolist())
+
+    def step(seq):
+        t = seq.shape[1]
+        return table[qid, t - 1, seq[:, -1]] + t5_ref.positional_mask(t, Vd, V)[t - 1]
+
+    dec, scores = beam_ref.beam_search(step, B, R, Vd, maxlen, 0.8, decode_tree=tree)
+    np.testing.assert_allclose(np.array(scores), g[f"{case}_scores"], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(dec.numpy(), g[f"{case}_decoded"])
+    # every returned id is a real docid of the trie
+    valid = {tuple(int(t) for t in s if t != 0) for s in g[f"{case}_seqs"].tolist()}
+    for row in dec.numpy():
+        toks = [int(t) for t in row[1:] if t != 0]
+        assert tuple(toks) in valid
