@@ -225,13 +225,28 @@ class GDRRetriever:
     beam-decode cluster ids -> id_mapping lookup -> tanh(q·d) over the candidates -> + alpha*softmax(beam scores)
     per cluster -> top-k, for every alpha in score_rate."""
 
-    def __init__(self, model: GDRModel, doc_embed, cluster_index: codec.ClusterIndex, args):
+    def __init__(self, model: GDRModel, doc_embed, cluster_index: codec.ClusterIndex, args, doc_tower=None,
+                 doc_tokens=None):
+        """doc_embed: fp32 [N, d] resident on the GPU (the reference's `self.doc_embed`).
+        doc_tower + doc_tokens=(input_ids int64[N,Lp], attention_mask) enable the stage-2 re-encode path of
+        main_models.py:1445-1455 (`epoch > train_encoder_epoch`): candidate docs are embedded on the fly by the
+        BERT/DPR tower instead of being looked up (tokenisation itself is out of scope: tokens come pre-computed)."""
         self.model, self.args, self.index = model, args, cluster_index
-        self.doc_embed = doc_embed                      # fp32 [N, d] resident on the GPU
-        self.encoder = EncoderModel()
+        self.doc_embed = doc_embed
+        self.encoder = doc_tower if doc_tower is not None else EncoderModel()
+        self.doc_tokens = doc_tokens
+
+    def _reencode(self, cand_ids, chunk=1024):
+        """Embeds the candidate docs with the doc tower (main_models.py:1445-1455).  cand_ids int32 [total] on device."""
+        tok, msk = self.doc_tokens
+        out = []
+        for lo in range(0, cand_ids.numel(), chunk):
+            sel = cand_ids[lo:lo + chunk].long()
+            out.append(self.encoder(passage={"input_ids": tok[sel], "attention_mask": msk[sel]}))
+        return torch.cat(out, dim=0)
 
     @torch.no_grad()
-    def validation_step_i(self, batch, i=-1):
+    def validation_step_i(self, batch, i=-1, reencode=False):
         a = self.args
         R = a.num_return_sequences
         decode_vocab_size = a.output_vocab_size * a.max_output_length + 2
@@ -245,9 +260,19 @@ class GDRRetriever:
         offs, ids, max_cand = self.index.candidates(dec)
         B = len(dec)
         beam_scores = torch.tensor(scores, dtype=torch.float32, device=query_embeds.device).view(B, R)
-        vals, idx = ops.rerank_topk(query_embeds, self.doc_embed, offs.to(query_embeds.device),
-                                    ids.to(query_embeds.device), beam_scores, list(a.score_rate), R,
-                                    func=getattr(a, "loss_func", "tanh"), max_cand=max_cand)
+        dev_ids = ids.to(query_embeds.device)
+        if reencode:
+            if self.doc_tokens is None or getattr(self.encoder, "bert", None) is None:
+                raise _ffi.GdrError("re-encode needs doc_tower= and doc_tokens=")
+            cand_embeds = self._reencode(dev_ids)                                   # [total, d], candidate order
+            local = torch.arange(dev_ids.numel(), dtype=torch.int32, device=dev_ids.device)
+            vals, pos = ops.rerank_topk(query_embeds, cand_embeds, offs.to(query_embeds.device), local, beam_scores,
+                                        list(a.score_rate), R, func=getattr(a, "loss_func", "tanh"), max_cand=max_cand)
+            idx = torch.where(pos >= 0, dev_ids[pos.clamp(min=0).long()], pos)      # candidate position -> doc id
+        else:
+            vals, idx = ops.rerank_topk(query_embeds, self.doc_embed, offs.to(query_embeds.device), dev_ids,
+                                        beam_scores, list(a.score_rate), R, func=getattr(a, "loss_func", "tanh"),
+                                        max_cand=max_cand)
         idx_h = idx.cpu().tolist()
         inf_index = [[[str(x) for x in idx_h[b][ai]] for ai in range(len(a.score_rate))] for b in range(B)]
         return {"clusters": dec, "inf_result_batch_prob": scores, "inf_index_batch": inf_index,

@@ -199,3 +199,44 @@ def test_generate_with_trie_only_returns_corpus_docids(dev):
     rd, rs = beam_ref.beam_search(step, 3, R, cfg.decode_vocab_size, cfg.max_output_length, 0.8, decode_tree=tree)
     np.testing.assert_allclose(np.array(sc), np.array(rs), rtol=1e-4, atol=1e-4)
     assert np.array_equal(dec.cpu().numpy(), rd.numpy())
+
+
+def test_two_stage_with_reencode_vs_oracle(dev):
+    """Stage-2 re-encode path (main_models.py:1445-1455): candidate docs embedded on the fly by the
+    doc tower, then reranked — vs the oracle composition bert_ref + rerank."""
+    from gdr_amd import codec
+    from gdr_amd.modeling import GDRModel, GDRRetriever, EncoderModel
+    from oracle import beam_ref, bert_ref, codec_ref, retrieval_ref
+    bc = synth.bert_config(True)                                                   # hidden 128
+    cfg = GDRConfig.tiny(d_model=128, d_kv=32, num_heads=4, d_ff=256)
+    sd, bsd = synth.make_state_dict(cfg, seed=6), synth.make_bert_state_dict(bc, seed=7)
+    # keep q·d of order 1: raw dot products of un-normalised embeddings saturate tanh to exactly 1.0 and turn the
+    # ranking into a mass tie (SURVEY §7.2 "tanh saturation")
+    last = f"{synth.BERT_PREFIX}encoder.layer.{bc['num_layers'] - 1}.output.LayerNorm."
+    bsd[last + "weight"], bsd[last + "bias"] = bsd[last + "weight"] * 0.008, bsd[last + "bias"] * 0.008
+    V = cfg.output_vocab_size
+    B, R, csize, Lp = 2, 4, 3, 24
+    ids, mask = synth.make_tokens(B, L=10, vocab_hi=cfg.vocab_size, seed=13, min_len=2)
+    (rd, rs), enc_x = beam_ref.generate(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask), R, restricted_head=True)
+    dec = codec_ref.dec_2d(codec_ref.decode_token(rd.numpy(), output_vocab_size=V, kary=V), R)
+    names = sorted({s for row in dec for s in row}) + ["filler-a", "filler-b"]
+    N = len(names) * csize
+    offsets = (np.arange(len(names) + 1) * csize).astype(np.int32)
+    members = np.random.Generator(np.random.PCG64(4)).permutation(N).astype(np.int32)
+    ptok, pmask = synth.make_tokens(N, L=Lp, vocab_hi=bc["vocab_size"], seed=19, min_len=4)
+    args = types.SimpleNamespace(num_return_sequences=R, output_vocab_size=V, max_output_length=cfg.max_output_length,
+                                 length_penalty=0.8, kary=V, position=1, score_rate=[0, 1, 3], loss_func="tanh")
+    tower = EncoderModel.from_state_dict(bc, bsd, dev)
+    retr = GDRRetriever(GDRModel(cfg, sd, dev), None, codec.ClusterIndex(names, offsets, members), args, doc_tower=tower,
+                        doc_tokens=(torch.from_numpy(ptok).to(dev), torch.from_numpy(pmask).to(dev)))
+    out = retr.validation_step_i({"source_ids": torch.from_numpy(ids).to(dev), "source_mask": torch.from_numpy(mask).to(dev)},
+                                 reencode=True)
+    assert out["clusters"] == dec
+    _, Dref = bert_ref.bert_forward(bsd, bc, torch.from_numpy(ptok), torch.from_numpy(pmask))     # every doc's embedding
+    look = {n: i for i, n in enumerate(names)}
+    mem_q = [[m for s in row for m in members[offsets[look[s]]:offsets[look[s] + 1]].tolist()] for row in dec]
+    ref = retrieval_ref.rerank(enc_x[::R][:, 0], Dref, mem_q, [[csize] * R] * B, np.array(rs, np.float32).reshape(B, R).tolist(),
+                               args.score_rate, R)
+    for b in range(B):
+        for a in range(len(args.score_rate)):
+            assert out["inf_index_batch"][b][a] == [str(x) for x in ref[b][a][1].tolist()]

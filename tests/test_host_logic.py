@@ -210,3 +210,29 @@ def test_trie_flattening_matches_reference_treebuilder_semantics():
                     walk(sub, int(t.child[node, tok - (depth * V + 2)]), depth + 1)
 
         walk(nested, 0, 0)
+
+
+def test_artifact_converters_on_synthetic_pickles(tmp_path):
+    """tools/convert_artifacts.py on pickles shaped like the reference's (doc_embedding.pkl: list of [1,d] tensors;
+    indexmap.pkl: dict cluster-string -> doc ids; Lightning ckpt with model./encoder.model. prefixes)."""
+    import importlib.util
+    import pickle
+    import torch
+    spec = importlib.util.spec_from_file_location("convert_artifacts", os.path.join(REPO, "tools", "convert_artifacts.py"))
+    ca = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ca)
+    g = np.random.Generator(np.random.PCG64(1))
+    emb = [torch.from_numpy(g.standard_normal((1, 16)).astype(np.float32)) for _ in range(7)]
+    arr = ca.convert_doc_embedding(pickle.loads(pickle.dumps(emb)))
+    assert arr.shape == (7, 16) and arr.dtype == np.float32 and np.array_equal(arr[3], emb[3].numpy()[0])
+    assert np.array_equal(ca.convert_doc_embedding({i: e[0] for i, e in enumerate(emb)}), arr)
+    im = {"3-1": [5, 2], "0-0": [1], "29-4-7": [0, 3, 4, 6]}
+    z = ca.convert_indexmap(pickle.loads(pickle.dumps(im)))
+    from gdr_amd import codec
+    idx = codec.ClusterIndex([str(x) for x in z["cluster_names"]], z["cluster_offsets"], z["cluster_members"])
+    assert all(idx[k] == v for k, v in im.items())
+    ckpt = {"state_dict": {"model.shared.weight": torch.zeros(2, 2), "model.encoder.block.0.x": torch.ones(1),
+                           "encoder.model.ctx_encoder.bert_model.embeddings.word_embeddings.weight": torch.ones(3)}}
+    t5, tower = ca.split_checkpoint(ckpt)
+    assert set(t5) == {"shared.weight", "encoder.block.0.x"}
+    assert set(tower) == {"ctx_encoder.bert_model.embeddings.word_embeddings.weight"}
