@@ -23,6 +23,7 @@
 namespace gdr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDS_STRIDE = BK + 4;  // floats; 144 B rows, 16-B aligned
@@ -50,8 +51,13 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int EPI>
+// BF16 = false: fp32 operands on v_mfma_f32_32x32x2_f32.  BF16 = true: bf16 operands (fp32 accumulate) on
+// v_mfma_f32_32x32x16_bf16.  A K-step is 128 BYTES of every row either way (32 floats / 64 bf16), so staging, LDS
+// image and fragment addressing are byte-identical; only the MFMA issued per 16-byte fragment pair differs.
+template <int EPI, bool BF16 = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const GemmArgs g) {
+  constexpr int ES = BF16 ? 2 : 4;       // element size
+  constexpr int BKE = 128 / ES;          // elements per K-step
   __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDS_STRIDE + 2 * BN * LDS_STRIDE];
   float* const As = smem;
   float* const Bs = smem + 2 * BM * LDS_STRIDE;
@@ -85,17 +91,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
   const int tid = threadIdx.x;
   // ---- staging map: 8 lanes cover one 128-B row segment, 32 rows per pass, 4 passes ----
   const int lrow = tid >> 3;
-  const int lcol = (tid & 7) * 4;
-  const float* a_src[4];
-  const float* w_src[4];
+  const int lcol = (tid & 7) * 4;        // LDS column in floats (16-byte chunk index * 4)
+  const int lcole = (tid & 7) * (16 / ES);  // the same chunk in elements
+  const char* a_src[4];
+  const char* w_src[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     int64_t ra = m0 + lrow + 32 * p;
     ra = ra < g.M ? ra : g.M - 1;  // clamp: rows past the edge are computed and discarded
     int rw = n0 + lrow + 32 * p;
     rw = rw < g.N ? rw : g.N - 1;
-    a_src[p] = g.A + ra * g.lda + lcol + split * g.kchunk;
-    w_src[p] = g.W + (int64_t)rw * g.ldw + lcol + split * g.kchunk;
+    a_src[p] = reinterpret_cast<const char*>(g.A) + (ra * g.lda + lcole + split * g.kchunk) * ES;
+    w_src[p] = reinterpret_cast<const char*>(g.W) + ((int64_t)rw * g.ldw + lcole + split * g.kchunk) * ES;
   }
   const int st_off = lrow * LDS_STRIDE + lcol;
 
@@ -115,19 +122,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
 
   int klen = g.K;
   if (EPI == EPI_LINEAR && g.ksplit > 1) klen = min(g.kchunk, g.K - split * g.kchunk);
-  const int nk = (klen + BK - 1) / BK;
+  const int nk = (klen + BKE - 1) / BKE;
   // K tail (K % 32 != 0, K % 4 == 0): loads past K re-read the row's last float4 (a valid address) and the
   // VALUE is zeroed — never select between addresses, that demotes the loads to flat + scratch.
-  const bool ktail = (klen % BK) != 0;
+  const bool ktail = (klen % BKE) != 0;
   float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 
 #define GDR_GLOAD(kt_)                                                                    \
   do {                                                                                    \
-    int koff = (kt_)*BK;                                                                  \
+    int koff = (kt_)*128; /* bytes */                                                     \
     bool ok = true;                                                                       \
     if (ktail) {                                                                          \
-      ok = koff + lcol < klen;                                                            \
-      koff = ok ? koff : klen - 4 - lcol;                                                 \
+      ok = (kt_)*BKE + lcole < klen;                                                      \
+      koff = ok ? koff : (klen - 16 / ES - lcole) * ES;                                   \
     }                                                                                     \
     ra0 = *reinterpret_cast<const float4*>(a_src[0] + koff);                              \
     ra1 = *reinterpret_cast<const float4*>(a_src[1] + koff);                              \
@@ -171,8 +178,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
   acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x_, B1.x_, acc[0][1], 0, 0, 0); \
   acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x_, B0.x_, acc[1][0], 0, 0, 0); \
   acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x_, B1.x_, acc[1][1], 0, 0, 0);
-#define GDR_MFMA16(A0, A1, B0, B1) \
-  GDR_MFMA4(A0, A1, B0, B1, x) GDR_MFMA4(A0, A1, B0, B1, y) GDR_MFMA4(A0, A1, B0, B1, z) GDR_MFMA4(A0, A1, B0, B1, w)
+#define GDR_MFMA_BF(A, B, C) \
+  C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, B), C, 0, 0, 0);
+#define GDR_MFMA16(A0, A1, B0, B1)                                                                                   \
+  if constexpr (BF16) {                                                                                              \
+    GDR_MFMA_BF(A0, B0, acc[0][0]) GDR_MFMA_BF(A0, B1, acc[0][1]) GDR_MFMA_BF(A1, B0, acc[1][0])                     \
+    GDR_MFMA_BF(A1, B1, acc[1][1])                                                                                   \
+  } else {                                                                                                           \
+    GDR_MFMA4(A0, A1, B0, B1, x) GDR_MFMA4(A0, A1, B0, B1, y) GDR_MFMA4(A0, A1, B0, B1, z) GDR_MFMA4(A0, A1, B0, B1, w) \
+  }
 
   if (!ktail) {
     // Steady-state loop (K % 32 == 0), branch-free so that it is ONE scheduling region: the staging registers run
@@ -199,22 +213,41 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
       GDR_MFMA16(c2a0, c2a1, c2b0, c2b1)
       GDR_MFMA16(c3a0, c3a1, c3b0, c3b1)
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // ds_read: chunks 0,1
+      if constexpr (BF16) {  // 16 MFMAs of 32 cycles per K-step: two memory instructions behind each of the first 12
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // ds_write
-      }
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ds_read: chunks 2,3
-      }
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // global_load
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // ds_write
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ds_read: chunks 2,3
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // global_load
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 40, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 40, 0);
       __syncthreads();
     }
   } else {
@@ -225,7 +258,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
       const float* a = As + buf * BM * LDS_STRIDE + a_rd;
       const float* b = Bs + buf * BN * LDS_STRIDE + b_rd;
 #pragma unroll
-      for (int jj = 0; jj < BK / 8; ++jj) {
+      for (int jj = 0; jj < 4; ++jj) {
         float4 a0, a1, b0, b1;
         GDR_READ(a0, a1, b0, b1, a, b, jj)
         GDR_MFMA16(a0, a1, b0, b1)
@@ -329,7 +362,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
   }
 }
 
-template <int EPI>
+template <int EPI, bool BF16 = false>
 static int launch(const GemmArgs& g, int64_t tiles_m, hipStream_t stream) {
   const int64_t blocks = tiles_m * g.tiles_n;
   if (blocks <= 0) return GDR_OK;
@@ -337,7 +370,7 @@ static int launch(const GemmArgs& g, int64_t tiles_m, hipStream_t stream) {
     set_error("gemm: grid too large (%lld blocks)", (long long)blocks);
     return GDR_EINVAL;
   }
-  hipLaunchKernelGGL(gemm_nt_f32_kernel<EPI>, dim3((unsigned)blocks), dim3(GEMM_THREADS), 0, stream, g);
+  hipLaunchKernelGGL((gemm_nt_f32_kernel<EPI, BF16>), dim3((unsigned)blocks), dim3(GEMM_THREADS), 0, stream, g);
   GDR_CHECK_LAUNCH("gemm_nt_f32_kernel");
   return GDR_OK;
 }
@@ -477,8 +510,10 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
   return launch<EPI_LINEAR>(g, tiles_m, stream);
 }
 
-int launch_sim_gemm(const float* D, int64_t N, const float* Q, int B, int d, const SimEpilogue& ep,
+int launch_sim_gemm(const void* D_, int64_t N, const void* Q_, int B, int d, const SimEpilogue& ep, bool bf16,
                     hipStream_t stream) {
+  const float* D = static_cast<const float*>(D_);   // opaque: the kernel addresses operands in bytes
+  const float* Q = static_cast<const float*>(Q_);
   GemmArgs g{};
   g.A = D, g.W = Q, g.lda = d, g.ldw = d;
   g.M = N, g.N = B, g.K = d;
@@ -490,12 +525,13 @@ int launch_sim_gemm(const float* D, int64_t N, const float* Q, int B, int d, con
     int64_t rows = n_sample_tiles * BM;
     if (rows > N) rows = N;
     ProfScope prof(PROF_SIM_SAMPLE, 2.0 * (double)rows * (double)B * (double)d, stream);
-    return launch<EPI_SIM_SAMPLE>(g, n_sample_tiles, stream);
+    return bf16 ? launch<EPI_SIM_SAMPLE, true>(g, n_sample_tiles, stream) : launch<EPI_SIM_SAMPLE>(g, n_sample_tiles, stream);
   }
   int64_t rows = (tiles_m - n_sample_tiles) * BM;
   if (rows > N) rows = N;
   ProfScope prof(PROF_SIM_FILTER, 2.0 * (double)rows * (double)B * (double)d, stream);
-  return launch<EPI_SIM_FILTER>(g, tiles_m - n_sample_tiles, stream);
+  return bf16 ? launch<EPI_SIM_FILTER, true>(g, tiles_m - n_sample_tiles, stream)
+              : launch<EPI_SIM_FILTER>(g, tiles_m - n_sample_tiles, stream);
 }
 
 }  // namespace gdr

@@ -243,13 +243,57 @@ extern "C" size_t gdr_sim_topk_workspace_bytes(int B, int64_t N, int d, int k, i
   return gdr::make_plan(B, N, k, (flags & GDR_SIM_EXHAUSTIVE) != 0).total;
 }
 
+namespace gdr {
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float4* __restrict__ in, uint2* __restrict__ out,
+                                                            int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = in[i];
+  union {
+    __bf16 h[4];
+    uint2 u;
+  } o;
+  o.h[0] = (__bf16)v.x, o.h[1] = (__bf16)v.y, o.h[2] = (__bf16)v.z, o.h[3] = (__bf16)v.w;  // v_cvt_pk_bf16_f32: RNE, NaN-safe
+  out[i] = o.u;
+}
+
+static int sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, int k, int32_t idx_offset, float* out_val,
+                         int32_t* out_idx, int32_t* status, int flags, void* workspace, size_t workspace_bytes,
+                         bool bf16, hipStream_t stream);
+}  // namespace gdr
+
+extern "C" int gdr_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, void* stream_) {
+  using namespace gdr;
+  GDR_CHECK_ARG(in && out_bf16 && n >= 0 && n % 4 == 0, "cast: null pointer or n %% 4 != 0");
+  GDR_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)out_bf16 & 7) == 0, "cast: misaligned pointer");
+  if (n == 0) return GDR_OK;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), reinterpret_cast<const float4*>(in),
+                     reinterpret_cast<uint2*>(out_bf16), n / 4);
+  GDR_CHECK_LAUNCH("cast_f32_bf16_kernel");
+  return GDR_OK;
+}
+
 extern "C" int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, int d, int k, int32_t idx_offset,
                             float* out_val, int32_t* out_idx, int32_t* status, int flags, void* workspace,
                             size_t workspace_bytes, void* stream_) {
-  using namespace gdr;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  return gdr::sim_topk_impl(Q, B, D, N, d, k, idx_offset, out_val, out_idx, status, flags, workspace, workspace_bytes,
+                            false, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int gdr_sim_topk_bf16(const void* Q, int B, const void* D, int64_t N, int d, int k, int32_t idx_offset,
+                                 float* out_val, int32_t* out_idx, int32_t* status, int flags, void* workspace,
+                                 size_t workspace_bytes, void* stream_) {
+  return gdr::sim_topk_impl(Q, B, D, N, d, k, idx_offset, out_val, out_idx, status, flags, workspace, workspace_bytes,
+                            true, static_cast<hipStream_t>(stream_));
+}
+
+int gdr::sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, int k, int32_t idx_offset,
+                       float* out_val, int32_t* out_idx, int32_t* status, int flags, void* workspace,
+                       size_t workspace_bytes, bool bf16, hipStream_t stream) {
   GDR_CHECK_ARG(Q && D && out_val && out_idx && workspace, "sim_topk: null pointer");
-  GDR_CHECK_ARG(B > 0 && N > 0 && d > 0 && d % 4 == 0, "sim_topk: bad shape B=%d N=%lld d=%d", B, (long long)N, d);
+  GDR_CHECK_ARG(B > 0 && N > 0 && d > 0 && d % (bf16 ? 8 : 4) == 0, "sim_topk: bad shape B=%d N=%lld d=%d", B,
+                (long long)N, d);
   GDR_CHECK_ARG(k >= 1 && k <= 1024 && k <= N, "sim_topk: k=%d must be in [1, min(1024, N)]", k);
   GDR_CHECK_ARG(N < 0x7fffffffLL - 256, "sim_topk: shard too large for int32 doc ids");
   GDR_CHECK_ARG(((uintptr_t)Q & 15) == 0 && ((uintptr_t)D & 15) == 0 && ((uintptr_t)workspace & 255) == 0,
@@ -270,14 +314,14 @@ extern "C" int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, in
   ep.cap = (int32_t)p.cap;
   ep.tile_stride = p.stride;
   ep.mode = 1;
-  int rc = launch_sim_gemm(D, N, Q, B, d, ep, stream);
+  int rc = launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(sim_threshold_kernel, dim3(B), dim3(SEL_THREADS), 0, stream, ep.cand_val, p.cap, (int)p.n_slots,
                      k, thr, ep.cand_cnt);
   GDR_CHECK_LAUNCH("sim_threshold_kernel");
   if (p.stride > 1) {
     ep.mode = 2;
-    rc = launch_sim_gemm(D, N, Q, B, d, ep, stream);
+    rc = launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
     if (rc) return rc;
   }
   const int kpad = next_pow2(k);

@@ -57,6 +57,15 @@ class Workspace:
         return self.buf
 
 
+def to_bf16(x):
+    """fp32 tensor -> bf16 tensor (round-to-nearest-even) — gdr_cast_f32_bf16."""
+    _need_cuda(x)
+    x = _f32c(x)
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib().gdr_cast_f32_bf16(ptr(x), ptr(out), x.numel(), stream_ptr()), "gdr_cast_f32_bf16")
+    return out
+
+
 def _sim_topk_raw(Q, D, k, idx_offset, workspace, flags):
     B, d = Q.shape
     N = D.shape[0]
@@ -65,8 +74,9 @@ def _sim_topk_raw(Q, D, k, idx_offset, workspace, flags):
     vals = torch.empty((B, k), dtype=torch.float32, device=Q.device)
     idx = torch.empty((B, k), dtype=torch.int32, device=Q.device)
     status = torch.empty((B,), dtype=torch.int32, device=Q.device)
-    check(lib().gdr_sim_topk(ptr(Q), B, ptr(D), N, d, k, idx_offset, ptr(vals), ptr(idx), ptr(status), flags, ptr(ws),
-                             ws.numel(), stream_ptr()), "gdr_sim_topk")
+    fn = lib().gdr_sim_topk_bf16 if Q.dtype == torch.bfloat16 else lib().gdr_sim_topk
+    check(fn(ptr(Q), B, ptr(D), N, d, k, idx_offset, ptr(vals), ptr(idx), ptr(status), flags, ptr(ws), ws.numel(),
+             stream_ptr()), "gdr_sim_topk")
     return vals, idx, status
 
 
@@ -76,7 +86,11 @@ def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_o
     list overflowed (degenerate corpora with tens of thousands of tied docs) exhaustively, so the result is exact for
     every input; return_status=True hands the device status tensor to the caller instead."""
     _need_cuda(Q, D)
-    Q, D = _f32c(Q), _f32c(D)
+    if D.dtype == torch.bfloat16:                                    # bf16 corpus: queries are cast on the device
+        Q = (Q if Q.dtype == torch.bfloat16 else to_bf16(Q)).contiguous()
+        D = D.contiguous()
+    else:
+        Q, D = _f32c(Q), _f32c(D)
     if D.shape[1] != Q.shape[1]:
         raise _ffi.GdrError(f"sim_topk: dim mismatch {Q.shape} vs {D.shape}")
     if k > D.shape[0]:

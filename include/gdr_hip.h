@@ -125,6 +125,16 @@ int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, int d, int k,
                  float* out_val, int32_t* out_idx, int32_t* status, int flags, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* bf16 corpus / bf16 queries, fp32 accumulate on v_mfma_f32_32x32x16_bf16 (BASELINE config C5: 1M x 768 bf16).
+ * Q, D are bf16 (uint16 bit patterns) [B,d] / [N,d]; d % 8 == 0 and d*2 % 128 == 0 is the fast path.  Scores and the
+ * top-k semantics are those of gdr_sim_topk applied to the bf16-rounded inputs (products of bf16 values are exact in
+ * fp32; only the summation order differs from a CPU fp32 matmul of the same rounded inputs). */
+int gdr_sim_topk_bf16(const void* Q, int B, const void* D, int64_t N, int d, int k, int32_t idx_offset,
+                      float* out_val, int32_t* out_idx, int32_t* status, int flags, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* fp32 -> bf16, round-to-nearest-even (v_cvt_pk_bf16_f32), n % 4 == 0. */
+int gdr_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, void* stream);
+
 /* Merge of per-shard top-k lists after the RCCL all-gather (no reference analogue):
  * vals/idx [G,B,k] (shard-major) -> [B,k]; same tie rule, so every rank computes identical output. */
 int gdr_topk_merge(const float* vals, const int32_t* idx, int G, int B, int k, float* out_val, int32_t* out_idx,

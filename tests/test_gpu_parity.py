@@ -169,6 +169,26 @@ def test_sim_topk_vs_oracle(dev, B, N, d, k):
     assert (np.diff(v.cpu().numpy(), axis=1) <= 0).all(), "values must be sorted descending"
 
 
+@pytest.mark.parametrize("B,N,d,k", [(5, 3000, 64, 7), (96, 40000, 768, 100), (33, 70001, 128, 10)])
+def test_sim_topk_bf16_vs_oracle_on_rounded_inputs(dev, B, N, d, k):
+    """bf16 corpus path (config C5): equals the fp32 oracle applied to the bf16-rounded inputs (products of bf16 values
+    are exact in fp32), and stays within the stated bf16 tolerance (3e-2 rel) of the unrounded fp32 scores."""
+    from gdr_amd import ops
+    from oracle import retrieval_ref
+    D = synth.make_corpus(N, d, seed=N + d)
+    Q, _ = synth.make_queries(D, B, seed=B)
+    Qd, Dd = torch.from_numpy(Q).to(dev), torch.from_numpy(D).to(dev)
+    Db = ops.to_bf16(Dd)
+    assert torch.equal(Db.cpu(), torch.from_numpy(D).to(torch.bfloat16)), "cast must be round-to-nearest-even like torch"
+    v, i, st = ops.sim_topk(Qd, Db, k, return_status=True)
+    assert int(st.sum().item()) == 0
+    Qr, Dr = torch.from_numpy(Q).to(torch.bfloat16).float(), torch.from_numpy(D).to(torch.bfloat16).float()
+    rv, ri = retrieval_ref.sim_topk(Qr, Dr, k)
+    order_insensitive_topk_match(rv.numpy(), ri.numpy(), v.cpu().numpy(), i.cpu().numpy().astype(np.int64), TOL)
+    fv, _ = retrieval_ref.sim_topk(torch.from_numpy(Q), torch.from_numpy(D), k)
+    np.testing.assert_allclose(v.cpu().numpy(), fv.numpy(), rtol=3e-2, atol=3e-2)
+
+
 def test_sim_topk_ties_resolve_to_lowest_id_and_offset(dev):
     """Duplicate docs give exactly tied scores: the rule 'higher score, then lower id' must hold bit-exactly."""
     from gdr_amd import ops
