@@ -72,6 +72,8 @@ _FLAGS = [
     ("trivia", int, 0),                      # infer.sh:15 passes it; only main_metrics.py reads it
     ("synthetic", int, 1), ("data_npz", str, ""), ("doc_embed_npy", str, ""), ("corpus_rows", int, 320000),
     ("n_queries", int, 512), ("res1_save_path", str, ""), ("device", str, "cuda:0"),
+    ("constrain_tree", int, 0),              # 1: apply the trie constraint of generation_utils_previous.py:714-729 (the
+                                             #    shipped generate() ignores decode_tree even with --tree 1)
 ]
 _SIZES = {"base": (12, 6, 3072, 768, 12, 64), "large": (24, 12, 4096, 1024, 16, 64), "small": (6, 3, 2048, 512, 8, 64)}
 
@@ -141,8 +143,9 @@ def inference(args):
         print("[gdr_amd] no --infer_ckpt: using seeded synthetic weights (no trained checkpoint ships with the reference)")
         sd = synth.make_state_dict(cfg, seed=1234)
     dev = torch.device(args.device)
-    model = GDRModel(cfg, sd, dev)
     data = _load_inputs(args, cfg)
+    trie = codec.Trie.from_docids(data["index"].names, args.kary) if args.constrain_tree else None
+    model = GDRModel(cfg, sd, dev, trie=trie)
     R = args.num_return_sequences
     two_stage = bool(args.is_train_encoder) and data["doc_embed"] is not None
     retr = GDRRetriever(model, torch.from_numpy(np.ascontiguousarray(data["doc_embed"], dtype=np.float32)).to(dev),
