@@ -288,26 +288,50 @@ template <int NT>
 __global__ __launch_bounds__(64 * NT) void attention_mfma_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int DK = 64, DS = DK + 4, LP = 32 * NT, NTHR = 64 * NT;
+  // Only the L real rows are staged; fragment reads of padded rows are clamped to row L-1 (finite duplicates): padded
+  // keys are removed by Mk = -inf (their probabilities are exactly 0), padded queries are never stored.
+  const int Lr = a.Lk;
   float* Qs = smem;
-  float* Ks = Qs + LP * DS;
-  float* Vs = Ks + LP * DS;
-  float* Bs = Vs + LP * DS;
+  float* Ks = Qs + Lr * DS;
+  float* Vs = Ks + Lr * DS;
+  float* RelB = Vs + Lr * DS;   // [2*LP]  bias of relative distance n = i_abs - j, index n + LP - 1 (+ q_pos0 folded in)
+  float* Mk = RelB + 2 * LP;    // [LP]    additive key term: 0, pad mask (-1e9) or -inf for padded rows
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int L = a.Lk, tid = threadIdx.x;
-  for (int e = tid; e < LP * (DK / 4); e += NTHR) {
-    const int r = e >> 4, c = e & 15;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f), k = q, v = q;
-    if (r < L) {
-      q = *reinterpret_cast<const float4*>(a.q + ((int64_t)b * a.q_bstride + r) * a.ldq + h * DK + 4 * c);
-      k = *reinterpret_cast<const float4*>(a.k + ((int64_t)b * a.k_bstride + r) * a.ldk + h * DK + 4 * c);
-      v = *reinterpret_cast<const float4*>(a.v + ((int64_t)b * a.k_bstride + r) * a.ldv + h * DK + 4 * c);
-      q.x *= a.scale, q.y *= a.scale, q.z *= a.scale, q.w *= a.scale;
+  // Per-key / per-distance additive terms are tabulated once per workgroup: inside the softmax loop every lane would
+  // otherwise issue one LUT load, one mask load and one bias read per score (96 dependent loads per lane).
+  for (int e = tid; e < 2 * LP; e += NTHR) {
+    float v = 0.f;
+    if (a.rel_bias) {
+      int n = e - (LP - 1), bucket = 0;
+      if (a.bidirectional) {
+        if (n < 0) {
+          bucket = a.num_buckets >> 1;
+          n = -n;
+        }
+      } else if (n < 0) {
+        n = 0;
+      }
+      bucket += a.lut.v[n < 127 ? n : 127];
+      v = a.rel_bias[bucket * a.H + h];
     }
+    RelB[e] = v;
+  }
+  for (int j = tid; j < LP; j += NTHR) {
+    float v = -INFINITY;
+    if (j < L) v = (a.key_mask && a.key_mask[(int64_t)b * a.mask_bstride + j] == 0) ? (a.causal_neg_inf ? -INFINITY : -1e9f) : 0.f;
+    Mk[j] = v;
+  }
+  for (int e = tid; e < L * (DK / 4); e += NTHR) {
+    const int r = e >> 4, c = e & 15;
+    float4 q = *reinterpret_cast<const float4*>(a.q + ((int64_t)b * a.q_bstride + r) * a.ldq + h * DK + 4 * c);
+    const float4 k = *reinterpret_cast<const float4*>(a.k + ((int64_t)b * a.k_bstride + r) * a.ldk + h * DK + 4 * c);
+    const float4 v = *reinterpret_cast<const float4*>(a.v + ((int64_t)b * a.k_bstride + r) * a.ldv + h * DK + 4 * c);
+    q.x *= a.scale, q.y *= a.scale, q.z *= a.scale, q.w *= a.scale;
     *reinterpret_cast<float4*>(Qs + r * DS + 4 * c) = q;
     *reinterpret_cast<float4*>(Ks + r * DS + 4 * c) = k;
     *reinterpret_cast<float4*>(Vs + r * DS + 4 * c) = v;
   }
-  if (a.rel_bias && tid < a.num_buckets) Bs[tid] = a.rel_bias[tid * a.H + h];
   __syncthreads();
 
   const int w = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -317,13 +341,13 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma_kernel(const AttnArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
   // ---- S^T tiles: A = K rows (keys), B = Q rows (queries); k index permuted inside chunks of 8 as in the GEMM core
-  const float* qrow = Qs + (32 * w + l31) * DS + 4 * hh;
+  const float* qrow = Qs + min(32 * w + l31, L - 1) * DS + 4 * hh;
 #pragma unroll
   for (int jj = 0; jj < DK / 8; ++jj) {
     const float4 qv = *reinterpret_cast<const float4*>(qrow + 8 * jj);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const float4 kv = *reinterpret_cast<const float4*>(Ks + (32 * t + l31) * DS + 4 * hh + 8 * jj);
+      const float4 kv = *reinterpret_cast<const float4*>(Ks + min(32 * t + l31, L - 1) * DS + 4 * hh + 8 * jj);
       st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qv.x, st[t], 0, 0, 0);
       st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qv.y, st[t], 0, 0, 0);
       st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qv.z, st[t], 0, 0, 0);
@@ -331,8 +355,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma_kernel(const AttnArgs 
     }
   }
   // ---- bias + mask + softmax over keys (this lane's query column)
-  const int i = 32 * w + l31, i_abs = a.q_pos0 + i;
-  const int half = a.num_buckets >> 1;
+  const int i = 32 * w + l31;  // relative distance n = (q_pos0 + i) - j; q_pos0 = 0 for full self-attention
   const float masked = a.causal_neg_inf ? -INFINITY : -1e9f;
   float mx = -INFINITY;
 #pragma unroll
@@ -340,28 +363,9 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma_kernel(const AttnArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      float s = -INFINITY;
-      if (j < L) {
-        float add = 0.f;
-        if (a.rel_bias) {
-          int n = i_abs - j, bucket = 0;
-          if (a.bidirectional) {
-            if (n < 0) {
-              bucket = half;
-              n = -n;
-            }
-          } else if (n < 0) {
-            n = 0;
-          }
-          bucket += a.lut.v[n < 127 ? n : 127];
-          add = Bs[bucket];
-        }
-        bool allowed = true;
-        if (a.causal) allowed = j <= i_abs;
-        if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)b * a.mask_bstride + j] != 0);
-        if (!allowed) add += masked;
-        s = st[t][r] + add;
-      }
+      float add = RelB[i - j + (LP - 1)] + Mk[j];          // (bias + mask) first, as the reference (modeling_t5.py:399-400)
+      if (a.causal && j > i && Mk[j] == 0.f) add += masked;  // one -1e9 per masked key, never two
+      const float s = st[t][r] + add;
       st[t][r] = s;
       mx = fmaxf(mx, s);
     }
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma_kernel(const AttnArgs 
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = expf(st[t][r] - mx);  // padded keys: exp(-inf) = 0
+      const float p = __expf(st[t][r] - mx);  // padded keys: exp(-inf) = 0
       st[t][r] = p;
       sum += p;
     }
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma_kernel(const AttnArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const float vv = Vs[j * DS + 32 * dt + l31];
+        const float vv = Vs[min(j, L - 1) * DS + 32 * dt + l31];
         o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[t][r], o, 0, 0, 0);
       }
     }
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma_kernel(const AttnArgs 
 
 template <int NT>
 static int launch_attention_mfma(const AttnArgs& a, hipStream_t stream) {
-  const size_t lds = sizeof(float) * ((size_t)3 * 32 * NT * 68 + 256);
+  const size_t lds = sizeof(float) * ((size_t)3 * a.Lk * 68 + 3 * 32 * NT);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<NT>),
@@ -518,7 +522,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     GDR_CHECK_LAUNCH("attention_decode_kernel");
     return GDR_OK;
   }
-  if (a.Lq == a.Lk && !a.kv_rows && a.kv_group == 1 && !a.q_same_pos && a.dk == 64 && a.ldo % 4 == 0) {
+  if (a.Lq == a.Lk && a.q_pos0 == 0 && !a.kv_rows && a.kv_group == 1 && !a.q_same_pos && a.dk == 64 && a.ldo % 4 == 0) {
     switch ((a.Lk + 31) / 32) {
       case 1: return launch_attention_mfma<1>(a, stream);
       case 2: return launch_attention_mfma<2>(a, stream);
