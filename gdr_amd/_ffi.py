@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgdr_hip.so")
 
 GDR_OK, GDR_EINVAL, GDR_ENOSPC, GDR_EHIP = 0, -1, -2, -3
 SIM_EXHAUSTIVE = 1
+SIM_NO_STREAM = 2
 EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL, EPI_BIAS_GELU = range(7)
 
 

@@ -64,4 +64,8 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
 int launch_sim_gemm(const void* D, int64_t N, const void* Q, int B, int d, const SimEpilogue& ep, bool bf16,
                     hipStream_t stream);
 
+// latency-mode similarity (B <= 32, fp32): stationary queries in LDS, corpus streamed from HBM (sim_stream.hip)
+bool sim_stream_supported(int B, int d, bool bf16);
+int launch_sim_stream(const float* D, int64_t N, const float* Q, int B, int d, const SimEpilogue& ep, hipStream_t stream);
+
 }  // namespace gdr

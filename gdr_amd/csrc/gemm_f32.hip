@@ -302,28 +302,37 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
           }
         }
       } else {
+        // one counter reservation per query and wave tile: survivors are flagged first, the two lane halves that
+        // share a query pool their counts, and a single returning atomic replaces up to 32 serial round trips
         const float thr = g.sim.thr[n];
+        unsigned keep[2] = {0u, 0u};
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          float mx = acc[mi][ni][0];
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[mi][ni][r]);
-          if (mx >= thr) {
+          for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            keep[mi] |= (acc[mi][ni][r] >= thr && m < g.M) ? (1u << r) : 0u;
+          }
+        const int mine = __popc(keep[0]) + __popc(keep[1]);
+        const int other = __shfl_xor(mine, 32);
+        int base = 0;
+        if (h == 0 && mine + other > 0) base = atomicAdd(g.sim.cand_cnt + n, mine + other);
+        base = __shfl(base, l31);
+        int pos = base + (h ? other : 0);
+        if (mine) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float v = acc[mi][ni][r];
-              const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-              if (v >= thr && m < g.M) {
-                const int pos = atomicAdd(g.sim.cand_cnt + n, 1);
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (keep[mi] >> r & 1u) {
                 if (pos < g.sim.cap) {
-                  cv[pos] = v;
-                  ci[pos] = (int)m;
+                  cv[pos] = acc[mi][ni][r];
+                  ci[pos] = (int)(m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
                 } else if (g.sim.status) {
                   *g.sim.status = 1;
                 }
+                ++pos;
               }
-            }
-          }
         }
       }
     }

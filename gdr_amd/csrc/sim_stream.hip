@@ -1,0 +1,177 @@
+// Latency-mode similarity (B <= 32 queries, fp32): the HBM-bound regime of SURVEY §8d / the north-star's "coalesced
+// HBM reads".  At B <= 40 the contraction Q·Dᵀ has intensity 2B/4 flop per corpus byte, below the fp32-MFMA ridge, so
+// the corpus stream is the roof — and the general 128x128-tile GEMM core wastes 3/4 of its MFMA work on absent queries.
+//
+// Shape: the queries are STATIONARY — Q (<= 32 x d fp32, <= 128 KB) is loaded once per workgroup into LDS — and every
+// wave streams its own 32-doc slices of the corpus straight from HBM into MFMA A-operand registers: no LDS round trip
+// for the streamed operand, no workgroup barrier after the prologue (waves are independent), a 4-deep register
+// prefetch ring (4 x 64 B per lane in flight) to cover HBM latency.  One persistent workgroup of 8 waves per CU.
+//   per 32-k group and wave: 4 global_load_dwordx4 (each lane: 64 contiguous bytes of its doc row; the two lane
+//   halves cover one 128-B line) + 4 ds_read_b128 of the Q fragments (row stride d+4 floats: conflict-free) +
+//   16 v_mfma_f32_32x32x2_f32; the k index inside a group is permuted identically on both operands.
+// Epilogues are those of the GEMM core: store the strided sample / compare with thr[q] and append survivors.
+#include "common.h"
+
+namespace gdr {
+
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+
+struct StreamArgs {
+  const float* D;
+  const float* Q;
+  int64_t N;
+  int B, d;
+  int64_t n_tiles;   // 128-doc tiles of this launch
+  SimEpilogue sim;
+};
+
+template <int MODE>  // 1 sample, 2 filter
+__global__ __launch_bounds__(512, 2) void sim_stream_f32_kernel(const StreamArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float qs[];  // [32][d + 4]
+  const int d = g.d, QS = d + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  for (int e = tid; e < 32 * (d >> 2); e += 512) {
+    const int r = e / (d >> 2), c = e - r * (d >> 2);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < g.B) v = *reinterpret_cast<const float4*>(g.Q + (int64_t)r * d + 4 * c);
+    *reinterpret_cast<float4*>(qs + r * QS + 4 * c) = v;
+  }
+  __syncthreads();
+  const float* qrow = qs + l31 * QS + 16 * h;
+  const int G = d >> 5;  // 32-k groups, multiple of 4
+  const float thr = (MODE == 2 && l31 < g.B) ? g.sim.thr[l31] : 0.f;
+  float* cv = g.sim.cand_val + (int64_t)l31 * g.sim.cap;
+  int32_t* ci = g.sim.cand_idx + (int64_t)l31 * g.sim.cap;
+
+  const int64_t n_units = g.n_tiles * 4;  // 32-doc slices
+  for (int64_t u = (int64_t)blockIdx.x * 8 + wave; u < n_units; u += (int64_t)gridDim.x * 8) {
+    int64_t t = u >> 2;
+    const int sub = (int)(u & 3);
+    int64_t slot_base = 0;
+    if (MODE == 1) {
+      slot_base = t * 128;
+      t = t * g.sim.tile_stride;
+    } else {
+      const int s1 = g.sim.tile_stride - 1;
+      t = (t / s1) * g.sim.tile_stride + 1 + (t % s1);
+    }
+    const int64_t m0 = t * 128 + sub * 32;
+    int64_t row = m0 + l31;
+    row = row < g.N ? row : g.N - 1;
+    const float* drow = g.D + row * d + 16 * h;
+
+    f32x16s acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 a0[4], a1[4], a2[4], a3[4];
+#define LOADG(A, grp)                                                         \
+  A[0] = *reinterpret_cast<const float4*>(drow + 32 * (grp));                 \
+  A[1] = *reinterpret_cast<const float4*>(drow + 32 * (grp) + 4);             \
+  A[2] = *reinterpret_cast<const float4*>(drow + 32 * (grp) + 8);             \
+  A[3] = *reinterpret_cast<const float4*>(drow + 32 * (grp) + 12);
+#define MFMA4(av, bv)                                                  \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0); \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0); \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0); \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+#define COMPUTE(A, grp)                                                                  \
+  {                                                                                      \
+    const float4 b0 = *reinterpret_cast<const float4*>(qrow + 32 * (grp));               \
+    const float4 b1 = *reinterpret_cast<const float4*>(qrow + 32 * (grp) + 4);           \
+    const float4 b2 = *reinterpret_cast<const float4*>(qrow + 32 * (grp) + 8);           \
+    const float4 b3 = *reinterpret_cast<const float4*>(qrow + 32 * (grp) + 12);          \
+    MFMA4(A[0], b0) MFMA4(A[1], b1) MFMA4(A[2], b2) MFMA4(A[3], b3)                      \
+  }
+    LOADG(a0, 0) LOADG(a1, 1) LOADG(a2, 2)
+    for (int gq = 0; gq < G; gq += 4) {  // ring of 4 register sets, 3 groups in flight ahead of the one consumed
+      LOADG(a3, gq + 3)
+      COMPUTE(a0, gq)
+      if (gq + 4 < G) { LOADG(a0, gq + 4) }
+      COMPUTE(a1, gq + 1)
+      if (gq + 5 < G) { LOADG(a1, gq + 5) }
+      COMPUTE(a2, gq + 2)
+      if (gq + 6 < G) { LOADG(a2, gq + 6) }
+      COMPUTE(a3, gq + 3)
+    }
+#undef LOADG
+#undef MFMA4
+#undef COMPUTE
+    // accumulator map: col (query) = l31, row (doc in slice) = (r&3) + 8*(r>>2) + 4*h
+    if (l31 < g.B) {
+      if (MODE == 1) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int roff = sub * 32 + 8 * q4 + 4 * h;
+          const int64_t m = m0 + 8 * q4 + 4 * h;
+          float4 v;
+          int4 id;
+          v.x = m + 0 < g.N ? acc[4 * q4 + 0] : -INFINITY, v.y = m + 1 < g.N ? acc[4 * q4 + 1] : -INFINITY;
+          v.z = m + 2 < g.N ? acc[4 * q4 + 2] : -INFINITY, v.w = m + 3 < g.N ? acc[4 * q4 + 3] : -INFINITY;
+          id.x = m + 0 < g.N ? (int)m : -1, id.y = m + 1 < g.N ? (int)m + 1 : -1;
+          id.z = m + 2 < g.N ? (int)m + 2 : -1, id.w = m + 3 < g.N ? (int)m + 3 : -1;
+          *reinterpret_cast<float4*>(cv + slot_base + roff) = v;
+          *reinterpret_cast<int4*>(ci + slot_base + roff) = id;
+        }
+      } else {
+        unsigned keep = 0u;  // flag survivors, pool the two lane halves of a query, reserve with ONE returning atomic
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          keep |= (acc[r] >= thr && m < g.N) ? (1u << r) : 0u;
+        }
+        const int mine = __popc(keep);
+        const int other = __shfl_xor(mine, 32);
+        int base = 0;
+        if (h == 0 && mine + other > 0) base = atomicAdd(g.sim.cand_cnt + l31, mine + other);
+        base = __shfl(base, l31);
+        int pos = base + (h ? other : 0);
+        if (mine) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (keep >> r & 1u) {
+              if (pos < g.sim.cap) {
+                cv[pos] = acc[r];
+                ci[pos] = (int)(m0 + (r & 3) + 8 * (r >> 2) + 4 * h);
+              }
+              ++pos;
+            }
+        }
+      }
+    }
+  }
+}
+
+bool sim_stream_supported(int B, int d, bool bf16) { return !bf16 && B <= 32 && d % 128 == 0 && d <= 1024; }
+
+int launch_sim_stream(const float* D, int64_t N, const float* Q, int B, int d, const SimEpilogue& ep, hipStream_t stream) {
+  StreamArgs g{};
+  g.D = D, g.Q = Q, g.N = N, g.B = B, g.d = d, g.sim = ep;
+  const int64_t tiles_m = (N + 127) / 128;
+  const int64_t n_sample_tiles = (tiles_m + ep.tile_stride - 1) / ep.tile_stride;
+  g.n_tiles = ep.mode == 1 ? n_sample_tiles : tiles_m - n_sample_tiles;
+  if (g.n_tiles <= 0) return GDR_OK;
+  const size_t lds = (size_t)32 * (d + 4) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sim_stream_f32_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(sim_stream_f32_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      set_error("sim_stream: hipFuncSetAttribute failed");
+      return GDR_EHIP;
+    }
+    attr_set = true;
+  }
+  int64_t blocks = (g.n_tiles * 4 + 7) / 8;
+  if (blocks > 256) blocks = 256;  // persistent: one workgroup per CU
+  const double rows = (double)(g.n_tiles * 128 < N ? g.n_tiles * 128 : N);
+  ProfScope prof(ep.mode == 1 ? PROF_SIM_SAMPLE : PROF_SIM_FILTER, 2.0 * rows * B * d, stream);
+  if (ep.mode == 1)
+    hipLaunchKernelGGL(sim_stream_f32_kernel<1>, dim3((unsigned)blocks), dim3(512), lds, stream, g);
+  else
+    hipLaunchKernelGGL(sim_stream_f32_kernel<2>, dim3((unsigned)blocks), dim3(512), lds, stream, g);
+  GDR_CHECK_LAUNCH("sim_stream_f32_kernel");
+  return GDR_OK;
+}
+
+}  // namespace gdr

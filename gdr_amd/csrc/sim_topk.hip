@@ -74,48 +74,86 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
 }
 
 // Given hist[256] (LDS) find the highest bin b with  sum(hist[b..255]) >= need.
-// Returns b and the count strictly above it through *above.  All 256 threads call it.
-__device__ __forceinline__ int find_bin(int* hist, int* scan, int need, int* above, int* res) {
+// Returns b and the count strictly above it through *above.  Every thread of the block calls it (blockDim >= 256).
+// `need` is clamped to the number of keys counted (a merge input may hold fewer than k live entries).
+__device__ __forceinline__ int find_bin(int* hist, int* scan, int& need, int* above, int* res) {
   const int t = threadIdx.x;
-  scan[t] = hist[t];
+  const bool on = t < 256;
+  if (on) scan[t] = hist[t];
+  if (t == 0) res[0] = 0, res[1] = 0;
   __syncthreads();
 #pragma unroll
   for (int off = 1; off < 256; off <<= 1) {
-    const int v = (t + off < 256) ? scan[t + off] : 0;
+    const int v = (on && t + off < 256) ? scan[t + off] : 0;
     __syncthreads();
-    scan[t] += v;
+    if (on) scan[t] += v;
     __syncthreads();
   }
-  const int mine = scan[t];
-  const int next = (t + 1 < 256) ? scan[t + 1] : 0;
-  if (mine >= need && next < need) {
-    res[0] = t;
-    res[1] = next;
+  if (scan[0] < need) need = scan[0];
+  if (on && need > 0) {
+    const int mine = scan[t];
+    const int next = (t + 1 < 256) ? scan[t + 1] : 0;
+    if (mine >= need && next < need) {
+      res[0] = t;
+      res[1] = next;
+    }
   }
   __syncthreads();
   *above = res[1];
   return res[0];
 }
 
+// Block-wide min / max of 32-bit keys (red[] holds 2 * 16 words).  Result broadcast to every thread.
+__device__ __forceinline__ void block_minmax(uint32_t& lo, uint32_t& hi, uint32_t* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+  }
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[w] = lo, red[16 + w] = hi;
+  __syncthreads();
+  lo = red[0], hi = red[16];
+  for (int i = 1; i < nw; ++i) lo = min(lo, red[i]), hi = max(hi, red[16 + i]);
+  __syncthreads();
+}
+
+// The radix passes below work on RANGE-NORMALISED keys: (key - lo) left-aligned so that the first 8-bit digit already
+// spreads the live range over 256 bins.  Similarity scores share sign and exponent, so digits taken from the raw
+// float bits spend two full sweeps (and ~10^4 same-address LDS atomics each) without separating anything.
+
 // ---- step 2: per-query threshold = k-th largest of the sample scores ----------------------------
-__global__ __launch_bounds__(SEL_THREADS) void sim_threshold_kernel(const float* __restrict__ cand_val, int64_t cap,
-                                                                    int n_slots, int k, float* thr,
-                                                                    int32_t* cand_cnt) {
+__global__ __launch_bounds__(1024) void sim_threshold_kernel(const float* __restrict__ cand_val, int64_t cap,
+                                                             int n_slots, int k, float* thr, int32_t* cand_cnt) {
   __shared__ int hist[256];
   __shared__ int scan[256];
   __shared__ int res[2];
+  __shared__ uint32_t red[32];
   const int q = blockIdx.x;
   const float* v = cand_val + (int64_t)q * cap;
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;  // range of the real scores; -inf padding slots of a ragged tile stay below it
+  for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
+    const float x = v[i];
+    if (x > -INFINITY) {
+      const uint32_t key = fkey(x);
+      lo = min(lo, key), hi = max(hi, key);
+    }
+  }
+  block_minmax(lo, hi, red);
+  if (hi < lo) lo = hi = fkey(-INFINITY);  // nothing but padding
+  const int nbits = hi > lo ? 32 - __clz(hi - lo) : 0;
+  const int lsh = 32 - nbits;  // nbits == 0: every key equal, no pass runs
   uint32_t prefix = 0;
   int need = k;
-  for (int pass = 0; pass < 4; ++pass) {
+  for (int pass = 0; 8 * pass < nbits; ++pass) {
     const int shift = 24 - 8 * pass;
-    hist[threadIdx.x] = 0;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n_slots; i += SEL_THREADS) {
-      const uint32_t key = fkey(v[i]);
+    for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
+      const uint32_t raw = fkey(v[i]);
+      const uint32_t key = (raw - lo) << lsh;
       const bool match = pass == 0 ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-      if (match) atomicAdd(&hist[(key >> shift) & 255u], 1);
+      if (match && raw >= lo) atomicAdd(&hist[(key >> shift) & 255u], 1);
     }
     __syncthreads();
     int above;
@@ -125,24 +163,26 @@ __global__ __launch_bounds__(SEL_THREADS) void sim_threshold_kernel(const float*
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    thr[q] = fkey_inv(prefix);
+    thr[q] = fkey_inv(nbits ? (prefix >> lsh) + lo : lo);
     cand_cnt[q] = n_slots;  // survivors of the filter pass are appended behind the sample block
   }
 }
 
 // ---- step 4 / merge: exact top-k of a candidate list, sorted ------------------------------------
-// MERGE = false: entries cand_val/cand_idx[q*cap + i], i < min(cnt[q], cap)
+// MERGE = false: entries cand_val/cand_idx[q*cap + i], i < min(cnt[q], cap); thr[q] (the k-th largest sample score,
+//                at least k entries reach it) bounds the live range from below
 // MERGE = true : entries vals/idx[(g*B + q)*k + j], i = g*k + j < G*k
 template <bool MERGE>
-__global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const float* __restrict__ vals,
-                                                                  const int32_t* __restrict__ idxs,
-                                                                  const int32_t* __restrict__ cnt, int64_t cap, int G,
-                                                                  int B, int k, int kpad, int32_t idx_offset,
-                                                                  float* out_val, int32_t* out_idx,
-                                                                  int32_t* __restrict__ status) {
+__global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restrict__ vals,
+                                                           const int32_t* __restrict__ idxs,
+                                                           const int32_t* __restrict__ cnt, int64_t cap, int G, int B,
+                                                           int k, int kpad, int32_t idx_offset,
+                                                           const float* __restrict__ thr, float* out_val,
+                                                           int32_t* out_idx, int32_t* __restrict__ status) {
   __shared__ int hist[256];
   __shared__ int scan[256];
   __shared__ int res[2];
+  __shared__ uint32_t red[32];
   __shared__ int n_out;
   extern __shared__ __attribute__((aligned(16))) unsigned long long sortbuf[];  // kpad entries
   const int q = blockIdx.x;
@@ -154,69 +194,91 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const float* _
     count = c < (int)cap ? c : (int)cap;
     if (status && threadIdx.x == 0) status[q] = c > (int)cap ? 1 : 0;  // list overflowed: result is a subset's top-k
   }
-  auto key_at = [&](int i) -> unsigned long long {
-    int64_t a;
+  auto addr_of = [&](int i) -> int64_t {
     if (MERGE) {
       const int g = i / k, j = i - g * k;
-      a = ((int64_t)g * B + q) * k + j;
-    } else {
-      a = (int64_t)q * cap + i;
+      return ((int64_t)g * B + q) * k + j;
     }
-    const int32_t id = idxs[a];
-    if (id < 0) return 0ull;  // padding entry
-    return ((unsigned long long)fkey(vals[a]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+    return (int64_t)q * cap + i;
   };
-
+  // sweep 0: live range of the score keys
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    const int64_t a = addr_of(i);
+    if (idxs[a] >= 0) {
+      const uint32_t key = fkey(vals[a]);
+      lo = min(lo, key), hi = max(hi, key);
+    }
+  }
+  block_minmax(lo, hi, red);
+  if (!MERGE && thr) lo = max(lo, fkey(thr[q]));
+  if (hi < lo) hi = lo;  // no valid entry at all
+  const int nbits = hi > lo ? 32 - __clz(hi - lo) : 0;
+  const int lsh = 32 - nbits;
+  // normalised 64-bit key: (score key - lo) : nbits | ~id : 32, left-aligned; 0 = padding / below the live range
+  auto key_at = [&](int i, unsigned long long* raw) -> unsigned long long {
+    const int64_t a = addr_of(i);
+    const int32_t id = idxs[a];
+    if (id < 0) return 0ull;
+    const uint32_t sk = fkey(vals[a]);
+    if (sk < lo) return 0ull;
+    const unsigned long long idpart = (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+    if (raw) *raw = ((unsigned long long)sk << 32) | idpart;
+    return ((((unsigned long long)(sk - lo)) << 32) | idpart) << lsh;
+  };
+  // number of entries in the live range bounds `need` (a merge input may hold fewer than k valid entries)
   unsigned long long prefix = 0ull;
   int need = k < count ? k : count;
-  const int want = need;
+  int want = need;
   bool exact = false;
   for (int pass = 0; pass < 8 && !exact; ++pass) {
     const int shift = 56 - 8 * pass;
-    hist[threadIdx.x] = 0;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < count; i += SEL_THREADS) {
-      const unsigned long long key = key_at(i);
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+      const unsigned long long key = key_at(i, nullptr);
       const bool match = pass == 0 ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-      if (match) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+      if (match && key != 0ull) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
     }
     __syncthreads();
     int above;
     const int b = find_bin(hist, scan, need, &above, res);
+    if (pass == 0) want = need;  // clamped to the live entries
     need -= above;
     prefix |= (unsigned long long)b << shift;
     exact = hist[b] == need;  // the whole bin is taken: the low bits need no refinement
     __syncthreads();
   }
-  // gather the `want` keys >= prefix
+  // gather the `want` keys >= prefix (raw keys: the sort below needs no range)
   if (threadIdx.x == 0) n_out = 0;
-  for (int i = threadIdx.x; i < kpad; i += SEL_THREADS) sortbuf[i] = 0ull;
+  for (int i = threadIdx.x; i < kpad; i += blockDim.x) sortbuf[i] = 0ull;
   __syncthreads();
-  for (int i = threadIdx.x; i < count; i += SEL_THREADS) {
-    const unsigned long long key = key_at(i);
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    unsigned long long raw = 0ull;
+    const unsigned long long key = key_at(i, &raw);
     if (key >= prefix && key != 0ull) {
       const int p = atomicAdd(&n_out, 1);
-      if (p < kpad) sortbuf[p] = key;
+      if (p < kpad) sortbuf[p] = raw;
     }
   }
   __syncthreads();
   // bitonic sort, descending
   for (int size = 2; size <= kpad; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < (kpad >> 1); t += SEL_THREADS) {
-        const int lo = (t / stride) * (stride << 1) + (t % stride);
-        const int hi = lo + stride;
-        const bool desc = ((lo & size) == 0);
-        const unsigned long long a = sortbuf[lo], b = sortbuf[hi];
+      for (int t = threadIdx.x; t < (kpad >> 1); t += blockDim.x) {
+        const int lo_i = (t / stride) * (stride << 1) + (t % stride);
+        const int hi_i = lo_i + stride;
+        const bool desc = ((lo_i & size) == 0);
+        const unsigned long long a = sortbuf[lo_i], b = sortbuf[hi_i];
         if ((a < b) == desc) {
-          sortbuf[lo] = b;
-          sortbuf[hi] = a;
+          sortbuf[lo_i] = b;
+          sortbuf[hi_i] = a;
         }
       }
       __syncthreads();
     }
   }
-  for (int i = threadIdx.x; i < k; i += SEL_THREADS) {
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {
     const unsigned long long key = sortbuf[i];
     float v = -INFINITY;
     int32_t id = -1;
@@ -314,19 +376,24 @@ int gdr::sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, in
   ep.cap = (int32_t)p.cap;
   ep.tile_stride = p.stride;
   ep.mode = 1;
-  int rc = launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
+  const bool stream_mode = sim_stream_supported(B, d, bf16) && !(flags & GDR_SIM_NO_STREAM);
+  int rc = stream_mode ? launch_sim_stream(static_cast<const float*>(D), N, static_cast<const float*>(Q), B, d, ep, stream)
+                       : launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(sim_threshold_kernel, dim3(B), dim3(SEL_THREADS), 0, stream, ep.cand_val, p.cap, (int)p.n_slots,
+  const int sel_threads = B <= 128 ? 1024 : SEL_THREADS;  // few queries: spend the idle CUs' worth of lanes per query
+  hipLaunchKernelGGL(sim_threshold_kernel, dim3(B), dim3(sel_threads), 0, stream, ep.cand_val, p.cap, (int)p.n_slots,
                      k, thr, ep.cand_cnt);
   GDR_CHECK_LAUNCH("sim_threshold_kernel");
   if (p.stride > 1) {
     ep.mode = 2;
-    rc = launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
+    rc = stream_mode ? launch_sim_stream(static_cast<const float*>(D), N, static_cast<const float*>(Q), B, d, ep, stream)
+                     : launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
     if (rc) return rc;
   }
   const int kpad = next_pow2(k);
-  hipLaunchKernelGGL(topk_select_kernel<false>, dim3(B), dim3(SEL_THREADS), kpad * sizeof(unsigned long long), stream,
-                     ep.cand_val, ep.cand_idx, ep.cand_cnt, p.cap, 1, B, k, kpad, idx_offset, out_val, out_idx, status);
+  hipLaunchKernelGGL(topk_select_kernel<false>, dim3(B), dim3(sel_threads), kpad * sizeof(unsigned long long), stream,
+                     ep.cand_val, ep.cand_idx, ep.cand_cnt, p.cap, 1, B, k, kpad, idx_offset, (const float*)thr, out_val,
+                     out_idx, status);
   GDR_CHECK_LAUNCH("topk_select_kernel");
   return GDR_OK;
 }
@@ -339,7 +406,8 @@ extern "C" int gdr_topk_merge(const float* vals, const int32_t* idx, int G, int 
   GDR_CHECK_ARG(G > 0 && B > 0 && k >= 1 && k <= 1024, "topk_merge: bad shape G=%d B=%d k=%d", G, B, k);
   const int kpad = next_pow2(k);
   hipLaunchKernelGGL(topk_select_kernel<true>, dim3(B), dim3(SEL_THREADS), kpad * sizeof(unsigned long long), stream,
-                     vals, idx, (const int32_t*)nullptr, (int64_t)0, G, B, k, kpad, 0, out_val, out_idx, (int32_t*)nullptr);
+                     vals, idx, (const int32_t*)nullptr, (int64_t)0, G, B, k, kpad, 0, (const float*)nullptr, out_val, out_idx,
+                     (int32_t*)nullptr);
   GDR_CHECK_LAUNCH("topk_select_kernel<merge>");
   return GDR_OK;
 }

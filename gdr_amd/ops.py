@@ -80,11 +80,11 @@ def _sim_topk_raw(Q, D, k, idx_offset, workspace, flags):
     return vals, idx, status
 
 
-def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_on_overflow=False):
+def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_on_overflow=False, flags=0):
     """Fused Q·Dᵀ + per-row top-k — gdr_sim_topk.  Returns (values fp32[B,k], indices int32[B,k]).
     exact_on_overflow=True reads the per-query status back (one host sync) and recomputes any query whose candidate
     list overflowed (degenerate corpora with tens of thousands of tied docs) exhaustively, so the result is exact for
-    every input; return_status=True hands the device status tensor to the caller instead."""
+    every input; return_status=True hands the device status tensor to the caller instead.  flags: _ffi.SIM_* bits."""
     _need_cuda(Q, D)
     if D.dtype == torch.bfloat16:                                    # bf16 corpus: queries are cast on the device
         Q = (Q if Q.dtype == torch.bfloat16 else to_bf16(Q)).contiguous()
@@ -95,7 +95,7 @@ def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_o
         raise _ffi.GdrError(f"sim_topk: dim mismatch {Q.shape} vs {D.shape}")
     if k > D.shape[0]:
         raise RuntimeError("selected index k out of range")          # torch.topk's message
-    vals, idx, status = _sim_topk_raw(Q, D, k, idx_offset, workspace, 0)
+    vals, idx, status = _sim_topk_raw(Q, D, k, idx_offset, workspace, flags)
     if exact_on_overflow:
         bad = torch.nonzero(status).flatten()
         if bad.numel():

@@ -120,6 +120,7 @@ int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_t* ids, con
  * d % 4 == 0, 1 <= k <= 1024, k <= N.
  * ---------------------------------------------------------------------------------------------- */
 #define GDR_SIM_EXHAUSTIVE 1
+#define GDR_SIM_NO_STREAM 2   /* force the tiled GEMM core even at B <= 32 (A/B testing of the latency-mode kernel) */
 size_t gdr_sim_topk_workspace_bytes(int B, int64_t N, int d, int k, int flags);
 int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, int d, int k, int32_t idx_offset,
                  float* out_val, int32_t* out_idx, int32_t* status, int flags, void* workspace,

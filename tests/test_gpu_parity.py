@@ -169,6 +169,26 @@ def test_sim_topk_vs_oracle(dev, B, N, d, k):
     assert (np.diff(v.cpu().numpy(), axis=1) <= 0).all(), "values must be sorted descending"
 
 
+@pytest.mark.parametrize("B,N,d,k", [(1, 50000, 768, 100), (32, 70001, 128, 37), (17, 40000, 256, 10), (8, 1000, 128, 1000)])
+def test_sim_topk_latency_mode_stream_kernel(dev, B, N, d, k):
+    """B <= 32 with d % 128 == 0 takes the stationary-query / streamed-corpus kernel (sim_stream.hip): same results as
+    the oracle and as the tiled GEMM core forced with SIM_NO_STREAM."""
+    from gdr_amd import ops, _ffi
+    from oracle import retrieval_ref
+    D = synth.make_corpus(N, d, seed=N + d)
+    Q, _ = synth.make_queries(D, B, seed=B)
+    rv, ri = retrieval_ref.sim_topk(torch.from_numpy(Q), torch.from_numpy(D), k)
+    Qd, Dd = torch.from_numpy(Q).to(dev), torch.from_numpy(D).to(dev)
+    v, i, st = ops.sim_topk(Qd, Dd, k, return_status=True)
+    assert int(st.sum().item()) == 0
+    order_insensitive_topk_match(rv.numpy(), ri.numpy(), v.cpu().numpy(), i.cpu().numpy().astype(np.int64), TOL)
+    v2, i2 = ops.sim_topk(Qd, Dd, k, flags=_ffi.SIM_NO_STREAM)
+    order_insensitive_topk_match(v2.cpu().numpy(), i2.cpu().numpy().astype(np.int64), v.cpu().numpy(),
+                                 i.cpu().numpy().astype(np.int64), TOL)
+    ve, ie = ops.sim_topk(Qd, Dd, k, flags=_ffi.SIM_EXHAUSTIVE)
+    order_insensitive_topk_match(rv.numpy(), ri.numpy(), ve.cpu().numpy(), ie.cpu().numpy().astype(np.int64), TOL)
+
+
 @pytest.mark.parametrize("B,N,d,k", [(5, 3000, 64, 7), (96, 40000, 768, 100), (33, 70001, 128, 10)])
 def test_sim_topk_bf16_vs_oracle_on_rounded_inputs(dev, B, N, d, k):
     """bf16 corpus path (config C5): equals the fp32 oracle applied to the bf16-rounded inputs (products of bf16 values

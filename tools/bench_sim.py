@@ -12,15 +12,18 @@ N, d, k = int(os.environ.get("N", 320000)), 768, 100
 D = torch.from_numpy(synth.make_corpus(N, d)).to(dev)
 Db = ops.to_bf16(D)
 out = []
-for B in (32, 128, 512, 4096):
+for B in (1, 8, 32, 128, 512, 4096):
     Qn, _ = synth.make_queries(D[:50000].cpu().numpy(), B)
     Q = torch.from_numpy(Qn).to(dev)
-    for name, Dm, peak in (("f32", D, 157.3), ("bf16", Db, 2500.0)):
+    variants = [("f32", D, 157.3, 0), ("bf16", Db, 2500.0, 0)]
+    if B <= 32:
+        variants.insert(1, ("f32-tiled", D, 157.3, 2))            # SIM_NO_STREAM: A/B of the latency-mode kernel
+    for name, Dm, peak, fl in variants:
         ws = ops.Workspace(dev)
-        for _ in range(3): ops.sim_topk(Q, Dm, k, workspace=ws)
+        for _ in range(3): ops.sim_topk(Q, Dm, k, workspace=ws, flags=fl)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         n = 10
-        for _ in range(n): ops.sim_topk(Q, Dm, k, workspace=ws)
+        for _ in range(n): ops.sim_topk(Q, Dm, k, workspace=ws, flags=fl)
         torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / n * 1e3
         tf = 2.0 * B * N * d / (ms * 1e-3) / 1e12
         gbs = N * d * Dm.element_size() / (ms * 1e-3) / 1e9
