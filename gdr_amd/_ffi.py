@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgdr_hip.so")
+LIB_PATH = os.environ.get("GDR_HIP_LIB") or os.path.join(_HERE, "libgdr_hip.so")   # override: A/B builds in the lab
 
 GDR_OK, GDR_EINVAL, GDR_ENOSPC, GDR_EHIP = 0, -1, -2, -3
 SIM_EXHAUSTIVE = 1

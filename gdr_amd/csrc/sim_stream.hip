@@ -25,12 +25,17 @@ struct StreamArgs {
   SimEpilogue sim;
 };
 
+#ifndef STREAM_THREADS
+#define STREAM_THREADS 512
+#endif
+constexpr int STREAM_WAVES = STREAM_THREADS / 64;
+
 template <int MODE>  // 1 sample, 2 filter
-__global__ __launch_bounds__(512, 2) void sim_stream_f32_kernel(const StreamArgs g) {
+__global__ __launch_bounds__(STREAM_THREADS) void sim_stream_f32_kernel(const StreamArgs g) {
   extern __shared__ __attribute__((aligned(16))) float qs[];  // [32][d + 4]
   const int d = g.d, QS = d + 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  for (int e = tid; e < 32 * (d >> 2); e += 512) {
+  for (int e = tid; e < 32 * (d >> 2); e += STREAM_THREADS) {
     const int r = e / (d >> 2), c = e - r * (d >> 2);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < g.B) v = *reinterpret_cast<const float4*>(g.Q + (int64_t)r * d + 4 * c);
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(512, 2) void sim_stream_f32_kernel(const StreamArgs
   int32_t* ci = g.sim.cand_idx + (int64_t)l31 * g.sim.cap;
 
   const int64_t n_units = g.n_tiles * 4;  // 32-doc slices
-  for (int64_t u = (int64_t)blockIdx.x * 8 + wave; u < n_units; u += (int64_t)gridDim.x * 8) {
+  for (int64_t u = (int64_t)blockIdx.x * STREAM_WAVES + wave; u < n_units; u += (int64_t)gridDim.x * STREAM_WAVES) {
     int64_t t = u >> 2;
     const int sub = (int)(u & 3);
     int64_t slot_base = 0;
@@ -68,7 +73,8 @@ __global__ __launch_bounds__(512, 2) void sim_stream_f32_kernel(const StreamArgs
   A[0] = *reinterpret_cast<const float4*>(drow + 32 * (grp));                 \
   A[1] = *reinterpret_cast<const float4*>(drow + 32 * (grp) + 4);             \
   A[2] = *reinterpret_cast<const float4*>(drow + 32 * (grp) + 8);             \
-  A[3] = *reinterpret_cast<const float4*>(drow + 32 * (grp) + 12);
+  A[3] = *reinterpret_cast<const float4*>(drow + 32 * (grp) + 12); \
+  asm volatile("" ::: "memory"); /* pin the issue point: the optimiser otherwise sinks the prefetch to its use */
 #define MFMA4(av, bv)                                                  \
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0); \
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0); \
@@ -83,16 +89,22 @@ __global__ __launch_bounds__(512, 2) void sim_stream_f32_kernel(const StreamArgs
     MFMA4(A[0], b0) MFMA4(A[1], b1) MFMA4(A[2], b2) MFMA4(A[3], b3)                      \
   }
     LOADG(a0, 0) LOADG(a1, 1) LOADG(a2, 2)
-    for (int gq = 0; gq < G; gq += 4) {  // ring of 4 register sets, 3 groups in flight ahead of the one consumed
-      LOADG(a3, gq + 3)
+    int gq = 0;
+    for (; gq + 8 <= G; gq += 4) {  // ring of 4 register sets, 3 groups in flight ahead of the one consumed;
+      LOADG(a3, gq + 3)             // branch-free body so the compiler keeps counted vmcnt waits
       COMPUTE(a0, gq)
-      if (gq + 4 < G) { LOADG(a0, gq + 4) }
+      LOADG(a0, gq + 4)
       COMPUTE(a1, gq + 1)
-      if (gq + 5 < G) { LOADG(a1, gq + 5) }
+      LOADG(a1, gq + 5)
       COMPUTE(a2, gq + 2)
-      if (gq + 6 < G) { LOADG(a2, gq + 6) }
+      LOADG(a2, gq + 6)
       COMPUTE(a3, gq + 3)
     }
+    LOADG(a3, gq + 3)
+    COMPUTE(a0, gq)
+    COMPUTE(a1, gq + 1)
+    COMPUTE(a2, gq + 2)
+    COMPUTE(a3, gq + 3)
 #undef LOADG
 #undef MFMA4
 #undef COMPUTE
@@ -141,6 +153,74 @@ __global__ __launch_bounds__(512, 2) void sim_stream_f32_kernel(const StreamArgs
   }
 }
 
+// Sample pass when it holds only a few hundred 32-doc slices (sqrt(kN) docs): one slice per WORKGROUP, the K range
+// dealt round-robin to the 8 waves (every load of a slice in flight at once instead of a 24-group dependent chain per
+// wave), partial accumulators summed through LDS in fixed wave order.
+__global__ __launch_bounds__(STREAM_THREADS) void sim_stream_sample_splitk_kernel(const StreamArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float qs[];  // [32][d + 4] then red[STREAM_WAVES][16][64]
+  const int d = g.d, QS = d + 4;
+  float* red = qs + 32 * QS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int64_t u = blockIdx.x;
+  const int64_t t = (u >> 2) * g.sim.tile_stride;
+  const int sub = (int)(u & 3);
+  const int64_t slot_base = (u >> 2) * 128;
+  const int64_t m0 = t * 128 + sub * 32;
+  int64_t row = m0 + l31;
+  row = row < g.N ? row : g.N - 1;
+  const float* drow = g.D + row * d + 16 * h;
+  const int G = d >> 5;
+  float4 a[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int grp = wave + STREAM_WAVES * i;
+    const float* src = drow + 32 * (grp < G ? grp : 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[i][j] = *reinterpret_cast<const float4*>(src + 4 * j);
+  }
+  for (int e = tid; e < 32 * (d >> 2); e += STREAM_THREADS) {
+    const int r = e / (d >> 2), c = e - r * (d >> 2);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < g.B) v = *reinterpret_cast<const float4*>(g.Q + (int64_t)r * d + 4 * c);
+    *reinterpret_cast<float4*>(qs + r * QS + 4 * c) = v;
+  }
+  __syncthreads();
+  const float* qrow = qs + l31 * QS + 16 * h;
+  f32x16s acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int grp = wave + STREAM_WAVES * i;
+    if (grp < G) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 b = *reinterpret_cast<const float4*>(qrow + 32 * grp + 4 * j);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j].x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j].y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j].z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j].w, b.w, acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (l31 < g.B) {
+    float* cv = g.sim.cand_val + (int64_t)l31 * g.sim.cap + slot_base + sub * 32;
+    int32_t* ci = g.sim.cand_idx + (int64_t)l31 * g.sim.cap + slot_base + sub * 32;
+    for (int r = wave; r < 16; r += STREAM_WAVES) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < STREAM_WAVES; ++w) v += red[(w * 16 + r) * 64 + lane];
+      const int roff = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const bool ok = m0 + roff < g.N;
+      cv[roff] = ok ? v : -INFINITY;
+      ci[roff] = ok ? (int)(m0 + roff) : -1;
+    }
+  }
+}
+
 bool sim_stream_supported(int B, int d, bool bf16) { return !bf16 && B <= 32 && d % 128 == 0 && d <= 1024; }
 
 int launch_sim_stream(const float* D, int64_t N, const float* Q, int B, int d, const SimEpilogue& ep, hipStream_t stream) {
@@ -156,20 +236,26 @@ int launch_sim_stream(const float* D, int64_t N, const float* Q, int B, int d, c
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sim_stream_f32_kernel<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(sim_stream_f32_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(sim_stream_sample_splitk_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       set_error("sim_stream: hipFuncSetAttribute failed");
       return GDR_EHIP;
     }
     attr_set = true;
   }
-  int64_t blocks = (g.n_tiles * 4 + 7) / 8;
+  int64_t blocks = (g.n_tiles * 4 + STREAM_WAVES - 1) / STREAM_WAVES;
   if (blocks > 256) blocks = 256;  // persistent: one workgroup per CU
   const double rows = (double)(g.n_tiles * 128 < N ? g.n_tiles * 128 : N);
   ProfScope prof(ep.mode == 1 ? PROF_SIM_SAMPLE : PROF_SIM_FILTER, 2.0 * rows * B * d, stream);
-  if (ep.mode == 1)
-    hipLaunchKernelGGL(sim_stream_f32_kernel<1>, dim3((unsigned)blocks), dim3(512), lds, stream, g);
+  const size_t lds_split = lds + (size_t)STREAM_WAVES * 16 * 64 * sizeof(float);
+  if (ep.mode == 1 && g.n_tiles * 4 <= 128 * STREAM_WAVES && lds_split <= 160 * 1024)  // fewer slices than half the waves
+    hipLaunchKernelGGL(sim_stream_sample_splitk_kernel, dim3((unsigned)(g.n_tiles * 4)), dim3(STREAM_THREADS), lds_split,
+                       stream, g);
+  else if (ep.mode == 1)
+    hipLaunchKernelGGL(sim_stream_f32_kernel<1>, dim3((unsigned)blocks), dim3(STREAM_THREADS), lds, stream, g);
   else
-    hipLaunchKernelGGL(sim_stream_f32_kernel<2>, dim3((unsigned)blocks), dim3(512), lds, stream, g);
+    hipLaunchKernelGGL(sim_stream_f32_kernel<2>, dim3((unsigned)blocks), dim3(STREAM_THREADS), lds, stream, g);
   GDR_CHECK_LAUNCH("sim_stream_f32_kernel");
   return GDR_OK;
 }
