@@ -380,7 +380,7 @@ int gdr::sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, in
   int rc = stream_mode ? launch_sim_stream(static_cast<const float*>(D), N, static_cast<const float*>(Q), B, d, ep, stream)
                        : launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
   if (rc) return rc;
-  const int sel_threads = B <= 128 ? 1024 : SEL_THREADS;  // few queries: spend the idle CUs' worth of lanes per query
+  const int sel_threads = 1024;  // per-query sweeps are latency-bound: more lanes per query = fewer dependent trips
   hipLaunchKernelGGL(sim_threshold_kernel, dim3(B), dim3(sel_threads), 0, stream, ep.cand_val, p.cap, (int)p.n_slots,
                      k, thr, ep.cand_cnt);
   GDR_CHECK_LAUNCH("sim_threshold_kernel");
