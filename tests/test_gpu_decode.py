@@ -79,9 +79,10 @@ def test_generate_base_vs_reference_golden(dev):
                                atol=2e-4)
 
 
-@pytest.mark.parametrize("B,R,L", [(1, 2, 3), (5, 6, 9), (2, 16, 12)])
+@pytest.mark.parametrize("B,R,L", [(1, 2, 3), (5, 6, 9), (2, 16, 12), (2, 30, 8)])
 def test_generate_tiny_vs_oracle(dev, B, R, L):
-    """More shapes than the golden covers, incl. R=16 > V+1=7 valid columns at step 1 (garbage candidates)."""
+    """More shapes than the golden covers, incl. R=16 > V+1=7 valid columns at step 1 (garbage candidates) and the
+    beam width of config C5 (30)."""
     from gdr_amd.modeling import GDRModel
     from oracle import beam_ref
     cfg = GDRConfig.tiny()

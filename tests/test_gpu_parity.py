@@ -155,9 +155,10 @@ def test_sim_topk_c1_vs_reference_golden(dev):
 
 
 @pytest.mark.parametrize("B,N,d,k", [(3, 1000, 64, 1), (5, 129, 32, 129), (96, 40000, 768, 100), (130, 70001, 128, 37),
-                                     (2, 20000, 64, 1024)])
+                                     (2, 20000, 64, 1024), (1024, 30000, 128, 100)])
 def test_sim_topk_vs_oracle(dev, B, N, d, k):
-    """Covers: all-sample path (small N), sample+filter path (N > 16384), ragged last tile, k = N, k = 1024."""
+    """Covers: all-sample path (small N), sample+filter path (N > 16384), ragged last tile, k = N, k = 1024, a C4-sized
+    query batch (8 column tiles)."""
     from gdr_amd import ops
     from oracle import retrieval_ref
     D = synth.make_corpus(N, d, seed=N + d)
