@@ -371,6 +371,232 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
   }
 }
 
+// ---- persistent form of the linear kernel ---------------------------------------------------------------------
+// The one-tile-per-workgroup launch above runs its 512 resident workgroups in lockstep: every tile of a round reaches
+// its epilogue at the same moment, so each round ends with the whole chip storing (and re-loading residuals) while the
+// matrix pipes idle, then starts with every workgroup waiting on its first operand loads.  Measured: time(K) at
+// M=20480 has an intercept worth 13-15 us per round of tiles — 13 % of a K=768 tile, the reason the K=768 linears ran
+// at 103-113 TFLOP/s against 134-139 asymptotically (tools/bench_linear_ksweep.py).
+// Here a workgroup owns a strided list of tiles and runs ONE flattened K-step stream across them: the operand prefetch
+// (two K-steps ahead) simply continues into the next tile while the current one finishes, and the epilogue is a burst
+// of stores issued between two K-steps that drains in the background under the next tile's MFMAs.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel(const GemmArgs g, const int total_tiles) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDS_STRIDE + 2 * BN * LDS_STRIDE];
+  float* const As = smem;
+  float* const Bs = smem + 2 * BM * LDS_STRIDE;
+  unsigned bid = blockIdx.x;
+  {
+    const unsigned nblk = gridDim.x, q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int G = (int)gridDim.x;
+  const int tid = threadIdx.x;
+  const int lrow = tid >> 3;
+  const int lcol = (tid & 7) * 4;
+  const int st_off = lrow * LDS_STRIDE + lcol;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int a_rd = (wm * 64 + l31) * LDS_STRIDE + 4 * h;
+  const int b_rd = (wn * 64 + l31) * LDS_STRIDE + 4 * h;
+  const int nk = g.K / BK;
+
+  int64_t a_ld[4];  // element offsets from g.A / g.W — kept as integers: pointers that pass through the tile-crossing
+  int64_t w_ld[4];  // select lose their address space and the loads degrade to flat_load (vmcnt AND lgkmcnt)
+#define P_SETPTRS(tile_)                                                     \
+  {                                                                          \
+    const int mt_ = (tile_) / g.tiles_n;                                     \
+    const int nt_ = (tile_) - mt_ * g.tiles_n;                               \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                          \
+      int64_t ra_ = (int64_t)mt_ * BM + lrow + 32 * p;                       \
+      ra_ = ra_ < g.M ? ra_ : g.M - 1;                                       \
+      int rw_ = nt_ * BN + lrow + 32 * p;                                    \
+      rw_ = rw_ < g.N ? rw_ : g.N - 1;                                       \
+      a_ld[p] = ra_ * g.lda + lcol;                                          \
+      w_ld[p] = (int64_t)rw_ * g.ldw + lcol;                                 \
+    }                                                                        \
+  }
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define P_GLOAD                                          \
+  ra0 = *reinterpret_cast<const float4*>(g.A + a_ld[0]); \
+  ra1 = *reinterpret_cast<const float4*>(g.A + a_ld[1]); \
+  ra2 = *reinterpret_cast<const float4*>(g.A + a_ld[2]); \
+  ra3 = *reinterpret_cast<const float4*>(g.A + a_ld[3]); \
+  rb0 = *reinterpret_cast<const float4*>(g.W + w_ld[0]); \
+  rb1 = *reinterpret_cast<const float4*>(g.W + w_ld[1]); \
+  rb2 = *reinterpret_cast<const float4*>(g.W + w_ld[2]); \
+  rb3 = *reinterpret_cast<const float4*>(g.W + w_ld[3]);
+#define P_ADVANCE                                                            \
+  if (++ld_kt == nk) { /* the load stream crosses into the workgroup's next tile (or parks on its first) */ \
+    ld_kt = 0;                                                               \
+    ld_tile += G;                                                            \
+    const int t_ = ld_tile < total_tiles ? ld_tile : (int)bid;               \
+    P_SETPTRS(t_)                                                            \
+  } else {                                                                   \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) a_ld[p] += BK, w_ld[p] += BK; \
+  }
+#define P_LSTORE(buf_)                                                       \
+  {                                                                          \
+    float* a_ = As + (buf_)*BM * LDS_STRIDE + st_off;                        \
+    float* b_ = Bs + (buf_)*BN * LDS_STRIDE + st_off;                        \
+    *reinterpret_cast<float4*>(a_) = ra0;                                    \
+    *reinterpret_cast<float4*>(a_ + 32 * LDS_STRIDE) = ra1;                  \
+    *reinterpret_cast<float4*>(a_ + 64 * LDS_STRIDE) = ra2;                  \
+    *reinterpret_cast<float4*>(a_ + 96 * LDS_STRIDE) = ra3;                  \
+    *reinterpret_cast<float4*>(b_) = rb0;                                    \
+    *reinterpret_cast<float4*>(b_ + 32 * LDS_STRIDE) = rb1;                  \
+    *reinterpret_cast<float4*>(b_ + 64 * LDS_STRIDE) = rb2;                  \
+    *reinterpret_cast<float4*>(b_ + 96 * LDS_STRIDE) = rb3;                  \
+  }
+#define P_READ(A0, A1, B0, B1, ap, bp, jj)                                   \
+  A0 = *reinterpret_cast<const float4*>((ap) + 8 * (jj));                    \
+  A1 = *reinterpret_cast<const float4*>((ap) + 32 * LDS_STRIDE + 8 * (jj));  \
+  B0 = *reinterpret_cast<const float4*>((bp) + 8 * (jj));                    \
+  B1 = *reinterpret_cast<const float4*>((bp) + 32 * LDS_STRIDE + 8 * (jj));
+#define P_MFMA4(A0, A1, B0, B1, x_)                                                   \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x_, B0.x_, acc[0][0], 0, 0, 0); \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x_, B1.x_, acc[0][1], 0, 0, 0); \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x_, B0.x_, acc[1][0], 0, 0, 0); \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x_, B1.x_, acc[1][1], 0, 0, 0);
+#define P_MFMA16(A0, A1, B0, B1) \
+  P_MFMA4(A0, A1, B0, B1, x) P_MFMA4(A0, A1, B0, B1, y) P_MFMA4(A0, A1, B0, B1, z) P_MFMA4(A0, A1, B0, B1, w)
+
+  int ld_tile = (int)bid, ld_kt = 0;
+  P_SETPTRS(ld_tile)
+  P_GLOAD
+  P_ADVANCE
+  P_LSTORE(0)
+  __syncthreads();
+  P_GLOAD
+  P_ADVANCE
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int tile = (int)bid, kt = 0, buf = 0;
+  while (tile < total_tiles) {
+    {
+      const float* a = As + buf * BM * LDS_STRIDE + a_rd;
+      const float* b = Bs + buf * BN * LDS_STRIDE + b_rd;
+      float4 c0a0, c0a1, c0b0, c0b1, c1a0, c1a1, c1b0, c1b1, c2a0, c2a1, c2b0, c2b1, c3a0, c3a1, c3b0, c3b1;
+      P_READ(c0a0, c0a1, c0b0, c0b1, a, b, 0)
+      P_READ(c1a0, c1a1, c1b0, c1b1, a, b, 1)
+      P_LSTORE(buf ^ 1)
+      P_MFMA16(c0a0, c0a1, c0b0, c0b1)
+      P_READ(c2a0, c2a1, c2b0, c2b1, a, b, 2)
+      P_READ(c3a0, c3a1, c3b0, c3b1, a, b, 3)
+      P_GLOAD
+      P_MFMA16(c1a0, c1a1, c1b0, c1b1)
+      P_MFMA16(c2a0, c2a1, c2b0, c2b1)
+      P_MFMA16(c3a0, c3a1, c3b0, c3b1)
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // ds_read: chunks 0,1
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // ds_write
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ds_read: chunks 2,3
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // global_load
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 40, 0);
+    }
+    __syncthreads();  // stays in the MFMA block: the compiler hoists it above the trailing 40 MFMAs, which then cover the wait
+    P_ADVANCE
+    buf ^= 1;
+    if (++kt == nk) {
+      // epilogue of this tile: stores only (plus the residual / bias loads), no LDS — the other waves are already
+      // in the next tile's first K-step.  Accumulator map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+      const int mt = tile / g.tiles_n;
+      const int64_t m0 = (int64_t)mt * BM;
+      const int n0 = (tile - mt * g.tiles_n) * BN;
+      if (m0 + BM <= g.M && n0 + BN <= g.N) {
+        // interior tile: uniform branches only, so that the 64 residual loads go out as one batch and the 64 stores
+        // as another (per-element flag tests serialise them behind a vmcnt(0) each)
+        const int64_t mrow = m0 + wm * 64 + 4 * h;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {  // one column tile (32 accumulators) at a time: bounds the registers in flight
+          const int ncol = n0 + wn * 64 + ni * 32 + l31;
+          if (g.has_bias) {
+            const float bia = g.bias[ncol];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] += bia;
+          }
+          if (g.has_residual) {
+            const float* rp = g.residual + mrow * g.ldr + ncol;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] += rp[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr];
+          }
+          if (g.act == ACT_RELU) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaxf(acc[mi][ni][r], 0.f);
+          } else if (g.act == ACT_GELU) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] = gelu_erf(acc[mi][ni][r]);
+          }
+          float* cp = g.C + mrow * g.ldc + ncol;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              cp[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc] = acc[mi][ni][r];
+              acc[mi][ni][r] = 0.f;
+            }
+        }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int n = n0 + wn * 64 + ni * 32 + l31;
+          const bool n_ok = n < g.N;
+          const float bia = (g.has_bias && n_ok) ? g.bias[n] : 0.f;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+              float v = acc[mi][ni][r] + bia;
+              acc[mi][ni][r] = 0.f;
+              if (!n_ok || m >= g.M) continue;
+              if (g.has_residual) v += g.residual[m * g.ldr + n];
+              if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
+              if (g.act == ACT_GELU) v = gelu_erf(v);
+              g.C[m * g.ldc + n] = v;
+            }
+          }
+        }
+      }
+      kt = 0;
+      tile += G;
+    }
+  }
+#undef P_SETPTRS
+#undef P_GLOAD
+#undef P_ADVANCE
+#undef P_LSTORE
+#undef P_READ
+#undef P_MFMA4
+#undef P_MFMA16
+}
+
 template <int EPI, bool BF16 = false>
 static int launch(const GemmArgs& g, int64_t tiles_m, hipStream_t stream) {
   const int64_t blocks = tiles_m * g.tiles_n;
@@ -516,6 +742,15 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
     }
   }
   ProfScope prof(PROF_LINEAR, flops, stream);
+  static const bool persist_on = [] {
+    const char* e = getenv("GDR_GEMM_PERSIST");  // A/B knob: 0 = always one tile per workgroup
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (persist_on && tiles > SLOTS && tiles < 0x7fffffff && K % BK == 0) {  // more than one round of tiles: persistent form
+    hipLaunchKernelGGL(gemm_nt_f32_persistent_kernel, dim3((unsigned)SLOTS), dim3(GEMM_THREADS), 0, stream, g, (int)tiles);
+    GDR_CHECK_LAUNCH("gemm_nt_f32_persistent_kernel");
+    return GDR_OK;
+  }
   return launch<EPI_LINEAR>(g, tiles_m, stream);
 }
 
