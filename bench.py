@@ -171,7 +171,7 @@ def main():
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("gemm_nt_f32_kernel<0, false>_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("linear_gemm_bytes_per_launch")
             except Exception:
                 traffic = None
         result = {
@@ -184,7 +184,7 @@ def main():
                        "all-gather of queries and of per-shard top-k, local merge"),
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 40,
                        "corpus_rows": a.corpus, "dim": cfg.d_model, "k": a.k, "corpus_resident_in_hbm": True},
-            "roofline": {"bound": "mfma", "kernel": "gdr::gemm_nt_f32_kernel<0, false> (every encoder linear)",
+            "roofline": {"bound": "mfma", "kernel": "gdr::gemm_nt_f32_persistent_kernel (every encoder linear)",
                          "achieved": lin["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": lin["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "launches": lin["launches"], "avg_launch_ms": lin["avg_ms"],

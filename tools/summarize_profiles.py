@@ -51,7 +51,7 @@ with open(f"profiles/{tag}_bench_pmc_hbm.md", "w") as o:
             "290 MB/launch.  The excess is the W panel (7-9.4 MB) cycling through one XCD's 4 MiB L2 under the n-fastest tile "
             "order and being re-read through the Infinity Cache; the kernel is MFMA-bound, so this costs energy rather than time "
             "(an m-fastest supertile order was measured in tools/gemm_lab.hip: +3-5 % on the old loop, 0 % on the current one).\n")
-key = [k for k in out if "gemm_nt_f32_kernel<0, false>" in k][0]
-json.dump({"gemm_nt_f32_kernel<0, false>_bytes_per_launch": out[key], "source": f"profiles/{tag}_bench_pmc_hbm.md"},
+key = [k for k in out if "gemm_nt_f32_persistent_kernel" in k or "gemm_nt_f32_kernel<0, false>" in k][0]   # the linear GEMM (persistent form in the bench)
+json.dump({"linear_gemm_bytes_per_launch": out[key], "kernel": key, "source": f"profiles/{tag}_bench_pmc_hbm.md"},
           open("profiles/traffic.json", "w"), indent=1)
 print(open(f"profiles/{tag}_bench_kernel_stats.csv").read()[:1500])
