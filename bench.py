@@ -28,6 +28,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA (no sparsity)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -39,6 +40,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=512, help="queries per GPU per step")
     ap.add_argument("--corpus", type=int, default=320000)
     ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = the reference's precision (the headline); bf16 = config C5's precision mode: bf16 linear "
+                         "operands in the encoder and a bf16 corpus, fp32 accumulate (not comparable with the f32 line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     return ap.parse_args()
@@ -116,10 +120,13 @@ def main():
 
     cfg = GDRConfig.base()
     sd = synth.make_state_dict(cfg, seed=1234, with_decoder=False)
-    enc = ops.T5EncoderHandle(cfg, sd, dev)
+    bf16 = a.dtype == "bf16"
+    enc = ops.T5EncoderHandle(cfg, sd, dev, dtype=torch.bfloat16 if bf16 else torch.float32)
     D = synth.make_corpus(a.corpus, cfg.d_model)
     lo, hi = shard_bounds(a.corpus, world, rank, cluster_size=12)
     D_dev = torch.from_numpy(D[lo:hi]).to(dev)
+    if bf16:
+        D_dev = ops.to_bf16(D_dev)
     index = ShardedIndex(D_dev, lo)
     ids_all, mask_all = synth.make_tokens(a.batch * world, L=40, seed=11)
     ids = torch.from_numpy(ids_all[rank * a.batch:(rank + 1) * a.batch]).to(dev)
@@ -177,16 +184,20 @@ def main():
         result = {
             "metric": "queries/sec on NQ-320k (768-d)", "value": total_q / dt, "unit": "queries/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": ("C2" if world == 1 else "C4-layout") +
                        f": t5-base encoder on {a.batch} queries/GPU (L=40) + fused Q.D^T top-{a.k} over a "
-                       f"{a.corpus}x{cfg.d_model} fp32 corpus" + ("" if world == 1 else f" row-sharded {world} ways, "
+                       f"{a.corpus}x{cfg.d_model} {'bf16' if bf16 else 'fp32'} corpus" +
+                       (" [C5 precision mode: bf16 linear operands, fp32 accumulate]" if bf16 else "") + ("" if world == 1 else f" row-sharded {world} ways, "
                        "all-gather of queries and of per-shard top-k, local merge"),
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 40,
                        "corpus_rows": a.corpus, "dim": cfg.d_model, "k": a.k, "corpus_resident_in_hbm": True},
-            "roofline": {"bound": "mfma", "kernel": "gdr::gemm_nt_f32_persistent_kernel (every encoder linear)",
-                         "achieved": lin["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": lin["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": ("gdr::gemm_nt_f32_kernel<0, true> (bf16 operands; every encoder linear)"
+                                                     if bf16 else "gdr::gemm_nt_f32_persistent_kernel (every encoder linear)"),
+                         "achieved": lin["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS if bf16 else F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s",
+                         "frac": lin["tflops"] / (BF16_MFMA_PEAK_TFLOPS if bf16 else F32_MFMA_PEAK_TFLOPS),
+                         "traffic": None if bf16 else traffic,
                          "launches": lin["launches"], "avg_launch_ms": lin["avg_ms"],
                          "algorithmic_gflop_per_launch": lin["gflop_per_launch"], "share_of_step": lin["share_of_step"]},
             "kernels": {"sim_sample_gemm": smp, "sim_filter_gemm": flt, "attention": att, "splitk_reduce": red},
@@ -197,9 +208,10 @@ def main():
             rows = hi - lo
             result["kernels"]["sim_total"] = {
                 "ms_per_step": sim_ms, "tflops": (w_l[1] + w_l[2]) / a.steps / (sim_ms * 1e-3) / 1e12,
-                "frac_of_f32_mfma_peak": (w_l[1] + w_l[2]) / a.steps / (sim_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                "corpus_stream_gbs": rows * cfg.d_model * 4 / (sim_ms * 1e-3) / 1e9,
-                "frac_of_hbm_peak": rows * cfg.d_model * 4 / (sim_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                "frac_of_mfma_peak": (w_l[1] + w_l[2]) / a.steps / (sim_ms * 1e-3) / 1e12 /
+                                     (BF16_MFMA_PEAK_TFLOPS if bf16 else F32_MFMA_PEAK_TFLOPS),
+                "corpus_stream_gbs": rows * cfg.d_model * (2 if bf16 else 4) / (sim_ms * 1e-3) / 1e9,
+                "frac_of_hbm_peak": rows * cfg.d_model * (2 if bf16 else 4) / (sim_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not a.no_recall:
             from oracle import retrieval_ref
             Q, gold = synth.make_queries(D, a.batch)

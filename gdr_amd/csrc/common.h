@@ -64,6 +64,10 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
 int launch_sim_gemm(const void* D, int64_t N, const void* Q, int B, int d, const SimEpilogue& ep, bool bf16,
                     hipStream_t stream);
 
+int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
+                       int K, int epilogue, const float* bias, const float* residual, int64_t ldr, hipStream_t stream);
+int launch_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, hipStream_t stream);
+
 // latency-mode similarity (B <= 32, fp32): stationary queries in LDS, corpus streamed from HBM (sim_stream.hip)
 bool sim_stream_supported(int B, int d, bool bf16);
 int launch_sim_stream(const float* D, int64_t N, const float* Q, int B, int d, const SimEpilogue& ep, hipStream_t stream);

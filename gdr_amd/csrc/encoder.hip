@@ -16,10 +16,10 @@ namespace gdr {
 constexpr size_t ENC_SPLITK_BYTES = (size_t)112 << 20;  // <= 384 tail tiles x 4 splits x 64 KiB + slack
 
 struct EncWs {
-  size_t off_h, off_nx, off_qkv, off_ctx, off_ff, off_splitk, total;
+  size_t off_h, off_nx, off_qkv, off_ctx, off_ff, off_splitk, off_bf, total;
 };
 
-static EncWs enc_ws(const GdrT5Dims& dm, int64_t M) {
+static EncWs enc_ws(const GdrT5Dims& dm, int64_t M, bool bf16 = false) {
   EncWs w{};
   const size_t inner = (size_t)dm.num_heads * dm.d_kv;
   size_t o = 0;
@@ -29,6 +29,8 @@ static EncWs enc_ws(const GdrT5Dims& dm, int64_t M) {
   w.off_ctx = o, o += align_up((size_t)M * inner * 4, 256);
   w.off_ff = o, o += align_up((size_t)M * dm.d_ff * 4, 256);
   w.off_splitk = o, o += ENC_SPLITK_BYTES;  // small batches: split-K partial slabs (gemm_f32.hip)
+  w.off_bf = o;
+  if (bf16) o += align_up((size_t)M * (dm.d_ff > dm.d_model ? dm.d_ff : dm.d_model) * 2, 256);  // bf16 copy of a GEMM's A operand
   w.total = o;
   return w;
 }
@@ -40,18 +42,19 @@ extern "C" size_t gdr_t5_encoder_workspace_bytes(const GdrT5Dims* dims, int B, i
   return gdr::enc_ws(*dims, (int64_t)B * L).total;
 }
 
-extern "C" int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B,
-                                      int L, float* out_hidden, float* out_pooled, void* workspace,
-                                      size_t workspace_bytes, void* stream_) {
-  using namespace gdr;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+namespace gdr {
+static int t5_encoder_impl(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L,
+                           float* out_hidden, float* out_pooled, void* workspace, size_t workspace_bytes, bool bf16,
+                           hipStream_t stream) {
   GDR_CHECK_ARG(w && ids && out_hidden && workspace, "t5_encoder: null pointer");
   const GdrT5Dims& dm = w->dims;
   GDR_CHECK_ARG(B > 0 && L > 0 && L <= 128, "t5_encoder: B=%d L=%d (L must be in [1,128])", B, L);
   GDR_CHECK_ARG(dm.d_model % 4 == 0 && dm.d_kv % 4 == 0 && dm.d_ff % 4 == 0, "t5_encoder: dims must be multiples of 4");
   GDR_CHECK_ARG(w->embed && w->rel_bias && w->final_ln && w->layers, "t5_encoder: null weight pointer");
   const int64_t M = (int64_t)B * L;
-  const EncWs ws = enc_ws(dm, M);
+  const EncWs ws = enc_ws(dm, M, bf16);
+  GDR_CHECK_ARG(!bf16 || (dm.d_model % 8 == 0 && dm.d_ff % 8 == 0 && (dm.num_heads * dm.d_kv) % 8 == 0),
+                "t5_encoder_bf16: dims must be multiples of 8");
   if (workspace_bytes < ws.total) {
     set_error("t5_encoder: workspace %zu < required %zu", workspace_bytes, ws.total);
     return GDR_ENOSPC;
@@ -64,6 +67,18 @@ extern "C" int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_
   float* ctx = reinterpret_cast<float*>(base + ws.off_ctx);
   float* ff = reinterpret_cast<float*>(base + ws.off_ff);
   float* skw = reinterpret_cast<float*>(base + ws.off_splitk);
+  void* abf = base + ws.off_bf;
+  // one linear: fp32 as is; in bf16 mode the activation operand is rounded to bf16 into `abf` first (the weights were
+  // rounded once by the caller) and the GEMM runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulate / epilogue / output
+  auto linear = [&](const float* A, int64_t lda, const float* W, float* C, int64_t ldc, int N, int K, int epi,
+                    const float* residual) -> int {
+    if (!bf16)
+      return launch_linear_f32_ws(A, lda, W, K, C, ldc, M, N, K, epi, nullptr, residual, ldc, skw, ENC_SPLITK_BYTES, stream);
+    GDR_CHECK_ARG(lda == K, "t5_encoder_bf16: operand must be dense");
+    int rc_ = launch_cast_f32_bf16(A, abf, M * (int64_t)K, stream);
+    if (rc_) return rc_;
+    return launch_linear_bf16(abf, K, W, K, C, ldc, M, N, K, epi, nullptr, residual, ldc, stream);
+  };
   const int d = dm.d_model, H = dm.num_heads, dk = dm.d_kv, inner = H * dk;
 
   int rc = launch_embed(w->embed, ids, M, d, dm.vocab_size, h, stream);  // modeling_t5.py:725
@@ -84,17 +99,33 @@ extern "C" int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_
     const GdrT5EncLayer& ly = w->layers[i];
     GDR_CHECK_ARG(ly.ln_attn && ly.wqkv && ly.wo && ly.ln_ff && ly.wi && ly.wo_ff, "t5_encoder: layer %d null weight", i);
     if ((rc = launch_rmsnorm(h, ly.ln_attn, nx, M, d, dm.eps, nullptr, 1, stream))) return rc;
-    if ((rc = launch_linear_f32_ws(nx, d, ly.wqkv, d, qkv, 3 * inner, M, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0, skw, ENC_SPLITK_BYTES, stream)))
-      return rc;
+    if ((rc = linear(nx, d, ly.wqkv, qkv, 3 * inner, 3 * inner, d, GDR_EPI_NONE, nullptr))) return rc;
     if ((rc = launch_attention(at, stream))) return rc;
-    if ((rc = launch_linear_f32_ws(ctx, inner, ly.wo, inner, h, d, M, d, inner, GDR_EPI_RESIDUAL, nullptr, h, d, skw, ENC_SPLITK_BYTES, stream)))
-      return rc;
+    if ((rc = linear(ctx, inner, ly.wo, h, d, d, inner, GDR_EPI_RESIDUAL, h))) return rc;
     if ((rc = launch_rmsnorm(h, ly.ln_ff, nx, M, d, dm.eps, nullptr, 1, stream))) return rc;
-    if ((rc = launch_linear_f32_ws(nx, d, ly.wi, d, ff, dm.d_ff, M, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0, skw, ENC_SPLITK_BYTES, stream)))
-      return rc;
-    if ((rc = launch_linear_f32_ws(ff, dm.d_ff, ly.wo_ff, dm.d_ff, h, d, M, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, h, d, skw, ENC_SPLITK_BYTES, stream)))
-      return rc;
+    if ((rc = linear(nx, d, ly.wi, ff, dm.d_ff, dm.d_ff, d, GDR_EPI_RELU, nullptr))) return rc;
+    if ((rc = linear(ff, dm.d_ff, ly.wo_ff, h, d, d, dm.d_ff, GDR_EPI_RESIDUAL, h))) return rc;
   }
   // final_layer_norm (:803) + CLS pool h[:,0] (main_models.py:102-109)
   return launch_rmsnorm(h, w->final_ln, out_hidden, M, d, dm.eps, out_pooled, L, stream);
+}
+}  // namespace gdr
+
+extern "C" int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B,
+                                      int L, float* out_hidden, float* out_pooled, void* workspace,
+                                      size_t workspace_bytes, void* stream_) {
+  return gdr::t5_encoder_impl(w, ids, mask, B, L, out_hidden, out_pooled, workspace, workspace_bytes, false,
+                              static_cast<hipStream_t>(stream_));
+}
+
+extern "C" size_t gdr_t5_encoder_bf16_workspace_bytes(const GdrT5Dims* dims, int B, int L) {
+  if (!dims || B <= 0 || L <= 0) return 0;
+  return gdr::enc_ws(*dims, (int64_t)B * L, true).total;
+}
+
+extern "C" int gdr_t5_encoder_forward_bf16(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B,
+                                           int L, float* out_hidden, float* out_pooled, void* workspace,
+                                           size_t workspace_bytes, void* stream_) {
+  return gdr::t5_encoder_impl(w, ids, mask, B, L, out_hidden, out_pooled, workspace, workspace_bytes, true,
+                              static_cast<hipStream_t>(stream_));
 }

@@ -754,6 +754,39 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
   return launch<EPI_LINEAR>(g, tiles_m, stream);
 }
 
+// bf16 operands (fp32 accumulate, fp32 output): the precision mode of config C5.  Same tiling as the fp32 linears on
+// v_mfma_f32_32x32x16_bf16; no split-K form.
+int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
+                       int K, int epilogue, const float* bias, const float* residual, int64_t ldr, hipStream_t stream) {
+  GDR_CHECK_ARG(A && W && C, "linear_bf16: null pointer");
+  GDR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear_bf16: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  GDR_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "linear_bf16: K, lda, ldw must be multiples of 8");
+  GDR_CHECK_ARG(lda >= K && ldw >= K && ldc >= N, "linear_bf16: leading dimension smaller than the row");
+  GDR_CHECK_ARG(aligned16(A) && aligned16(W), "linear_bf16: A and W must be 16-byte aligned");
+  if (epilogue < GDR_EPI_NONE || epilogue > GDR_EPI_BIAS_GELU) {
+    set_error("linear_bf16: unknown epilogue %d", epilogue);
+    return GDR_EINVAL;
+  }
+  const bool needs_bias = epilogue == GDR_EPI_BIAS || epilogue == GDR_EPI_BIAS_RELU ||
+                          epilogue == GDR_EPI_BIAS_RESIDUAL || epilogue == GDR_EPI_BIAS_GELU;
+  const bool needs_res = epilogue == GDR_EPI_RESIDUAL || epilogue == GDR_EPI_BIAS_RESIDUAL;
+  GDR_CHECK_ARG(!needs_bias || bias, "linear_bf16: epilogue %d needs bias", epilogue);
+  GDR_CHECK_ARG(!needs_res || (residual && ldr >= N), "linear_bf16: epilogue %d needs residual", epilogue);
+  if (M == 0) return GDR_OK;
+  GemmArgs g{};
+  g.A = static_cast<const float*>(A), g.W = static_cast<const float*>(W);  // opaque: the kernel addresses operands in bytes
+  g.C = C, g.bias = bias, g.residual = residual;
+  g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr;
+  g.M = M, g.N = N, g.K = K;
+  g.tiles_n = (N + BN - 1) / BN;
+  g.has_bias = needs_bias, g.has_residual = needs_res;
+  g.act = (epilogue == GDR_EPI_RELU || epilogue == GDR_EPI_BIAS_RELU) ? ACT_RELU
+          : epilogue == GDR_EPI_BIAS_GELU                             ? ACT_GELU
+                                                                      : ACT_NONE;
+  ProfScope prof(PROF_LINEAR, 2.0 * (double)M * (double)N * (double)K, stream);
+  return launch<EPI_LINEAR, true>(g, (M + BM - 1) / BM, stream);
+}
+
 int launch_sim_gemm(const void* D_, int64_t N, const void* Q_, int B, int d, const SimEpilogue& ep, bool bf16,
                     hipStream_t stream) {
   const float* D = static_cast<const float*>(D_);   // opaque: the kernel addresses operands in bytes

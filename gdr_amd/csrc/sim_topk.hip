@@ -324,16 +324,20 @@ static int sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, 
                          bool bf16, hipStream_t stream);
 }  // namespace gdr
 
-extern "C" int gdr_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, void* stream_) {
-  using namespace gdr;
+namespace gdr {
+int launch_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, hipStream_t stream) {
   GDR_CHECK_ARG(in && out_bf16 && n >= 0 && n % 4 == 0, "cast: null pointer or n %% 4 != 0");
   GDR_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)out_bf16 & 7) == 0, "cast: misaligned pointer");
   if (n == 0) return GDR_OK;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream_), reinterpret_cast<const float4*>(in),
-                     reinterpret_cast<uint2*>(out_bf16), n / 4);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const float4*>(in), reinterpret_cast<uint2*>(out_bf16), n / 4);
   GDR_CHECK_LAUNCH("cast_f32_bf16_kernel");
   return GDR_OK;
+}
+}  // namespace gdr
+
+extern "C" int gdr_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, void* stream_) {
+  return gdr::launch_cast_f32_bf16(in, out_bf16, n, static_cast<hipStream_t>(stream_));
 }
 
 extern "C" int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, int d, int k, int32_t idx_offset,

@@ -146,15 +146,27 @@ def relative_bucket_table(bidirectional, num_buckets, max_distance, qlen, klen):
 
 class T5EncoderHandle:
     """Device-resident encoder weights + the pointer table gdr_t5_encoder_forward reads.
-    Built once from a reference-style state_dict; q/k/v are row-concatenated."""
+    Built once from a reference-style state_dict; q/k/v are row-concatenated.
+    dtype=torch.bfloat16 selects the C5 precision mode: the linear weights are rounded to bf16 on the device
+    (gdr_cast_f32_bf16) and forward() calls gdr_t5_encoder_forward_bf16; everything else stays fp32."""
 
-    def __init__(self, cfg, sd, device, prefix="encoder."):
-        self.cfg, self.device = cfg, device
+    def __init__(self, cfg, sd, device, prefix="encoder.", dtype=torch.float32):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("T5EncoderHandle: dtype must be float32 or bfloat16")
+        self.cfg, self.device, self.dtype = cfg, device, dtype
         keep = []
 
         def dev(t):
             t = t.detach().to(device=device, dtype=torch.float32).contiguous()
             keep.append(t)
+            return t
+
+        def lin(t):                                      # a linear's weight: bf16 copy in the C5 mode
+            t = dev(t)
+            if dtype == torch.bfloat16:
+                keep.pop()
+                t = to_bf16(t)
+                keep.append(t)
             return t
 
         self.embed = dev(sd["shared.weight"] if "shared.weight" in sd else sd[prefix + "embed_tokens.weight"])
@@ -164,15 +176,15 @@ class T5EncoderHandle:
         self._layers = (_ffi.GdrT5EncLayer * nl)()
         for i in range(nl):
             p = f"{prefix}block.{i}.layer."
-            wqkv = dev(torch.cat([sd[p + "0.SelfAttention.q.weight"], sd[p + "0.SelfAttention.k.weight"],
+            wqkv = lin(torch.cat([sd[p + "0.SelfAttention.q.weight"], sd[p + "0.SelfAttention.k.weight"],
                                   sd[p + "0.SelfAttention.v.weight"]], dim=0))
             L = self._layers[i]
             L.ln_attn = dev(sd[p + "0.layer_norm.weight"]).data_ptr()
             L.wqkv = wqkv.data_ptr()
-            L.wo = dev(sd[p + "0.SelfAttention.o.weight"]).data_ptr()
+            L.wo = lin(sd[p + "0.SelfAttention.o.weight"]).data_ptr()
             L.ln_ff = dev(sd[p + "1.layer_norm.weight"]).data_ptr()
-            L.wi = dev(sd[p + "1.DenseReluDense.wi.weight"]).data_ptr()
-            L.wo_ff = dev(sd[p + "1.DenseReluDense.wo.weight"]).data_ptr()
+            L.wi = lin(sd[p + "1.DenseReluDense.wi.weight"]).data_ptr()
+            L.wo_ff = lin(sd[p + "1.DenseReluDense.wo.weight"]).data_ptr()
         self._keep = keep
         self.dims = _ffi.GdrT5Dims(cfg.vocab_size, cfg.d_model, cfg.d_kv, cfg.d_ff, cfg.num_heads, nl,
                                    cfg.relative_attention_num_buckets, cfg.relative_attention_max_distance,
@@ -188,12 +200,15 @@ class T5EncoderHandle:
         if attention_mask is None:
             attention_mask = torch.ones_like(ids)
         mask = attention_mask.to(torch.int64).contiguous()
-        need = lib().gdr_t5_encoder_workspace_bytes(C.byref(self.dims), B, L)
+        bf = self.dtype == torch.bfloat16
+        need = (lib().gdr_t5_encoder_bf16_workspace_bytes if bf else lib().gdr_t5_encoder_workspace_bytes)(
+            C.byref(self.dims), B, L)
         ws = self.ws.get(need)
         out = torch.empty((B, L, self.cfg.d_model), dtype=torch.float32, device=ids.device)
         pooled = torch.empty((B, self.cfg.d_model), dtype=torch.float32, device=ids.device) if want_pooled else None
-        check(lib().gdr_t5_encoder_forward(C.byref(self.struct), ptr(ids), ptr(mask), B, L, ptr(out), ptr(pooled),
-                                           ptr(ws), ws.numel(), stream_ptr()), "gdr_t5_encoder_forward")
+        fn = lib().gdr_t5_encoder_forward_bf16 if bf else lib().gdr_t5_encoder_forward
+        check(fn(C.byref(self.struct), ptr(ids), ptr(mask), B, L, ptr(out), ptr(pooled), ptr(ws), ws.numel(),
+                 stream_ptr()), "gdr_t5_encoder_forward")
         return out, pooled
 
 

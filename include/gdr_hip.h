@@ -107,6 +107,17 @@ int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_t* ids, con
                            float* out_hidden, float* out_pooled, void* workspace, size_t workspace_bytes,
                            void* stream);
 
+/* bf16 precision mode (BASELINE config C5): the SAME structs, but the four linear weights of every layer (wqkv, wo, wi,
+ * wo_ff) point to bf16 [N,K] matrices (round-to-nearest-even of the fp32 checkpoint, e.g. gdr_cast_f32_bf16); the
+ * `const float*` field type is nominal for them.  Each linear rounds its activation operand to bf16 and accumulates in
+ * fp32; embedding, norms, attention (QK^T, softmax, PV), the residual stream and both outputs stay fp32.  The
+ * reference has no such mode (it runs precision=32, main.py:61,91): parity is against the fp32 path within bf16
+ * tolerance and against the oracle's bf16 emulation (oracle/t5_ref.py bf16_linears). */
+size_t gdr_t5_encoder_bf16_workspace_bytes(const GdrT5Dims* dims, int B, int L);
+int gdr_t5_encoder_forward_bf16(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L,
+                                float* out_hidden, float* out_pooled, void* workspace, size_t workspace_bytes,
+                                void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Corpus similarity + top-k, fused: never materialises the [B,N] score matrix.
  * replaces `compute_similarity` (dense.py:53-54, encoder.py:128-129: q @ p.T) followed by

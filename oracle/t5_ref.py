@@ -47,6 +47,29 @@ def t5_layer_norm(x, w, eps=1e-6):
     return w * x
 
 
+GEMM_BF16 = False   # set by bf16_linears(): emulate the C5 precision mode (linear operands rounded to bf16, fp32 accumulate)
+
+
+class bf16_linears:
+    """Context manager: every T5 linear rounds its activation and weight operands to bf16 (round-to-nearest-even) and
+    accumulates in fp32 — what gdr_t5_encoder_forward_bf16 computes.  Norms, softmax, QK^T / PV and the residual
+    stream stay fp32."""
+
+    def __enter__(self):
+        global GEMM_BF16
+        self.prev, GEMM_BF16 = GEMM_BF16, True
+
+    def __exit__(self, *a):
+        global GEMM_BF16
+        GEMM_BF16 = self.prev
+
+
+def _lin(x, w):
+    if GEMM_BF16:
+        x, w = x.to(torch.bfloat16).to(torch.float32), w.to(torch.bfloat16).to(torch.float32)
+    return x @ w.T
+
+
 def t5_attention(x, kv, sd, prefix, H, dk, position_bias):
     """modeling_t5.py:316-421 without cache.  No 1/sqrt(d) scaling; fp32 softmax."""
     bs = x.shape[0]
@@ -54,21 +77,21 @@ def t5_attention(x, kv, sd, prefix, H, dk, position_bias):
     def shape(t):
         return t.view(bs, -1, H, dk).transpose(1, 2)
 
-    q = shape(x @ sd[prefix + ".q.weight"].T)
+    q = shape(_lin(x, sd[prefix + ".q.weight"]))
     src = x if kv is None else kv
-    k = shape(src @ sd[prefix + ".k.weight"].T)
-    v = shape(src @ sd[prefix + ".v.weight"].T)
+    k = shape(_lin(src, sd[prefix + ".k.weight"]))
+    v = shape(_lin(src, sd[prefix + ".v.weight"]))
     scores = torch.matmul(q, k.transpose(3, 2))
     scores = scores + position_bias
     weights = F.softmax(scores.float(), dim=-1).type_as(scores)
     ctx = torch.matmul(weights, v).transpose(1, 2).contiguous().view(bs, -1, H * dk)
-    return ctx @ sd[prefix + ".o.weight"].T
+    return _lin(ctx, sd[prefix + ".o.weight"])
 
 
 def t5_ff(x, sd, prefix):
     """modeling_t5.py:181-186: wo(relu(wi(x))), no bias."""
-    h = F.relu(x @ sd[prefix + ".wi.weight"].T)
-    return h @ sd[prefix + ".wo.weight"].T
+    h = F.relu(_lin(x, sd[prefix + ".wi.weight"]))
+    return _lin(h, sd[prefix + ".wo.weight"])
 
 
 def encoder_forward(sd, cfg, input_ids, attention_mask, return_bias=False):

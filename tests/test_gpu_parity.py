@@ -143,6 +143,44 @@ def test_encoder_dk64_mfma_attention_vs_oracle(dev, B, L):
     torch.testing.assert_close(h.cpu(), ref, rtol=TOL, atol=TOL)
 
 
+@pytest.mark.parametrize("kind,B,L", [("tiny", 3, 5), ("tiny", 7, 40), ("dk64", 3, 33), ("dk64", 2, 128), ("base", 4, 40)])
+def test_encoder_bf16_mode_vs_oracle_emulation(dev, kind, B, L):
+    """C5 precision mode (gdr_t5_encoder_forward_bf16): linear operands rounded to bf16, fp32 accumulate, everything else
+    fp32.  Tight against the oracle's emulation of exactly that (same rounding points; a few activations may round the
+    other way because the fp32 values feeding the rounding differ in their last bits), loose against the fp32 path."""
+    from gdr_amd import ops
+    from oracle import t5_ref
+    if kind == "tiny":
+        cfg = GDRConfig.tiny()
+    elif kind == "dk64":
+        cfg = GDRConfig.tiny(d_model=128, d_kv=64, num_heads=3, d_ff=256, num_layers=2)
+    else:
+        cfg = GDRConfig.base()
+    sd = synth.make_state_dict(cfg, seed=41, with_decoder=False)
+    ids, mask = synth.make_tokens(B, L=L, vocab_hi=cfg.vocab_size, seed=B * 10 + L, min_len=max(1, L // 3))
+    ti, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    ref32 = t5_ref.encoder_forward(sd, cfg, ti, tm)
+    with t5_ref.bf16_linears():
+        ref16 = t5_ref.encoder_forward(sd, cfg, ti, tm)
+    enc = ops.T5EncoderHandle(cfg, sd, dev, dtype=torch.bfloat16)
+    h, pooled = enc.forward(ti.to(dev), tm.to(dev))
+    hc = h.cpu()
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    e_emul, e_modes = rel(hc, ref16), rel(ref32, ref16)
+    print(f"bf16 mode {kind}: |gpu-emul|/|emul| = {e_emul:.2e}, |fp32-emul|/|emul| = {e_modes:.2e}, "
+          f"max abs gpu-emul {float((hc - ref16).abs().max()):.3e}")
+    if kind == "base":
+        # 12 layers, d = 768: a rounding that flips (the fp32 values feeding it differ in their last bits between two
+        # summation orders) perturbs everything downstream, so two correct bf16 implementations sit about one
+        # bf16-noise level apart (measured 3.0e-3 against 4.9e-3 between the modes).  Bound norm and worst element.
+        assert e_emul < 8e-3 and rel(hc, ref32) < 8e-3 and float((hc - ref16).abs().max()) < 6e-2
+    else:
+        torch.testing.assert_close(hc, ref16, rtol=5e-3, atol=5e-3)
+        assert e_emul < 0.5 * e_modes, "the GPU bf16 path must sit much closer to the bf16 emulation than fp32 does"
+    torch.testing.assert_close(pooled.cpu(), hc[:, 0], rtol=0, atol=0)
+    torch.testing.assert_close(hc, ref32, rtol=1e-1, atol=1e-1)
+
+
 # ------------------------------------------------------------------------------------------- sim + top-k
 def test_sim_topk_c1_vs_reference_golden(dev):
     from gdr_amd import ops
