@@ -81,6 +81,36 @@ def test_linear_splitk_matches_cpu(dev, M, N, K):
     assert torch.equal(out, out) and torch.equal(ops.linear(A, W, splitk_ws=ws).cpu(), out2), "fixed-order reduce is deterministic"
 
 
+@pytest.mark.parametrize("M,N,K", [(8321, 1100, 96), (16500, 520, 64), (20480, 768, 768)])
+def test_linear_persistent_form(dev, M, N, K):
+    """More than 512 tiles takes the persistent kernel (one flattened K-step stream per workgroup across its tiles):
+    ragged edges in both dimensions, every epilogue, in-place residual — and bit-identical to the one-tile-per-workgroup
+    kernel, which the same rows take when the call is cut into slabs of fewer than 512 tiles (same k order per element)."""
+    from gdr_amd import ops, _ffi
+    assert ((M + 127) // 128) * ((N + 127) // 128) > 512
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    A, W, Bv, Rv = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    base = a @ w.T
+    out = ops.linear(A, W)
+    torch.testing.assert_close(out.cpu(), base, rtol=TOL, atol=TOL)
+    rows_per_slab = (500 // ((N + 127) // 128)) * 128
+    slabs = torch.cat([ops.linear(A[i:i + rows_per_slab].contiguous(), W) for i in range(0, M, rows_per_slab)])
+    assert torch.equal(out, slabs), "persistent and one-tile kernels must agree bit for bit"
+    cases = {
+        _ffi.EPI_RELU: (torch.relu(base), {}),
+        _ffi.EPI_BIAS_GELU: (torch.nn.functional.gelu(base + b), dict(bias=Bv)),
+        _ffi.EPI_BIAS_RESIDUAL: (base + b + r, dict(bias=Bv, residual=Rv)),
+    }
+    for epi, (ref, kw) in cases.items():
+        torch.testing.assert_close(ops.linear(A, W, epilogue=epi, **kw).cpu(), ref, rtol=TOL, atol=TOL, msg=f"epilogue {epi}")
+    h = Rv.clone()
+    ops.linear(A, W, epilogue=_ffi.EPI_RESIDUAL, residual=h, out=h)
+    torch.testing.assert_close(h.cpu(), base + r, rtol=TOL, atol=TOL)
+    assert torch.equal(ops.linear(A, W), out), "deterministic"
+
+
 def test_linear_is_exact_fmaf_chain_on_integers(dev):
     """A = I with an asymmetric B catches a transposed accumulator map; integer data must be exact."""
     from gdr_amd import ops
