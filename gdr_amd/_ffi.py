@@ -76,6 +76,7 @@ SIGNATURES = {
     "gdr_prof_enable": (_i, [_i]),
     "gdr_prof_collect": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gdr_linear_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    "gdr_linear_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "gdr_linear_f32_splitk": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "gdr_t5_encoder_workspace_bytes": (_sz, [C.POINTER(GdrT5Dims), _i, _i]),
     "gdr_t5_encoder_forward": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -1,0 +1,172 @@
+// bf16 "NT" linear for gfx950 (C5 precision mode):  C[M,N] fp32 = epilogue(A[M,K] bf16 · W[N,K]^T bf16), fp32 accumulate.
+//
+// At bf16 MFMA rates a 128x128 tile consumes 32 KB of operands per 512 MFMA cycles, so the operand path is the kernel:
+//   * staging is LDS-DMA (`global_load_lds_dwordx4`): no VGPR round trip, no ds_write pass; one wave-instruction
+//     deposits 8 rows x 128 B; the LDS image is lane-linear, so the bank swizzle (16-byte chunk ^ ((row>>1)&7),
+//     conflict-free for the 16 consecutive rows of a ds_read_b128 lane group) is applied to the per-lane SOURCE address
+//     and again on the fragment reads;
+//   * one 32 KB LDS buffer, two barriers per K-step (BK = 64), ~110 VGPRs: three to four workgroups per CU overlap one
+//     another's stage / compute phases instead of an in-kernel software pipeline;
+//   * v_mfma_f32_16x16x32_bf16, 4 waves 2x2, 64x64 per wave = 4x4 accumulator tiles; the W block takes the MFMA "A" role
+//     so that a lane holds 4 consecutive output columns of one row (16-byte epilogue accesses).
+#include "common.h"
+
+namespace gdr {
+
+typedef float f32x4b __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8b __attribute__((ext_vector_type(8)));
+
+struct Bf16GemmArgs {
+  const char* A;  // bf16 [M, lda]
+  const char* W;  // bf16 [N, ldw]
+  float* C;
+  const float* bias;
+  const float* residual;
+  int64_t lda, ldw, ldc, ldr;  // elements
+  int64_t M;
+  int N, K, tiles_n;
+  int has_bias, has_residual, act;  // act: 0 none, 1 relu, 2 gelu
+};
+
+__device__ __forceinline__ float gelu_erf_b(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16GemmArgs g) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 128 * 128];  // As [128 rows][128 B], Bs likewise
+  char* const As = smem;
+  char* const Bs = smem + 128 * 128;
+  unsigned bid = blockIdx.x;
+  {
+    const unsigned nblk = gridDim.x, q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int64_t mt = bid / (unsigned)g.tiles_n;
+  const int nt = bid % (unsigned)g.tiles_n;
+  const int64_t m0 = mt * 128;
+  const int n0 = nt * 128;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, q4 = lane >> 4;
+
+  // ---- staging map: instruction i of this wave covers tile rows (wave*4 + i)*8 .. +7; lane = (row_in, chunk') ----
+  const int srow = lane >> 3, schunk = lane & 7;
+  const char* a_src[4];
+  const char* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + srow;
+    const int chunk = schunk ^ ((row >> 1) & 7);
+    int64_t ra = m0 + row;
+    ra = ra < g.M ? ra : g.M - 1;  // rows past the edge are computed and discarded
+    int rw = n0 + row;
+    rw = rw < g.N ? rw : g.N - 1;
+    a_src[i] = g.A + (ra * g.lda) * 2 + chunk * 16;
+    w_src[i] = g.W + ((int64_t)rw * g.ldw) * 2 + chunk * 16;
+  }
+  // ---- fragment reads: lane (r16, q4) reads 16 B = k 8*q4..+7 of a 32-k half; 4 row blocks of A, 4 of W ----
+  int a_off[4], b_off[4], a_sw[4], b_sw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wm * 64 + i * 16 + r16, rb = wn * 64 + i * 16 + r16;
+    a_off[i] = ra * 128, a_sw[i] = (ra >> 1) & 7;
+    b_off[i] = rb * 128, b_sw[i] = (rb >> 1) & 7;
+  }
+
+  f32x4b acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4b){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K >> 6;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int koff = kt * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(As + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(Bs + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+    __syncthreads();  // emits vmcnt(0): the DMA writes are complete and visible
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      float4 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *reinterpret_cast<const float4*>(As + a_off[i] + (((kk * 4 + q4) ^ a_sw[i]) << 4));
+        fb[i] = *reinterpret_cast<const float4*>(Bs + b_off[i] + (((kk * 4 + q4) ^ b_sw[i]) << 4));
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, fb[ni]),
+                                                                __builtin_bit_cast(bf16x8b, fa[mi]), acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();  // every fragment read done before the next K-step's DMA overwrites the buffer
+  }
+
+  // ---- epilogue: row m = block*16 + lane&15, columns n = block*16 + 4*(lane>>4) + 0..3 ----
+  const bool interior = m0 + 128 <= g.M && n0 + 128 <= g.N && (g.ldc & 3) == 0 &&
+                        (!g.has_residual || (g.ldr & 3) == 0);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int64_t m = m0 + wm * 64 + mi * 16 + r16;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + 4 * q4;
+      float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+      if (interior) {
+        if (g.has_bias) {
+          const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+          v[0] += b.x, v[1] += b.y, v[2] += b.z, v[3] += b.w;
+        }
+        if (g.has_residual) {
+          const float4 r = *reinterpret_cast<const float4*>(g.residual + m * g.ldr + n);
+          v[0] += r.x, v[1] += r.y, v[2] += r.z, v[3] += r.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (g.act == 1) v[j] = fmaxf(v[j], 0.f);
+          if (g.act == 2) v[j] = gelu_erf_b(v[j]);
+        }
+        *reinterpret_cast<float4*>(g.C + m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (m >= g.M || n + j >= g.N) continue;
+          float x = v[j];
+          if (g.has_bias) x += g.bias[n + j];
+          if (g.has_residual) x += g.residual[m * g.ldr + n + j];
+          if (g.act == 1) x = fmaxf(x, 0.f);
+          if (g.act == 2) x = gelu_erf_b(x);
+          g.C[m * g.ldc + n + j] = x;
+        }
+      }
+    }
+  }
+}
+
+// Returns 1 if the shape is not served here (caller falls back to the generic core), 0 on launch, < 0 on error.
+int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
+                            int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
+                            int64_t ldr, hipStream_t stream) {
+  if (K % 64 != 0 || lda % 8 != 0 || ldw % 8 != 0) return 1;
+  if (((uintptr_t)C & 15) || (has_bias && ((uintptr_t)bias & 15)) || (has_residual && ((uintptr_t)residual & 15))) return 1;
+  Bf16GemmArgs g{};
+  g.A = static_cast<const char*>(A), g.W = static_cast<const char*>(W), g.C = C, g.bias = bias, g.residual = residual;
+  g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr, g.M = M, g.N = N, g.K = K;
+  g.tiles_n = (N + 127) / 128;
+  g.has_bias = has_bias, g.has_residual = has_residual, g.act = act;
+  const int64_t blocks = ((M + 127) / 128) * g.tiles_n;
+  if (blocks <= 0) return 0;
+  if (blocks > 0x7fffffffLL) {
+    set_error("linear_bf16: grid too large");
+    return GDR_EINVAL;
+  }
+  hipLaunchKernelGGL(gemm_nt_bf16_glds_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  GDR_CHECK_LAUNCH("gemm_nt_bf16_glds_kernel");
+  return 0;
+}
+
+}  // namespace gdr

@@ -784,6 +784,15 @@ int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, f
           : epilogue == GDR_EPI_BIAS_GELU                             ? ACT_GELU
                                                                       : ACT_NONE;
   ProfScope prof(PROF_LINEAR, 2.0 * (double)M * (double)N * (double)K, stream);
+  static const bool glds_on = [] {
+    const char* e = getenv("GDR_BF16_GLDS");  // A/B knob: 0 = the generic register-staged core
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (glds_on) {
+    const int rc = launch_linear_bf16_glds(A, lda, W, ldw, C, ldc, M, N, K, needs_bias, needs_res, g.act, bias, residual, ldr,
+                                           stream);
+    if (rc <= 0) return rc;
+  }
   return launch<EPI_LINEAR, true>(g, (M + BM - 1) / BM, stream);
 }
 
@@ -825,4 +834,11 @@ extern "C" int gdr_linear_f32_splitk(const float* A, int64_t lda, const float* W
                                      int64_t ldr, void* workspace, size_t workspace_bytes, void* stream) {
   return gdr::launch_linear_f32_ws(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, residual, ldr,
                                    static_cast<float*>(workspace), workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gdr_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
+                               int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
+                               void* stream) {
+  return gdr::launch_linear_bf16(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, residual, ldr,
+                                 static_cast<hipStream_t>(stream));
 }

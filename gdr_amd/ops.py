@@ -44,6 +44,24 @@ def linear(a, w, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None, spl
     return out.view(*a.shape[:-1], N)
 
 
+def linear_bf16(a, w, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None):
+    """out[M,N] fp32 = epilogue(a[M,K] @ w[N,K].T) with bf16 operands (fp32 tensors are rounded on the device first) and
+    fp32 accumulate — gdr_linear_bf16, the linear of the C5 precision mode."""
+    _need_cuda(a, w, bias, residual)
+    a = (a if a.dtype == torch.bfloat16 else to_bf16(a)).contiguous()
+    w = (w if w.dtype == torch.bfloat16 else to_bf16(w)).contiguous()
+    K = a.shape[-1]
+    a2 = a.view(-1, K)
+    M, N = a2.shape[0], w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    res2 = _f32c(residual).view(-1, N) if residual is not None else None
+    check(lib().gdr_linear_bf16(ptr(a2), K, ptr(w), w.shape[1], ptr(out), N, M, N, K, epilogue,
+                                ptr(_f32c(bias)) if bias is not None else None, ptr(res2), N, stream_ptr()),
+          "gdr_linear_bf16")
+    return out.view(*a.shape[:-1], N)
+
+
 class Workspace:
     """Grow-only device scratch buffer (256-byte aligned by the caching allocator)."""
 

@@ -71,6 +71,12 @@ int gdr_linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t l
                           int64_t M, int N, int K, int epilogue, const float* bias, const float* residual,
                           int64_t ldr, void* workspace, size_t workspace_bytes, void* stream);
 
+/* bf16 operands (A [M,K], W [N,K] bf16, round-to-nearest-even of the fp32 tensors), fp32 accumulate, epilogue and output:
+ * the linear of the opt-in bf16 precision mode (BASELINE config C5; the reference itself runs precision=32).  K, lda,
+ * ldw multiples of 8.  K % 64 == 0 takes the LDS-DMA kernel (gemm_bf16.hip), other K the generic core. */
+int gdr_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
+                    int K, int epilogue, const float* bias, const float* residual, int64_t ldr, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * T5 encoder forward — replaces `model.get_encoder()(input_ids, attention_mask=, return_dict=True)
  * .last_hidden_state` (transformers/modeling_t5.py:685-821; called at generation_utils.py:410-411).

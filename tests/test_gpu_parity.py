@@ -111,6 +111,37 @@ def test_linear_persistent_form(dev, M, N, K):
     assert torch.equal(ops.linear(A, W), out), "deterministic"
 
 
+@pytest.mark.parametrize("M,N,K", [(5, 7, 64), (130, 129, 128), (257, 300, 768), (1000, 64, 3072), (4100, 2304, 768),
+                                   (130, 129, 96), (40, 72, 8)])
+def test_linear_bf16_matches_cpu_on_rounded_operands(dev, M, N, K):
+    """gdr_linear_bf16: K % 64 == 0 takes the LDS-DMA kernel (source-side bank swizzle, 16x16x32 MFMA), other K the
+    generic core.  Reference: fp32 matmul of the bf16-rounded operands (products of bf16 values are exact in fp32, so
+    only the summation order differs)."""
+    from gdr_amd import ops, _ffi
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ar, wr = a.bfloat16().float(), w.bfloat16().float()
+    base = ar @ wr.T
+    A, W, Bv, Rv = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    torch.testing.assert_close(ops.linear_bf16(A, W).cpu(), base, rtol=TOL, atol=TOL)
+    torch.testing.assert_close(ops.linear_bf16(A, W, epilogue=_ffi.EPI_BIAS_GELU, bias=Bv).cpu(),
+                               torch.nn.functional.gelu(base + b), rtol=TOL, atol=TOL)
+    h = Rv.clone()
+    ops.linear_bf16(A, W, epilogue=_ffi.EPI_RESIDUAL, residual=h, out=h)
+    torch.testing.assert_close(h.cpu(), base + r, rtol=TOL, atol=TOL)
+    torch.testing.assert_close(ops.linear_bf16(A, W, epilogue=_ffi.EPI_RELU).cpu(), torch.relu(base), rtol=TOL, atol=TOL)
+
+
+def test_linear_bf16_accumulator_map_on_integers(dev):
+    """A = I with an asymmetric B: exact in bf16, catches a transposed accumulator map or a wrong swizzle."""
+    from gdr_amd import ops
+    n = 192
+    a = torch.eye(n)
+    w = (torch.arange(n * n, dtype=torch.float32).view(n, n) % 127) - 60.0
+    assert torch.equal(ops.linear_bf16(a.to(dev), w.to(dev)).cpu(), w.T.contiguous())
+
+
 def test_linear_is_exact_fmaf_chain_on_integers(dev):
     """A = I with an asymmetric B catches a transposed accumulator map; integer data must be exact."""
     from gdr_amd import ops
