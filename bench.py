@@ -192,7 +192,7 @@ def main():
                        "all-gather of queries and of per-shard top-k, local merge"),
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 40,
                        "corpus_rows": a.corpus, "dim": cfg.d_model, "k": a.k, "corpus_resident_in_hbm": True},
-            "roofline": {"bound": "mfma", "kernel": ("gdr::gemm_nt_f32_kernel<0, true> (bf16 operands; every encoder linear)"
+            "roofline": {"bound": "mfma", "kernel": ("gdr::gemm_nt_bf16_glds_kernel (bf16 operands, LDS-DMA staging; every encoder linear)"
                                                      if bf16 else "gdr::gemm_nt_f32_persistent_kernel (every encoder linear)"),
                          "achieved": lin["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS if bf16 else F32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s",

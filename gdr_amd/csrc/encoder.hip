@@ -95,9 +95,35 @@ static int t5_encoder_impl(const GdrT5EncoderWeights* w, const int64_t* ids, con
   at.key_mask = mask, at.mask_bstride = L, at.causal = 0, at.causal_neg_inf = 0;
   at.kv_rows = nullptr, at.kv_group = 1;
 
+  // bf16 mode, fused form (every contraction length a multiple of 64, so the LDS-DMA linear serves all four): the
+  // producers write the bf16 operand of the next linear directly — RMSNorm, the attention context and the ReLU
+  // epilogue of wi — instead of fp32 + a cast pass.  Rounding points are the same as in the cast form.
+  const bool fused16 = bf16 && d % 64 == 0 && inner % 64 == 0 && dm.d_ff % 64 == 0 && (((uintptr_t)w->layers[0].wqkv) & 15) == 0;
+  auto lin16 = [&](const void* A, const float* W, float* C, int64_t ldc, int N, int K, int act, const float* residual,
+                   int out_bf16) -> int {
+    ProfScope prof(PROF_LINEAR, 2.0 * (double)M * (double)N * (double)K, stream);
+    const int rc_ = launch_linear_bf16_glds(A, K, W, K, C, ldc, M, N, K, 0, residual != nullptr, act, nullptr, residual, ldc,
+                                            out_bf16, stream);
+    if (rc_ > 0) {
+      set_error("t5_encoder_bf16: shape not served by the LDS-DMA linear");
+      return GDR_EINVAL;
+    }
+    return rc_;
+  };
   for (int i = 0; i < dm.num_layers; ++i) {
     const GdrT5EncLayer& ly = w->layers[i];
     GDR_CHECK_ARG(ly.ln_attn && ly.wqkv && ly.wo && ly.ln_ff && ly.wi && ly.wo_ff, "t5_encoder: layer %d null weight", i);
+    if (fused16) {
+      if ((rc = launch_rmsnorm_bf16(h, ly.ln_attn, abf, M, d, dm.eps, stream))) return rc;
+      if ((rc = lin16(abf, ly.wqkv, qkv, 3 * inner, 3 * inner, d, 0, nullptr, 0))) return rc;
+      at.out_bf16 = abf;  // ctx as bf16 [M, inner] (nx is dead)
+      if ((rc = launch_attention(at, stream))) return rc;
+      if ((rc = lin16(abf, ly.wo, h, d, d, inner, 0, h, 0))) return rc;
+      if ((rc = launch_rmsnorm_bf16(h, ly.ln_ff, abf, M, d, dm.eps, stream))) return rc;
+      if ((rc = lin16(abf, ly.wi, ff, dm.d_ff, dm.d_ff, d, 1, nullptr, 1))) return rc;  // relu, bf16 out (in the fp32 ff buffer)
+      if ((rc = lin16(ff, ly.wo_ff, h, d, d, dm.d_ff, 0, h, 0))) return rc;
+      continue;
+    }
     if ((rc = launch_rmsnorm(h, ly.ln_attn, nx, M, d, dm.eps, nullptr, 1, stream))) return rc;
     if ((rc = linear(nx, d, ly.wqkv, qkv, 3 * inner, 3 * inner, d, GDR_EPI_NONE, nullptr))) return rc;
     if ((rc = launch_attention(at, stream))) return rc;

@@ -19,13 +19,14 @@ typedef __bf16 bf16x8b __attribute__((ext_vector_type(8)));
 struct Bf16GemmArgs {
   const char* A;  // bf16 [M, lda]
   const char* W;  // bf16 [N, ldw]
-  float* C;
+  float* C;       // fp32 [M, ldc], or bf16 [M, ldc] when out_bf16 (the output only feeds another bf16 linear)
   const float* bias;
   const float* residual;
   int64_t lda, ldw, ldc, ldr;  // elements
   int64_t M;
   int N, K, tiles_n;
   int has_bias, has_residual, act;  // act: 0 none, 1 relu, 2 gelu
+  int out_bf16;
 };
 
 __device__ __forceinline__ float gelu_erf_b(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -130,7 +131,16 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
           if (g.act == 1) v[j] = fmaxf(v[j], 0.f);
           if (g.act == 2) v[j] = gelu_erf_b(v[j]);
         }
-        *reinterpret_cast<float4*>(g.C + m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.out_bf16) {
+          union {
+            __bf16 h[4];
+            uint2 u;
+          } o;
+          o.h[0] = (__bf16)v[0], o.h[1] = (__bf16)v[1], o.h[2] = (__bf16)v[2], o.h[3] = (__bf16)v[3];
+          *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(g.C) + m * g.ldc + n) = o.u;
+        } else {
+          *reinterpret_cast<float4*>(g.C + m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -140,7 +150,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
           if (g.has_residual) x += g.residual[m * g.ldr + n + j];
           if (g.act == 1) x = fmaxf(x, 0.f);
           if (g.act == 2) x = gelu_erf_b(x);
-          g.C[m * g.ldc + n + j] = x;
+          if (g.out_bf16)
+            reinterpret_cast<__bf16*>(g.C)[m * g.ldc + n + j] = (__bf16)x;
+          else
+            g.C[m * g.ldc + n + j] = x;
         }
       }
     }
@@ -150,14 +163,14 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
 // Returns 1 if the shape is not served here (caller falls back to the generic core), 0 on launch, < 0 on error.
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
-                            int64_t ldr, hipStream_t stream) {
+                            int64_t ldr, int out_bf16, hipStream_t stream) {
   if (K % 64 != 0 || lda % 8 != 0 || ldw % 8 != 0) return 1;
   if (((uintptr_t)C & 15) || (has_bias && ((uintptr_t)bias & 15)) || (has_residual && ((uintptr_t)residual & 15))) return 1;
   Bf16GemmArgs g{};
   g.A = static_cast<const char*>(A), g.W = static_cast<const char*>(W), g.C = C, g.bias = bias, g.residual = residual;
   g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr, g.M = M, g.N = N, g.K = K;
   g.tiles_n = (N + 127) / 128;
-  g.has_bias = has_bias, g.has_residual = has_residual, g.act = act;
+  g.has_bias = has_bias, g.has_residual = has_residual, g.act = act, g.out_bf16 = out_bf16;
   const int64_t blocks = ((M + 127) / 128) * g.tiles_n;
   if (blocks <= 0) return 0;
   if (blocks > 0x7fffffffLL) {

@@ -789,7 +789,7 @@ int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, f
     return e ? atoi(e) != 0 : true;
   }();
   if (glds_on) {
-    const int rc = launch_linear_bf16_glds(A, lda, W, ldw, C, ldc, M, N, K, needs_bias, needs_res, g.act, bias, residual, ldr,
+    const int rc = launch_linear_bf16_glds(A, lda, W, ldw, C, ldc, M, N, K, needs_bias, needs_res, g.act, bias, residual, ldr, 0,
                                            stream);
     if (rc <= 0) return rc;
   }

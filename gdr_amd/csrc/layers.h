@@ -17,6 +17,8 @@ struct AttnArgs {
   const float* k;  // row (b*k_bstride + j)
   const float* v;
   float* out;      // row (b*o_bstride + i), head h at column h*dk
+  void* out_bf16;  // when non-null the context is written here as bf16 (same indexing, ldo in elements) instead of `out`:
+                   // it only feeds the next linear of the bf16 precision mode.  Not supported by the Lq = 1 decode form.
   int64_t ldq, ldk, ldv, ldo;          // row strides in floats
   int64_t q_bstride, k_bstride, o_bstride;  // rows per batch entry
   int B, H, dk, Lq, Lk;
@@ -42,6 +44,8 @@ int launch_embed(const float* table, const int64_t* ids, int64_t rows, int d, in
 // `pooled` receives rows r with r % pool_every == 0 (CLS pool h[:,0]) when non-null.
 int launch_rmsnorm(const float* x, const float* w, float* y, int64_t rows, int d, float eps, float* pooled,
                    int pool_every, hipStream_t stream);
+// same, output rounded to bf16 (RNE): the activation operand of a bf16-mode linear
+int launch_rmsnorm_bf16(const float* x, const float* w, void* y_bf16, int64_t rows, int d, float eps, hipStream_t stream);
 // y = (x - mean) / sqrt(var + eps) * w + b   (torch.nn.LayerNorm; BERT / nn.TransformerDecoderLayer)
 // optional addv [d]: y = LN(x + addv)  (the adaptor's constant single-key cross-attention output)
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int d, float eps,

@@ -63,6 +63,16 @@ int launch_embed(const float* table, const int64_t* ids, int64_t rows, int d, in
 }
 
 // ------------------------------------------------------------------------------------------ norms
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
+  union {
+    __bf16 h[4];
+    uint2 u;
+  } o;
+  o.h[0] = (__bf16)a, o.h[1] = (__bf16)b, o.h[2] = (__bf16)c, o.h[3] = (__bf16)d;  // v_cvt_pk_bf16_f32: RNE
+  return o.u;
+}
+
+template <bool BF16OUT>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       float* __restrict__ y, int64_t rows, int d4, float eps,
                                                       float* __restrict__ pooled, int pool_every) {
@@ -85,8 +95,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     const float4 v = xr[c], g = wr[c];
     float4 o;
     o.x = g.x * (v.x / denom), o.y = g.y * (v.y / denom), o.z = g.z * (v.z / denom), o.w = g.w * (v.w / denom);
-    yr[c] = o;
-    if (pr) pr[c] = o;
+    if (BF16OUT) {
+      (reinterpret_cast<uint2*>(y) + row * d4)[c] = pack_bf16x4(o.x, o.y, o.z, o.w);
+    } else {
+      yr[c] = o;
+      if (pr) pr[c] = o;
+    }
   }
 }
 
@@ -94,9 +108,18 @@ int launch_rmsnorm(const float* x, const float* w, float* y, int64_t rows, int d
                    int pool_every, hipStream_t stream) {
   GDR_CHECK_ARG(d % 4 == 0, "rmsnorm: d %% 4 != 0");
   if (rows == 0) return GDR_OK;
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, y, rows, d / 4, eps,
+  hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, y, rows, d / 4, eps,
                      pooled, pool_every > 0 ? pool_every : 1);
   GDR_CHECK_LAUNCH("rmsnorm_kernel");
+  return GDR_OK;
+}
+
+int launch_rmsnorm_bf16(const float* x, const float* w, void* y_bf16, int64_t rows, int d, float eps, hipStream_t stream) {
+  GDR_CHECK_ARG(d % 4 == 0, "rmsnorm: d %% 4 != 0");
+  if (rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w,
+                     static_cast<float*>(y_bf16), rows, d / 4, eps, (float*)nullptr, 1);
+  GDR_CHECK_LAUNCH("rmsnorm_kernel<bf16>");
   return GDR_OK;
 }
 
@@ -264,7 +287,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
           o = fmaf(pp.w * inv, Vs[(j + 3) * dks + d], o);
         }
         for (; j < Lk; ++j) o = fmaf(ps[j] * inv, Vs[j * dks + d], o);
-        orow[d] = o;
+        if (a.out_bf16)
+          static_cast<__bf16*>(a.out_bf16)[((int64_t)b * a.o_bstride + i) * a.ldo + h * dk + d] = (__bf16)o;
+        else
+          orow[d] = o;
       }
     }
     __syncthreads();  // before the next row overwrites qs / ps
@@ -404,7 +430,10 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma_kernel(const AttnArgs 
       for (int q4 = 0; q4 < 4; ++q4) {
         float4 ov;
         ov.x = o[4 * q4 + 0] * inv, ov.y = o[4 * q4 + 1] * inv, ov.z = o[4 * q4 + 2] * inv, ov.w = o[4 * q4 + 3] * inv;
-        *reinterpret_cast<float4*>(orow + 8 * q4) = ov;
+        if (a.out_bf16)
+          *reinterpret_cast<uint2*>(static_cast<__bf16*>(a.out_bf16) + (orow - a.out) + 8 * q4) = pack_bf16x4(ov.x, ov.y, ov.z, ov.w);
+        else
+          *reinterpret_cast<float4*>(orow + 8 * q4) = ov;
       }
     }
   }
@@ -517,6 +546,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   GDR_CHECK_ARG(a.kv_group >= 1, "attention: kv_group must be >= 1");
   if (a.B == 0 || a.Lq == 0) return GDR_OK;
   ProfScope prof(PROF_ATTENTION, 4.0 * a.B * a.H * (double)a.Lq * a.Lk * a.dk, stream);
+  GDR_CHECK_ARG(!a.out_bf16 || a.Lq > 1, "attention: bf16 output is not available in the Lq = 1 decode form");
   if (a.Lq == 1) {
     hipLaunchKernelGGL(attention_decode_kernel, dim3((unsigned)((a.B * a.H + 3) / 4)), dim3(256), 0, stream, a);
     GDR_CHECK_LAUNCH("attention_decode_kernel");

@@ -204,7 +204,8 @@ def test_encoder_dk64_mfma_attention_vs_oracle(dev, B, L):
     torch.testing.assert_close(h.cpu(), ref, rtol=TOL, atol=TOL)
 
 
-@pytest.mark.parametrize("kind,B,L", [("tiny", 3, 5), ("tiny", 7, 40), ("dk64", 3, 33), ("dk64", 2, 128), ("base", 4, 40)])
+@pytest.mark.parametrize("kind,B,L", [("tiny", 3, 5), ("tiny", 7, 40), ("dk64", 3, 33), ("dk64", 2, 128), ("base", 4, 40),
+                                      ("odd", 5, 17)])
 def test_encoder_bf16_mode_vs_oracle_emulation(dev, kind, B, L):
     """C5 precision mode (gdr_t5_encoder_forward_bf16): linear operands rounded to bf16, fp32 accumulate, everything else
     fp32.  Tight against the oracle's emulation of exactly that (same rounding points; a few activations may round the
@@ -215,6 +216,8 @@ def test_encoder_bf16_mode_vs_oracle_emulation(dev, kind, B, L):
         cfg = GDRConfig.tiny()
     elif kind == "dk64":
         cfg = GDRConfig.tiny(d_model=128, d_kv=64, num_heads=3, d_ff=256, num_layers=2)
+    elif kind == "odd":    # contraction lengths that are not multiples of 64: the unfused form (cast pass + generic core)
+        cfg = GDRConfig.tiny(d_model=96, d_kv=24, num_heads=3, d_ff=160, num_layers=2)
     else:
         cfg = GDRConfig.base()
     sd = synth.make_state_dict(cfg, seed=41, with_decoder=False)
