@@ -5,6 +5,8 @@
 // global accesses, wave64 shuffle reductions, no score matrix in HBM.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "layers.h"
 
 namespace gdr {
@@ -458,6 +460,153 @@ static int launch_attention_mfma(const AttnArgs& a, hipStream_t stream) {
 }
 
 
+// The same attention on v_mfma_f32_16x16x4_f32: 16-query tiles (one wave each) against 16-key tiles.  With 32-wide
+// tiles a T5 query batch of L = 40 computes 64 x 64 scores per head to use 40 x 40 (61 % of the matrix work is
+// padding); 16-wide tiles compute 48 x 48.  Same staging, same arithmetic and the same tricks: S^T = K·Q^T so that a lane
+// holds scores of ONE query (4 lanes share a query: lane>>4 picks 4 of every 16 keys; max / sum need two shuffles), and
+// the probability registers are the B operand of the PV MFMAs as they stand (MFMA step s contracts keys 16t + 4q + s,
+// which is register s of lane-quarter q; the A operand reads V[that key][d] from LDS).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int NT>  // 16-key tiles = 16-query tiles = waves per workgroup: ceil(L / 16), 1..8
+__global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int DK = 64, DS = DK + 4, LP = 16 * NT, NTHR = 64 * NT;
+  const int Lr = a.Lk;
+  float* Qs = smem;
+  float* Ks = Qs + Lr * DS;
+  float* Vs = Ks + Lr * DS;
+  float* RelB = Vs + Lr * DS;   // [2*LP]
+  float* Mk = RelB + 2 * LP;    // [LP]
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int L = a.Lk, tid = threadIdx.x;
+  for (int e = tid; e < 2 * LP; e += NTHR) {
+    float v = 0.f;
+    if (a.rel_bias) {
+      int n = e - (LP - 1), bucket = 0;
+      if (a.bidirectional) {
+        if (n < 0) {
+          bucket = a.num_buckets >> 1;
+          n = -n;
+        }
+      } else if (n < 0) {
+        n = 0;
+      }
+      bucket += a.lut.v[n < 127 ? n : 127];
+      v = a.rel_bias[bucket * a.H + h];
+    }
+    RelB[e] = v;
+  }
+  for (int j = tid; j < LP; j += NTHR) {
+    float v = -INFINITY;
+    if (j < L) v = (a.key_mask && a.key_mask[(int64_t)b * a.mask_bstride + j] == 0) ? (a.causal_neg_inf ? -INFINITY : -1e9f) : 0.f;
+    Mk[j] = v;
+  }
+  for (int e = tid; e < L * (DK / 4); e += NTHR) {
+    const int r = e >> 4, c = e & 15;
+    float4 q = *reinterpret_cast<const float4*>(a.q + ((int64_t)b * a.q_bstride + r) * a.ldq + h * DK + 4 * c);
+    const float4 k = *reinterpret_cast<const float4*>(a.k + ((int64_t)b * a.k_bstride + r) * a.ldk + h * DK + 4 * c);
+    const float4 v = *reinterpret_cast<const float4*>(a.v + ((int64_t)b * a.k_bstride + r) * a.ldv + h * DK + 4 * c);
+    q.x *= a.scale, q.y *= a.scale, q.z *= a.scale, q.w *= a.scale;
+    *reinterpret_cast<float4*>(Qs + r * DS + 4 * c) = q;
+    *reinterpret_cast<float4*>(Ks + r * DS + 4 * c) = k;
+    *reinterpret_cast<float4*>(Vs + r * DS + 4 * c) = v;
+  }
+  __syncthreads();
+
+  const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, q4 = lane >> 4;
+  f32x4_t st[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) st[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // ---- S^T tiles: A = K rows (keys), B = Q rows (queries); d index permuted inside chunks of 16 (element s of the
+  //      float4 read at d = 16*jj + 4*q4 is the operand of MFMA step s) identically on both operands
+  const float* qrow = Qs + min(16 * w + c16, L - 1) * DS + 4 * q4;
+#pragma unroll
+  for (int jj = 0; jj < DK / 16; ++jj) {
+    const float4 qv = *reinterpret_cast<const float4*>(qrow + 16 * jj);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 kv = *reinterpret_cast<const float4*>(Ks + min(16 * t + c16, L - 1) * DS + 4 * q4 + 16 * jj);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qv.x, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qv.y, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qv.z, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qv.w, st[t], 0, 0, 0);
+    }
+  }
+  // ---- bias + mask + softmax over keys: this lane holds keys 16t + 4*q4 + r of query i
+  const int i = 16 * w + c16;
+  const float masked = a.causal_neg_inf ? -INFINITY : -1e9f;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * t + 4 * q4 + r;
+      float add = RelB[i - j + (LP - 1)] + Mk[j];          // (bias + mask) first, as the reference (modeling_t5.py:399-400)
+      if (a.causal && j > i && Mk[j] == 0.f) add += masked;  // one -1e9 per masked key, never two
+      const float s = st[t][r] + add;
+      st[t][r] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = __expf(st[t][r] - mx);  // padded keys: exp(-inf) = 0
+      st[t][r] = p;
+      sum += p;
+    }
+  }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  // ---- O^T = V^T · P^T, four 16-wide d tiles: lane ends with d = 16*dt + 4*q4 + 0..3 of its query
+#pragma unroll
+  for (int dt = 0; dt < DK / 16; ++dt) {
+    f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * t + 4 * q4 + r;
+        const float vv = Vs[min(j, L - 1) * DS + 16 * dt + c16];
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, st[t][r], o, 0, 0, 0);
+      }
+    }
+    if (i < L) {
+      const int64_t off = ((int64_t)b * a.o_bstride + i) * a.ldo + h * DK + 16 * dt + 4 * q4;
+      const float4 ov = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+      if (a.out_bf16)
+        *reinterpret_cast<uint2*>(static_cast<__bf16*>(a.out_bf16) + off) = pack_bf16x4(ov.x, ov.y, ov.z, ov.w);
+      else
+        *reinterpret_cast<float4*>(a.out + off) = ov;
+    }
+  }
+}
+
+template <int NT>
+static int launch_attention_mfma16(const AttnArgs& a, hipStream_t stream) {
+  const size_t lds = sizeof(float) * ((size_t)3 * a.Lk * 68 + 3 * 16 * NT);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma16_kernel<NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return GDR_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attention_mfma16_kernel<NT>, dim3((unsigned)(a.B * a.H)), dim3(64 * NT), lds, stream, a);
+  GDR_CHECK_LAUNCH("attention_mfma16_kernel");
+  return GDR_OK;
+}
+
+
 // ------------------------------------------------------------------------------------------ attention, Lq == 1
 // Decode-time attention (one query row per batch entry): one WAVE per (row, head), four per workgroup, nothing
 // staged in LDS.  Lane j scores key j (and j+64): its K row is read with 16-byte loads (L2-resident cache / cross
@@ -553,6 +702,22 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     return GDR_OK;
   }
   if (a.Lq == a.Lk && a.q_pos0 == 0 && !a.kv_rows && a.kv_group == 1 && !a.q_same_pos && a.dk == 64 && a.ldo % 4 == 0) {
+    static const bool tiles16 = [] {
+      const char* e = getenv("GDR_ATTN_MFMA16");  // A/B knob: 0 = 32x32x2 tiles
+      return e ? atoi(e) != 0 : true;
+    }();
+    if (tiles16) {
+      switch ((a.Lk + 15) / 16) {
+        case 1: return launch_attention_mfma16<1>(a, stream);
+        case 2: return launch_attention_mfma16<2>(a, stream);
+        case 3: return launch_attention_mfma16<3>(a, stream);
+        case 4: return launch_attention_mfma16<4>(a, stream);
+        case 5: return launch_attention_mfma16<5>(a, stream);
+        case 6: return launch_attention_mfma16<6>(a, stream);
+        case 7: return launch_attention_mfma16<7>(a, stream);
+        default: return launch_attention_mfma16<8>(a, stream);
+      }
+    }
     switch ((a.Lk + 31) / 32) {
       case 1: return launch_attention_mfma<1>(a, stream);
       case 2: return launch_attention_mfma<2>(a, stream);
