@@ -38,13 +38,13 @@ def decode_token(a, b=None, **kw):
     if torch.is_tensor(seqs):
         seqs = seqs.cpu().numpy()
     result = []
-    for seq in np.asarray(seqs):
-        lst = seq.tolist()
-        if 1 in lst:
-            seq = seq[1:lst.index(1)]
-        offset = np.arange(len(seq)) * V + 2 if position else 2
-        res = seq - offset
-        result.append(("-" if kary else "").join(str(c) for c in res))
+    sep = "-" if kary else ""
+    for lst in np.asarray(seqs).tolist():        # plain Python ints: str() of numpy scalars dominated this loop
+        body = lst[1:lst.index(1)] if 1 in lst else lst
+        if position:
+            result.append(sep.join([str(t - (i * V + 2)) for i, t in enumerate(body)]))
+        else:
+            result.append(sep.join([str(t - 2) for t in body]))
     return result
 
 
