@@ -66,6 +66,9 @@ int launch_sim_gemm(const void* D, int64_t N, const void* Q, int B, int d, const
 
 int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                        int K, int epilogue, const float* bias, const float* residual, int64_t ldr, hipStream_t stream);
+int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
+                            int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
+                            int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream);
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, int out_bf16, hipStream_t stream);

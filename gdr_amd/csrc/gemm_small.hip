@@ -1,0 +1,202 @@
+// fp32 "NT" linear for grids that cannot fill the chip with 128x128 tiles (decode: M = batch*beams rows).
+//
+// 64x64 output tiles: four times the workgroups of the 128x128 core for the same problem, so far fewer (or no) K splits
+// are needed to occupy 256 CUs and the partial slabs that a split costs are a quarter of the size.  A decode-step linear
+// is ~1 GFLOP: the launch is over in microseconds and what matters is how evenly the work lands on the SIMDs, not the
+// last percent of a steady-state loop — hence the plain structure: 4 waves 2x2, one 32x32 accumulator tile per wave
+// (v_mfma_f32_32x32x2_f32, same k order per output element as the big core), register-staged double-buffered LDS
+// (36.9 KB -> 4 workgroups per CU), one barrier per K-step, latency hidden by occupancy.
+// Split-K: block (tile, s) accumulates K range [s*kchunk, (s+1)*kchunk) and stores a raw 64x64 partial slab; a second
+// kernel sums the slabs in fixed order s = 0..S-1 (deterministic) and applies the epilogue.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace gdr {
+
+typedef float f32x16m __attribute__((ext_vector_type(16)));
+
+constexpr int SB = 64, SBK = 32, SLD = SBK + 4;
+
+struct SmallGemmArgs {
+  const float* A;
+  const float* W;
+  float* C;        // output, or the slab scratch when ksplit > 1
+  const float* bias;
+  const float* residual;
+  int64_t lda, ldw, ldc, ldr;
+  int64_t M;
+  int N, K, tiles_n;
+  int has_bias, has_residual, act;  // 0 none, 1 relu, 2 gelu
+  int ksplit, kchunk;               // kchunk in elements, multiple of 32
+};
+
+__device__ __forceinline__ float gelu_erf_s(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__global__ __launch_bounds__(256, 4) void gemm_nt_f32_small_kernel(const SmallGemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * SB * SLD];
+  float* const As = smem;
+  float* const Bs = smem + 2 * SB * SLD;
+  unsigned bid = blockIdx.x;
+  {
+    const unsigned nblk = gridDim.x, q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int split = bid % (unsigned)g.ksplit;  // the splits of one tile are neighbours (same XCD: shared operand panels)
+  const unsigned tile = bid / (unsigned)g.ksplit;
+  const int64_t m0 = (int64_t)(tile / (unsigned)g.tiles_n) * SB;
+  const int n0 = (int)(tile % (unsigned)g.tiles_n) * SB;
+  const int tid = threadIdx.x;
+  // staging: 8 lanes cover one 128-B row segment, 32 rows per pass, 2 passes per operand
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+  const float* a_src[2];
+  const float* w_src[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    int64_t ra = m0 + lrow + 32 * p;
+    ra = ra < g.M ? ra : g.M - 1;
+    int rw = n0 + lrow + 32 * p;
+    rw = rw < g.N ? rw : g.N - 1;
+    a_src[p] = g.A + ra * g.lda + lcol + (int64_t)split * g.kchunk;
+    w_src[p] = g.W + (int64_t)rw * g.ldw + lcol + (int64_t)split * g.kchunk;
+  }
+  const int st_off = lrow * SLD + lcol;
+  const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int a_rd = (wm * 32 + l31) * SLD + 4 * h;
+  const int b_rd = (wn * 32 + l31) * SLD + 4 * h;
+  int klen = g.K - split * g.kchunk;
+  klen = klen < g.kchunk ? klen : g.kchunk;
+  const int nk = klen / SBK;  // the launcher guarantees K % 32 == 0
+
+  f32x16m acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 ra0, ra1, rb0, rb1;
+  ra0 = *reinterpret_cast<const float4*>(a_src[0]), ra1 = *reinterpret_cast<const float4*>(a_src[1]);
+  rb0 = *reinterpret_cast<const float4*>(w_src[0]), rb1 = *reinterpret_cast<const float4*>(w_src[1]);
+  *reinterpret_cast<float4*>(As + st_off) = ra0, *reinterpret_cast<float4*>(As + st_off + 32 * SLD) = ra1;
+  *reinterpret_cast<float4*>(Bs + st_off) = rb0, *reinterpret_cast<float4*>(Bs + st_off + 32 * SLD) = rb1;
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const int nxt = kt + 1 < nk ? kt + 1 : kt;  // the last step re-fetches its own tile: in bounds, never used
+    ra0 = *reinterpret_cast<const float4*>(a_src[0] + nxt * SBK), ra1 = *reinterpret_cast<const float4*>(a_src[1] + nxt * SBK);
+    rb0 = *reinterpret_cast<const float4*>(w_src[0] + nxt * SBK), rb1 = *reinterpret_cast<const float4*>(w_src[1] + nxt * SBK);
+    const float* a = As + buf * SB * SLD + a_rd;
+    const float* b = Bs + buf * SB * SLD + b_rd;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {  // k permuted inside chunks of 8 exactly as in gemm_f32.hip
+      const float4 av = *reinterpret_cast<const float4*>(a + 8 * jj);
+      const float4 bv = *reinterpret_cast<const float4*>(b + 8 * jj);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    float* as = As + (buf ^ 1) * SB * SLD + st_off;
+    float* bs = Bs + (buf ^ 1) * SB * SLD + st_off;
+    *reinterpret_cast<float4*>(as) = ra0, *reinterpret_cast<float4*>(as + 32 * SLD) = ra1;
+    *reinterpret_cast<float4*>(bs) = rb0, *reinterpret_cast<float4*>(bs + 32 * SLD) = rb1;
+    __syncthreads();
+  }
+  // accumulator map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (g.ksplit > 1) {
+    float* slab = g.C + ((int64_t)tile * g.ksplit + split) * (SB * SB);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slab[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * SB + wn * 32 + l31] = acc[r];
+    return;
+  }
+  const int n = n0 + wn * 32 + l31;
+  if (n >= g.N) return;
+  const float bia = g.has_bias ? g.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (m >= g.M) continue;
+    float v = acc[r] + bia;
+    if (g.has_residual) v += g.residual[m * g.ldr + n];
+    if (g.act == 1) v = fmaxf(v, 0.f);
+    if (g.act == 2) v = gelu_erf_s(v);
+    g.C[m * g.ldc + n] = v;
+  }
+}
+
+// C tile = epilogue(sum_s slab[tile][s]) in fixed order.  4 blocks per 64x64 tile, a thread owns 4 consecutive columns.
+__global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const float* __restrict__ partial, int S, int tiles_n,
+                                                                  int64_t M, int N, float* __restrict__ C, int64_t ldc,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ residual, int64_t ldr,
+                                                                  int act) {
+  const int tile = blockIdx.x >> 2;
+  const int e = ((blockIdx.x & 3) << 8) + threadIdx.x;  // float4 index inside the tile: 64 rows x 16 float4
+  const int r = e >> 4, c = (e & 15) << 2;
+  const int64_t m = (int64_t)(tile / tiles_n) * SB + r;
+  const int n = (tile % tiles_n) * SB + c;
+  if (m >= M || n >= N) return;
+  const float* p = partial + (int64_t)tile * S * (SB * SB) + r * SB + c;
+  float4 v = *reinterpret_cast<const float4*>(p);
+  for (int s = 1; s < S; ++s) {
+    const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)s * (SB * SB));
+    v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+  }
+  float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (n + q >= N) break;
+    float x = o[q];
+    if (bias) x += bias[n + q];
+    if (residual) x += residual[m * ldr + n + q];
+    if (act == 1) x = fmaxf(x, 0.f);
+    if (act == 2) x = gelu_erf_s(x);
+    C[m * ldc + n + q] = x;
+  }
+}
+
+// Returns 1 when the shape is left to the 128x128 core, 0 after launching, < 0 on error.
+int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
+                            int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
+                            int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream) {
+  static const int target = [] {
+    const char* e = getenv("GDR_SMALL_TARGET");  // tuning knob: workgroups wanted per launch; 0 disables this kernel
+    return e ? atoi(e) : 512;
+  }();
+  if (target <= 0 || K % SBK != 0) return 1;
+  const int64_t tiles_m = (M + SB - 1) / SB;
+  const int tiles_n = (N + SB - 1) / SB;
+  const int64_t tiles = tiles_m * tiles_n;
+  if (tiles > 4096) return 1;
+  const int nk = K / SBK;
+  int S = (int)((target + tiles / 2) / tiles);  // nearest
+  if (S > nk / 4) S = nk / 4;
+  if (S < 1) S = 1;
+  const size_t slab = (size_t)SB * SB * sizeof(float);
+  if (S > 1 && (!ws || (size_t)S * tiles * slab > ws_bytes)) S = ws ? (int)(ws_bytes / (tiles * slab)) : 1;
+  if (S < 1) S = 1;
+  const int chunk_steps = (nk + S - 1) / S;
+  S = (nk + chunk_steps - 1) / chunk_steps;
+  SmallGemmArgs g{};
+  g.A = A, g.W = W, g.bias = bias, g.residual = residual;
+  g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr, g.M = M, g.N = N, g.K = K, g.tiles_n = tiles_n;
+  g.ksplit = S, g.kchunk = chunk_steps * SBK;
+  const double flops = 2.0 * (double)M * (double)N * (double)K;
+  if (S == 1) {
+    g.C = C, g.has_bias = has_bias, g.has_residual = has_residual, g.act = act;
+    ProfScope prof(PROF_LINEAR, flops, stream);
+    hipLaunchKernelGGL(gemm_nt_f32_small_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, g);
+    GDR_CHECK_LAUNCH("gemm_nt_f32_small_kernel");
+    return 0;
+  }
+  g.C = ws;
+  {
+    ProfScope prof(PROF_LINEAR, flops, stream);
+    hipLaunchKernelGGL(gemm_nt_f32_small_kernel, dim3((unsigned)(tiles * S)), dim3(256), 0, stream, g);
+  }
+  GDR_CHECK_LAUNCH("gemm_nt_f32_small_kernel(split)");
+  ProfScope prof_r(PROF_REDUCE, 0.0, stream);
+  hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((unsigned)(tiles * 4)), dim3(256), 0, stream, ws, S, tiles_n, M, N, C, ldc,
+                     has_bias ? bias : nullptr, has_residual ? residual : nullptr, ldr, act);
+  GDR_CHECK_LAUNCH("splitk_reduce_small_kernel");
+  return 0;
+}
+
+}  // namespace gdr
