@@ -71,34 +71,56 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_f32_small_kernel(const SmallGe
   f32x16m acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float4 ra0, ra1, rb0, rb1;
-  ra0 = *reinterpret_cast<const float4*>(a_src[0]), ra1 = *reinterpret_cast<const float4*>(a_src[1]);
-  rb0 = *reinterpret_cast<const float4*>(w_src[0]), rb1 = *reinterpret_cast<const float4*>(w_src[1]);
-  *reinterpret_cast<float4*>(As + st_off) = ra0, *reinterpret_cast<float4*>(As + st_off + 32 * SLD) = ra1;
-  *reinterpret_cast<float4*>(Bs + st_off) = rb0, *reinterpret_cast<float4*>(Bs + st_off + 32 * SLD) = rb1;
+  // Two register stages: the loads of K-step kt+2 are issued while kt is computed and kt+1 is written to LDS, so a
+  // load has two K-steps (plus the other resident workgroups) to arrive.
+  float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
+#define S_LOAD(R, kt_)                                                                       \
+  {                                                                                          \
+    const int t_ = (kt_) < nk ? (kt_) : nk - 1; /* past the end: re-fetch the last tile */   \
+    R##a0 = *reinterpret_cast<const float4*>(a_src[0] + t_ * SBK);                           \
+    R##a1 = *reinterpret_cast<const float4*>(a_src[1] + t_ * SBK);                           \
+    R##b0 = *reinterpret_cast<const float4*>(w_src[0] + t_ * SBK);                           \
+    R##b1 = *reinterpret_cast<const float4*>(w_src[1] + t_ * SBK);                           \
+  }
+#define S_STORE(R, buf_)                                                                     \
+  {                                                                                          \
+    float* as_ = As + (buf_)*SB * SLD + st_off;                                              \
+    float* bs_ = Bs + (buf_)*SB * SLD + st_off;                                              \
+    *reinterpret_cast<float4*>(as_) = R##a0, *reinterpret_cast<float4*>(as_ + 32 * SLD) = R##a1; \
+    *reinterpret_cast<float4*>(bs_) = R##b0, *reinterpret_cast<float4*>(bs_ + 32 * SLD) = R##b1; \
+  }
+#define S_COMPUTE(buf_)                                                                      \
+  {                                                                                          \
+    const float* a = As + (buf_)*SB * SLD + a_rd;                                            \
+    const float* b = Bs + (buf_)*SB * SLD + b_rd;                                            \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) { /* k permuted inside chunks of 8 as in gemm_f32.hip */ \
+      const float4 av = *reinterpret_cast<const float4*>(a + 8 * jj);                        \
+      const float4 bv = *reinterpret_cast<const float4*>(b + 8 * jj);                        \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);                  \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);                  \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);                  \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);                  \
+    }                                                                                        \
+  }
+  S_LOAD(p, 0)
+  S_STORE(p, 0)
+  S_LOAD(p, 1)
+  S_LOAD(q, 2)
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const int nxt = kt + 1 < nk ? kt + 1 : kt;  // the last step re-fetches its own tile: in bounds, never used
-    ra0 = *reinterpret_cast<const float4*>(a_src[0] + nxt * SBK), ra1 = *reinterpret_cast<const float4*>(a_src[1] + nxt * SBK);
-    rb0 = *reinterpret_cast<const float4*>(w_src[0] + nxt * SBK), rb1 = *reinterpret_cast<const float4*>(w_src[1] + nxt * SBK);
-    const float* a = As + buf * SB * SLD + a_rd;
-    const float* b = Bs + buf * SB * SLD + b_rd;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {  // k permuted inside chunks of 8 exactly as in gemm_f32.hip
-      const float4 av = *reinterpret_cast<const float4*>(a + 8 * jj);
-      const float4 bv = *reinterpret_cast<const float4*>(b + 8 * jj);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
-    }
-    float* as = As + (buf ^ 1) * SB * SLD + st_off;
-    float* bs = Bs + (buf ^ 1) * SB * SLD + st_off;
-    *reinterpret_cast<float4*>(as) = ra0, *reinterpret_cast<float4*>(as + 32 * SLD) = ra1;
-    *reinterpret_cast<float4*>(bs) = rb0, *reinterpret_cast<float4*>(bs + 32 * SLD) = rb1;
+  for (int kt = 0; kt < nk; kt += 2) {
+    S_COMPUTE(0)
+    S_STORE(p, 1)
+    S_LOAD(p, kt + 3)
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    S_COMPUTE(1)
+    S_STORE(q, 0)
+    S_LOAD(q, kt + 4)
     __syncthreads();
   }
+#undef S_LOAD
+#undef S_STORE
+#undef S_COMPUTE
   // accumulator map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   if (g.ksplit > 1) {
     float* slab = g.C + ((int64_t)tile * g.ksplit + split) * (SB * SB);
