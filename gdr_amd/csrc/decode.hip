@@ -39,6 +39,8 @@ struct BeamBufs {
   double* hyp_score;    // [B][R+1]
   int32_t* hyp_len;     // [B][R+1]
   int32_t* hyp_tok;     // [B][R+1][maxlen]
+  int32_t* hyp_seq;     // [B][R+1] insertion number of each live hypothesis (list order of the reference's self.beams)
+  int32_t* hyp_next;    // [B] next insertion number
   int32_t* hyp_cnt;     // [B]
   double* hyp_worst;    // [B]
   int32_t* done;        // [B]
@@ -83,6 +85,8 @@ static size_t beam_layout(const BeamDims& bd, char* base, BeamBufs* bb) {
   CARVE(hyp_score, double, (size_t)bd.B * (bd.R + 1));
   CARVE(hyp_len, int32_t, (size_t)bd.B * (bd.R + 1));
   CARVE(hyp_tok, int32_t, (size_t)bd.B * (bd.R + 1) * ml);
+  CARVE(hyp_seq, int32_t, (size_t)bd.B * (bd.R + 1));
+  CARVE(hyp_next, int32_t, bd.B);
   CARVE(hyp_cnt, int32_t, bd.B);
   CARVE(hyp_worst, double, bd.B);
   CARVE(done, int32_t, bd.B);
@@ -105,6 +109,7 @@ __global__ void beam_init_kernel(BeamBufs bb, BeamDims bd) {
   }
   if (r < bd.B) {
     bb.hyp_cnt[r] = 0;
+    bb.hyp_next[r] = 0;
     bb.hyp_worst[r] = 1e9;  // :1062
     bb.done[r] = 0;
   }
@@ -221,88 +226,162 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(BeamBufs bb, BeamDims bd
   }
 }
 
-// BeamHypotheses.add (generation_utils.py:1070-1084); Python-float arithmetic = double.
-__device__ void hyp_add(const BeamBufs& bb, const BeamDims& bd, int b, const int32_t* toks, int len, double sum_logp) {
-  const int cap = bd.R + 1;
-  double* sc = bb.hyp_score + (size_t)b * cap;
-  int32_t* ln = bb.hyp_len + (size_t)b * cap;
-  int32_t* tk = bb.hyp_tok + (size_t)b * cap * bd.maxlen;
-  int n = bb.hyp_cnt[b];
+// ---- BeamHypotheses of one query, held in LDS by the single wave that serves the query -------------------------------
+// The reference keeps `self.beams` as a Python list (generation_utils.py:1052-1099): add() appends, an over-full list
+// drops its worst entry with `del` (order of the rest kept), the final pick is a stable sort by score popped from the
+// end.  Only the RELATIVE list order of surviving entries is ever observed (tie-breaks), so each entry carries its
+// insertion number and the storage order is free: a delete moves the last entry into the hole.
+struct HypLds {
+  double* sc;   // [R+1]
+  int32_t* ln;  // [R+1]
+  int32_t* sq;  // [R+1]
+  int32_t* tk;  // [R+1][ml]
+  int n, next;
+  double worst;
+};
+__host__ __device__ static size_t hyp_lds_bytes(int R, int ml) { return (size_t)(R + 1) * (8 + 4 + 4 + 4 * (size_t)ml) + 8; }
+
+__device__ __forceinline__ void hyp_load(HypLds& H, char* smem, const BeamBufs& bb, const BeamDims& bd, int b, int lane) {
+  const int cap = bd.R + 1, ml = bd.maxlen;
+  H.sc = reinterpret_cast<double*>(smem);
+  H.ln = reinterpret_cast<int32_t*>(H.sc + cap);
+  H.sq = H.ln + cap;
+  H.tk = H.sq + cap;
+  H.n = bb.hyp_cnt[b], H.next = bb.hyp_next[b], H.worst = bb.hyp_worst[b];
+  for (int i = lane; i < H.n; i += 64) {
+    H.sc[i] = bb.hyp_score[(size_t)b * cap + i];
+    H.ln[i] = bb.hyp_len[(size_t)b * cap + i];
+    H.sq[i] = bb.hyp_seq[(size_t)b * cap + i];
+  }
+  for (int e = lane; e < H.n * ml; e += 64) H.tk[e] = bb.hyp_tok[(size_t)b * cap * ml + e];
+  __syncthreads();
+}
+
+__device__ __forceinline__ void hyp_store(const HypLds& H, const BeamBufs& bb, const BeamDims& bd, int b, int lane) {
+  const int cap = bd.R + 1, ml = bd.maxlen;
+  __syncthreads();
+  for (int i = lane; i < H.n; i += 64) {
+    bb.hyp_score[(size_t)b * cap + i] = H.sc[i];
+    bb.hyp_len[(size_t)b * cap + i] = H.ln[i];
+    bb.hyp_seq[(size_t)b * cap + i] = H.sq[i];
+  }
+  for (int e = lane; e < H.n * ml; e += 64) bb.hyp_tok[(size_t)b * cap * ml + e] = H.tk[e];
+  if (lane == 0) bb.hyp_cnt[b] = H.n, bb.hyp_next[b] = H.next, bb.hyp_worst[b] = H.worst;
+}
+
+// BeamHypotheses.add (generation_utils.py:1070-1084); Python-float arithmetic = double.  Called by all 64 lanes of the
+// query's wave with uniform arguments.
+__device__ void hyp_add(HypLds& H, const BeamDims& bd, const int32_t* toks, int len, double sum_logp, int lane) {
+  const int ml = bd.maxlen;
   const double score = sum_logp / pow((double)len, bd.lp);
-  if (n < bd.R || score > bb.hyp_worst[b]) {
-    sc[n] = score;
-    ln[n] = len;
-    for (int i = 0; i < len; ++i) tk[(size_t)n * bd.maxlen + i] = toks[i];
-    ++n;
-    if (n > bd.R) {
-      // sorted([(s, idx)])[0] is removed, [1] gives the new worst score
-      int lo = 0;
-      for (int i = 1; i < n; ++i)
-        if (sc[i] < sc[lo]) lo = i;  // ties: lowest idx first, as tuple sort does
-      double second = INFINITY;
-      for (int i = 0; i < n; ++i)
-        if (i != lo && sc[i] < second) second = sc[i];
-      for (int i = lo; i + 1 < n; ++i) {  // del self.beams[idx] keeps list order
-        sc[i] = sc[i + 1];
-        ln[i] = ln[i + 1];
-        for (int t = 0; t < bd.maxlen; ++t) tk[(size_t)i * bd.maxlen + t] = tk[(size_t)(i + 1) * bd.maxlen + t];
-      }
-      --n;
-      bb.hyp_worst[b] = second;
-    } else {
-      bb.hyp_worst[b] = score < bb.hyp_worst[b] ? score : bb.hyp_worst[b];
+  if (!(H.n < bd.R || score > H.worst)) return;
+  if (lane == 0) H.sc[H.n] = score, H.ln[H.n] = len, H.sq[H.n] = H.next;
+  for (int t = lane; t < len; t += 64) H.tk[(size_t)H.n * ml + t] = toks[t];
+  ++H.n, ++H.next;
+  __syncthreads();
+  if (H.n > bd.R) {
+    // sorted([(s, idx)])[0] is removed (lowest score, then lowest list index = lowest insertion number);
+    // [1] gives the new worst score
+    double bs = INFINITY;
+    int bq = 0x7fffffff, bi = -1;
+    for (int i = lane; i < H.n; i += 64) {
+      const double v = H.sc[i];
+      const int q = H.sq[i];
+      if (v < bs || (v == bs && q < bq)) bs = v, bq = q, bi = i;
     }
-    bb.hyp_cnt[b] = n;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double os = __shfl_xor(bs, off);
+      const int oq = __shfl_xor(bq, off), oi = __shfl_xor(bi, off);
+      if (os < bs || (os == bs && oq < bq)) bs = os, bq = oq, bi = oi;
+    }
+    const int lo = bi;
+    double second = INFINITY;
+    for (int i = lane; i < H.n; i += 64)
+      if (i != lo && H.sc[i] < second) second = H.sc[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) second = fmin(second, __shfl_xor(second, off));
+    const int last = H.n - 1;
+    if (lo != last) {
+      if (lane == 0) H.sc[lo] = H.sc[last], H.ln[lo] = H.ln[last], H.sq[lo] = H.sq[last];
+      for (int t = lane; t < ml; t += 64) H.tk[(size_t)lo * ml + t] = H.tk[(size_t)last * ml + t];
+    }
+    --H.n;
+    H.worst = second;
+    __syncthreads();
+  } else {
+    H.worst = score < H.worst ? score : H.worst;
   }
 }
 
-// The host loop of generation_utils.py:783-850, one thread per query.  cur = index of the current seq buffer.
-__global__ void beam_update_kernel(BeamBufs bb, BeamDims bd, int cur_len, int cur) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= bd.B) return;
+// The host loop of generation_utils.py:783-850: one wave per query.  The walk over the 2R ranked candidates stays
+// sequential (hypothesis state carries from one EOS candidate to the next) but only decides; rows are filled afterwards
+// by all lanes.  cur = index of the current seq buffer.
+__global__ __launch_bounds__(64) void beam_update_kernel(BeamBufs bb, BeamDims bd, int cur_len, int cur) {
+  extern __shared__ __attribute__((aligned(16))) char bsm[];
+  const int b = blockIdx.x, lane = threadIdx.x;
   const int R = bd.R, ml = bd.maxlen;
   const int32_t* seq_c = bb.seq[cur];
   int32_t* seq_n = bb.seq[cur ^ 1];
   if (bb.done[b]) {  // :786-794 padded batch entry
-    for (int j = 0; j < R; ++j) {
+    for (int j = lane; j < R; j += 64) {
       const int row = b * R + j;
       bb.beam_scores[row] = 0.f;
       bb.cur_tok[row] = PAD_ID;
       bb.parent[row] = b * R;
       bb.node[cur ^ 1][row] = -1;
-      for (int t = 0; t < cur_len; ++t) seq_n[(size_t)row * ml + t] = seq_c[(size_t)(b * R) * ml + t];
-      seq_n[(size_t)row * ml + cur_len] = PAD_ID;
+    }
+    for (int e = lane; e < R * (cur_len + 1); e += 64) {
+      const int j = e / (cur_len + 1), t = e - j * (cur_len + 1);
+      seq_n[(size_t)(b * R + j) * ml + t] = t < cur_len ? seq_c[(size_t)(b * R) * ml + t] : PAD_ID;
     }
     return;
   }
+  HypLds H;
+  hyp_load(H, bsm, bb, bd, b, lane);
+  int32_t* sel = reinterpret_cast<int32_t*>(bsm + ((hyp_lds_bytes(R, ml) + 15) & ~(size_t)15));  // [R] chosen candidate ranks
   const float* cs = bb.cand_score + (size_t)b * 2 * R;
   const int32_t* ci = bb.cand_idx + (size_t)b * 2 * R;
   int n = 0;
+  bool touched = false;
   for (int rank = 0; rank < 2 * R; ++rank) {
-    const int beam = ci[rank] / bd.Vd, tok = ci[rank] % bd.Vd;
-    const int eff = b * R + beam;
+    const int flat = ci[rank];
+    const int beam = flat / bd.Vd, tok = flat % bd.Vd;
     if (tok == EOS_ID) {
       if (rank >= R) continue;  // :811-813
-      hyp_add(bb, bd, b, seq_c + (size_t)eff * ml, cur_len, (double)cs[rank]);
+      hyp_add(H, bd, seq_c + (size_t)(b * R + beam) * ml, cur_len, (double)cs[rank], lane);
+      touched = true;
     } else {
-      const int row = b * R + n;
-      bb.beam_scores[row] = cs[rank];
-      bb.cur_tok[row] = tok;
-      bb.parent[row] = eff;
-      if (bd.trie_child) {
-        const int nd = bb.node[cur][eff], c = tok - ((cur_len - 1) * bd.V + 2);
-        bb.node[cur ^ 1][row] = (nd >= 0 && c >= 0 && c < bd.V) ? bd.trie_child[(size_t)nd * bd.V + c] : -1;
-      }
-      for (int t = 0; t < cur_len; ++t) seq_n[(size_t)row * ml + t] = seq_c[(size_t)eff * ml + t];
-      seq_n[(size_t)row * ml + cur_len] = tok;
+      if (lane == 0) sel[n] = rank;
       ++n;
     }
     if (n == R) break;
   }
+  __syncthreads();
+  for (int j = lane; j < n; j += 64) {
+    const int rank = sel[j];
+    const int flat = ci[rank];
+    const int beam = flat / bd.Vd, tok = flat % bd.Vd;
+    const int eff = b * R + beam, row = b * R + j;
+    bb.beam_scores[row] = cs[rank];
+    bb.cur_tok[row] = tok;
+    bb.parent[row] = eff;
+    if (bd.trie_child) {
+      const int nd = bb.node[cur][eff], c = tok - ((cur_len - 1) * bd.V + 2);
+      bb.node[cur ^ 1][row] = (nd >= 0 && c >= 0 && c < bd.V) ? bd.trie_child[(size_t)nd * bd.V + c] : -1;
+    }
+  }
+  for (int e = lane; e < n * (cur_len + 1); e += 64) {
+    const int j = e / (cur_len + 1), t = e - j * (cur_len + 1);
+    const int flat = ci[sel[j]];
+    const int beam = flat / bd.Vd, tok = flat % bd.Vd;
+    seq_n[(size_t)(b * R + j) * ml + t] = t < cur_len ? seq_c[(size_t)(b * R + beam) * ml + t] : tok;
+  }
+  if (touched) hyp_store(H, bb, bd, b, lane);
   // :827-829  is_done(best_sum_logprobs = next_scores[b].max(), cur_len)
-  if (bb.hyp_cnt[b] >= R) {
+  if (lane == 0 && H.n >= R) {
     const double cur_score = (double)cs[0] / pow((double)cur_len, bd.lp);
-    if (bb.hyp_worst[b] >= cur_score) bb.done[b] = 1;
+    if (H.worst >= cur_score) bb.done[b] = 1;
   }
 }
 
@@ -317,48 +396,51 @@ __global__ void anc_update_kernel(BeamBufs bb, int rows, int maxlen, int pos, in
   bb.kv_rows[(size_t)r * stride + p] = p * rows + a;
 }
 
-// :862-919 finalise open beams, pick the nret best per query, lay out tokens / EOS / PAD.
-__global__ void beam_finalize_kernel(BeamBufs bb, BeamDims bd, int final_len, int cur, int max_length,
-                                     int64_t* out_ids, int32_t* out_len, double* out_scores) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= bd.B) return;
-  const int R = bd.R, ml = bd.maxlen, cap = R + 1;
+// :862-919 finalise open beams, pick the nret best per query, lay out tokens / EOS / PAD.  One wave per query.
+__global__ __launch_bounds__(64) void beam_finalize_kernel(BeamBufs bb, BeamDims bd, int final_len, int cur, int max_length,
+                                                           int64_t* out_ids, int32_t* out_len, double* out_scores) {
+  extern __shared__ __attribute__((aligned(16))) char bsm[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int R = bd.R, ml = bd.maxlen;
+  HypLds H;
+  hyp_load(H, bsm, bb, bd, b, lane);
+  int32_t* order = reinterpret_cast<int32_t*>(bsm + ((hyp_lds_bytes(R, ml) + 15) & ~(size_t)15));  // [nret] entry of rank j
   if (!bb.done[b]) {
     for (int j = 0; j < R; ++j) {
       const int row = b * R + j;
-      hyp_add(bb, bd, b, bb.seq[cur] + (size_t)row * ml, final_len, (double)bb.beam_scores[row]);
+      hyp_add(H, bd, bb.seq[cur] + (size_t)row * ml, final_len, (double)bb.beam_scores[row], lane);
     }
   }
-  double* sc = bb.hyp_score + (size_t)b * cap;
-  const int32_t* ln = bb.hyp_len + (size_t)b * cap;
-  const int32_t* tk = bb.hyp_tok + (size_t)b * cap * ml;
-  const int n = bb.hyp_cnt[b];
-  // sorted(beams, key=score) is stable ascending; pop() takes the last: among equal scores the later entry first
-  unsigned long long taken_lo = 0ull, taken_hi[4] = {0ull, 0ull, 0ull, 0ull};  // up to 320 entries
-  for (int j = 0; j < bd.nret; ++j) {
-    int best = -1;
-    for (int i = 0; i < n; ++i) {
-      const bool tk_ = i < 64 ? ((taken_lo >> i) & 1ull) : ((taken_hi[(i - 64) >> 6] >> ((i - 64) & 63)) & 1ull);
-      if (tk_) continue;
-      if (best < 0 || sc[i] >= sc[best]) best = i;
+  __syncthreads();
+  // sorted(beams, key=score) is stable ascending and pop() takes the last: highest score first, among equal scores the
+  // later list entry first.  rank(i) = number of entries that precede i in that order.
+  const int n = H.n;
+  for (int i = lane; i < n; i += 64) {
+    const double v = H.sc[i];
+    const int q = H.sq[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const double w = H.sc[j];
+      rank += (w > v || (w == v && H.sq[j] > q)) ? 1 : 0;
     }
+    if (rank < bd.nret) order[rank] = i;
+  }
+  __syncthreads();
+  for (int j = lane; j < bd.nret; j += 64) {
     const size_t o = (size_t)b * bd.nret + j;
-    if (best < 0) {  // fewer hypotheses than requested: cannot happen when V^depth >= R (reference would raise)
-      out_len[o] = 0;
-      out_scores[o] = -INFINITY;
-      for (int t = 0; t < max_length; ++t) out_ids[o * max_length + t] = PAD_ID;
-      continue;
-    }
-    if (best < 64) taken_lo |= 1ull << best; else taken_hi[(best - 64) >> 6] |= 1ull << ((best - 64) & 63);
-    const int len = ln[best];
-    out_len[o] = len;
-    out_scores[o] = sc[best];
-    for (int t = 0; t < max_length; ++t) {
-      int64_t v = PAD_ID;
-      if (t < len) v = tk[(size_t)best * ml + t];
+    // fewer hypotheses than requested cannot happen when V^depth >= R (the reference would raise)
+    out_len[o] = j < n ? H.ln[order[j]] : 0;
+    out_scores[o] = j < n ? H.sc[order[j]] : -INFINITY;
+  }
+  for (int e = lane; e < bd.nret * max_length; e += 64) {
+    const int j = e / max_length, t = e - j * max_length;
+    int64_t v = PAD_ID;
+    if (j < n) {
+      const int best = order[j], len = H.ln[best];
+      if (t < len) v = H.tk[(size_t)best * ml + t];
       else if (t == len) v = EOS_ID;  // :915-916 (len < max_length)
-      out_ids[o * max_length + t] = v;
     }
+    out_ids[((size_t)b * bd.nret + j) * max_length + t] = v;
   }
 }
 
@@ -391,7 +473,8 @@ static int beam_step(const BeamBufs& bb, const BeamDims& bd, int pos, int cur, f
   hipLaunchKernelGGL(beam_topk_kernel, dim3(bd.B), dim3(256), lds, stream, bb, bd, pos, npad, cur,
                      step_scores ? step_scores + tr : nullptr, step_tokens ? step_tokens + tr : nullptr);
   GDR_CHECK_LAUNCH("beam_topk_kernel");
-  hipLaunchKernelGGL(beam_update_kernel, dim3((bd.B + 63) / 64), dim3(64), 0, stream, bb, bd, pos + 1, cur);
+  const size_t hyp_lds = ((hyp_lds_bytes(bd.R, bd.maxlen) + 15) & ~(size_t)15) + (size_t)bd.R * 4;
+  hipLaunchKernelGGL(beam_update_kernel, dim3(bd.B), dim3(64), hyp_lds, stream, bb, bd, pos + 1, cur);
   GDR_CHECK_LAUNCH("beam_update_kernel");
   const int n = rows * (pos + 2);
   hipLaunchKernelGGL(anc_update_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, bb, rows, bd.maxlen, pos + 1, cur);
@@ -418,8 +501,9 @@ static int beam_begin(const BeamBufs& bb, const BeamDims& bd, hipStream_t stream
 
 static int beam_end(const BeamBufs& bb, const BeamDims& bd, int max_length, int cur, int64_t* out_ids,
                     int32_t* out_len, double* out_scores, hipStream_t stream) {
-  hipLaunchKernelGGL(beam_finalize_kernel, dim3((bd.B + 63) / 64), dim3(64), 0, stream, bb, bd, max_length, cur,
-                     max_length, out_ids, out_len, out_scores);
+  const size_t hyp_lds = ((hyp_lds_bytes(bd.R, bd.maxlen) + 15) & ~(size_t)15) + (size_t)bd.R * 4;
+  hipLaunchKernelGGL(beam_finalize_kernel, dim3(bd.B), dim3(64), hyp_lds, stream, bb, bd, max_length, cur, max_length, out_ids,
+                     out_len, out_scores);
   GDR_CHECK_LAUNCH("beam_finalize_kernel");
   return GDR_OK;
 }

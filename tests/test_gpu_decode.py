@@ -36,6 +36,30 @@ def test_device_beam_search_vs_reference_golden(dev, case):
     assert np.array_equal(dec.cpu().numpy(), ref_dec)
 
 
+@pytest.mark.parametrize("V,maxlen,R,B,boost,seed", [(12, 6, 100, 2, 2.5, 7), (30, 5, 100, 1, 5.0, 3), (10, 7, 70, 3, 4.0, 11)])
+def test_device_beam_search_wide_beams_vs_oracle(dev, V, maxlen, R, B, boost, seed):
+    """infer.sh decodes with 100 beams: more hypotheses than lanes in the wave that keeps a query's BeamHypotheses (the
+    LDS heap is walked in several rounds; eviction, ties and the final stable pick go through the multi-round paths)."""
+    from gdr_amd import ops
+    from oracle import beam_ref, t5_ref
+    Vd = V * maxlen + 2
+    tab = synth.make_logit_table(B, maxlen, Vd, boost, seed)
+    table = torch.from_numpy(tab)
+    qid = torch.arange(B).repeat_interleave(R)
+
+    def step(seq):
+        t = seq.shape[1]
+        return table[qid, t - 1, seq[:, -1]] + t5_ref.positional_mask(t, Vd, V)[t - 1]
+
+    ref_dec, ref_sc = beam_ref.beam_search(step, B, R, Vd, maxlen, 0.8)
+    ids, lens, scores = ops.beam_search_table(table.to(dev), V, R, maxlen, 0.8)
+    dec, sc = ops.finish_generate_output(ids, lens, scores, maxlen)
+    np.testing.assert_allclose(np.array(sc), np.array(ref_sc), rtol=1e-5, atol=1e-5)
+    assert np.array_equal(dec.cpu().numpy(), ref_dec.numpy())
+    if V <= 12:   # small vocabularies put EOS among the top 2R often enough to exercise add / evict at every step
+        assert any(1 in row[1:-1] for row in ref_dec.numpy().tolist()), "want hypotheses that ended early"
+
+
 def _check_generate(g, cfg, dev, tol):
     from gdr_amd.modeling import GDRModel
     sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
