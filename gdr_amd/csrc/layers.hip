@@ -208,10 +208,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   float* ps = Ps + wave * Lkp;
   const int half = a.num_buckets >> 1;
   const float masked = a.causal_neg_inf ? -INFINITY : -1e9f;
-  const int iters = (a.Lq + 3) >> 2;
+  // query rows are dealt to gridDim.y workgroups per (batch, head): with few (batch, head) pairs and many rows (one
+  // query decoded with 100 beams) a single workgroup per pair left the chip idle
+  const int rows_per = (a.Lq + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int i0 = (int)blockIdx.y * rows_per, i1 = min(a.Lq, i0 + rows_per);
+  const int iters = i1 > i0 ? (i1 - i0 + 3) >> 2 : 0;
   for (int it = 0; it < iters; ++it) {
-    const int i = it * 4 + wave;
-    const bool active = i < a.Lq;
+    const int i = i0 + it * 4 + wave;
+    const bool active = i < i1;
     if (active) {
       const float* qr = a.q + ((int64_t)b * a.q_bstride + i) * a.ldq + h * dk;
       for (int d = lane; d < dk; d += 64) qs[d] = qr[d] * a.scale;
@@ -738,7 +742,10 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(a.B * a.H)), dim3(256), lds, stream, a);
+  int chunks = (512 + a.B * a.H - 1) / (a.B * a.H);  // aim at ~2 workgroups per CU, at least 4 rows (one per wave) each
+  const int max_chunks = (a.Lq + 3) / 4;
+  chunks = chunks < 1 ? 1 : (chunks > max_chunks ? max_chunks : chunks);
+  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(a.B * a.H), (unsigned)chunks), dim3(256), lds, stream, a);
   GDR_CHECK_LAUNCH("attention_kernel");
   return GDR_OK;
 }
