@@ -158,15 +158,15 @@ __global__ void table_logits_kernel(const float* __restrict__ table, const int64
 
 // Per query: log_softmax of every beam's row (masked columns contribute exp(-1e9 - max) = 0 exactly), add the
 // beam score, take the 2R best of the R*(V+1) unmasked candidates, sorted (generation_utils.py:698,766-775).
-__global__ __launch_bounds__(256) void beam_topk_kernel(BeamBufs bb, BeamDims bd, int pos, int npad, int cur,
+__global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims bd, int pos, int npad, int cur,
                                                         float* __restrict__ step_scores,
                                                         int32_t* __restrict__ step_tokens) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [npad]
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int R = bd.R, V1 = bd.V + 1;
+  const int R = bd.R, V1 = bd.V + 1, nthr = blockDim.x, nwaves = blockDim.x >> 6;
   float* lse_max = reinterpret_cast<float*>(keys + npad);  // [R]
   float* lse_log = lse_max + R;                            // [R]
-  for (int j = wave; j < R; j += 4) {
+  for (int j = wave; j < R; j += nwaves) {
     const float* lg = bb.logits + ((size_t)b * R + j) * V1;
     float mx = -INFINITY;
     for (int c = lane; c < V1; c += 64) mx = fmaxf(mx, lg[c]);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(BeamBufs bb, BeamDims bd
   }
   __syncthreads();
   const int ncand = R * V1;
-  for (int e = tid; e < npad; e += 256) {
+  for (int e = tid; e < npad; e += nthr) {
     unsigned long long key = 0ull;
     if (e < ncand) {
       const int j = e / V1, c = e - j * V1;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(BeamBufs bb, BeamDims bd
   __syncthreads();
   for (int size = 2; size <= npad; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < (npad >> 1); t += 256) {
+      for (int t = tid; t < (npad >> 1); t += nthr) {
         const int lo = (t / stride) * (stride << 1) + (t % stride), hi = lo + stride;
         const bool desc = ((lo & size) == 0);
         const unsigned long long x = keys[lo], y = keys[hi];
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(BeamBufs bb, BeamDims bd
       __syncthreads();
     }
   }
-  for (int i = tid; i < 2 * R; i += 256) {
+  for (int i = tid; i < 2 * R; i += nthr) {
     const unsigned long long key = keys[i];
     const float s = dfkey_inv((uint32_t)(key >> 32));
     const int32_t flat = (int32_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
@@ -470,7 +470,7 @@ static int beam_step(const BeamBufs& bb, const BeamDims& bd, int pos, int cur, f
   const int npad = next_pow2i(bd.R * (bd.V + 1));
   const size_t lds = (size_t)npad * 8 + (size_t)bd.R * 8;
   const size_t tr = (size_t)pos * bd.B * 2 * bd.R;
-  hipLaunchKernelGGL(beam_topk_kernel, dim3(bd.B), dim3(256), lds, stream, bb, bd, pos, npad, cur,
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(bd.B), dim3(npad >= 2048 ? 1024 : 256), lds, stream, bb, bd, pos, npad, cur,
                      step_scores ? step_scores + tr : nullptr, step_tokens ? step_tokens + tr : nullptr);
   GDR_CHECK_LAUNCH("beam_topk_kernel");
   const size_t hyp_lds = ((hyp_lds_bytes(bd.R, bd.maxlen) + 15) & ~(size_t)15) + (size_t)bd.R * 4;
