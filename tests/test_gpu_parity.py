@@ -361,6 +361,30 @@ def test_topk_merge_equals_single_shard(dev):
     assert torch.equal(im, i1) and torch.equal(vm, v1)      # row-independent arithmetic: bit-identical
 
 
+@pytest.mark.parametrize("N,G,B", [(320000, 8, 512), (1000003, 8, 96)])
+def test_full_size_shard_merge_property_and_spot_parity(dev, N, G, B):
+    """BASELINE's full sizes (C2/C4: 320k docs, 512 queries; C5: 1M docs), checked through a size-independent property —
+    top-k over the whole corpus == merge of the top-k of G row shards, bit for bit, fp32 and bf16 — plus exact parity of a
+    few queries against the oracle (the full B x N oracle product would take minutes on the CPU)."""
+    from gdr_amd import ops
+    from oracle import retrieval_ref
+    d, k = 768, 100
+    D = synth.make_corpus(N, d, seed=5)
+    Q, _ = synth.make_queries(D[:50000], B, seed=6)
+    Qd, Dd = torch.from_numpy(Q).to(dev), torch.from_numpy(D).to(dev)
+    bounds = [N * g // G for g in range(G + 1)]
+    for Dm in (Dd, ops.to_bf16(Dd)):
+        v1, i1, st = ops.sim_topk(Qd, Dm, k, return_status=True)
+        assert int(st.sum().item()) == 0
+        parts = [ops.sim_topk(Qd, Dm[bounds[g]:bounds[g + 1]], k, idx_offset=bounds[g]) for g in range(G)]
+        vm, im = ops.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+        assert torch.equal(im, i1) and torch.equal(vm, v1)
+        assert (np.diff(v1.cpu().numpy(), axis=1) <= 0).all()
+    v32, i32 = ops.sim_topk(Qd[:4], Dd, k)
+    rv, ri = retrieval_ref.sim_topk(torch.from_numpy(Q[:4]), torch.from_numpy(D), k)
+    order_insensitive_topk_match(rv.numpy(), ri.numpy(), v32.cpu().numpy(), i32.cpu().numpy().astype(np.int64), TOL)
+
+
 # ------------------------------------------------------------------------------------------- rerank
 def test_rerank_vs_reference_golden(dev):
     from gdr_amd import ops, codec
