@@ -23,14 +23,19 @@ struct Bf16GemmArgs {
   const float* bias;
   const float* residual;
   int64_t lda, ldw, ldc, ldr;  // elements
-  int64_t M;
+  int64_t M;      // rows of A
+  int64_t Nrows;  // rows of W (= N; 64-bit: the corpus in the similarity form)
   int N, K, tiles_n;
   int has_bias, has_residual, act;  // act: 0 none, 1 relu, 2 gelu
   int out_bf16;
+  // similarity epilogues (EPI 1 sample / 2 filter): A = queries [B,d] (lane role), W = docs [N,d] (register role);
+  // tiles_n then counts QUERY tiles (fastest in the grid: the workgroups that share a doc tile are neighbours)
+  SimEpilogue sim;
 };
 
 __device__ __forceinline__ float gelu_erf_b(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+template <int EPI>  // 0 linear, 1 similarity sample, 2 similarity filter
 __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16GemmArgs g) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * 128 * 128];  // As [128 rows][128 B], Bs likewise
   char* const As = smem;
@@ -40,10 +45,23 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     const unsigned nblk = gridDim.x, q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
-  const int64_t mt = bid / (unsigned)g.tiles_n;
-  const int nt = bid % (unsigned)g.tiles_n;
-  const int64_t m0 = mt * 128;
-  const int n0 = nt * 128;
+  int64_t m0, slot_base = 0;
+  int64_t n0;
+  if (EPI == 0) {
+    m0 = (int64_t)(bid / (unsigned)g.tiles_n) * 128;
+    n0 = (int64_t)(bid % (unsigned)g.tiles_n) * 128;
+  } else {
+    int64_t dt = bid / (unsigned)g.tiles_n;  // doc tile of this pass
+    m0 = (int64_t)(bid % (unsigned)g.tiles_n) * 128;  // query tile
+    if (EPI == 1) {
+      slot_base = dt * 128;
+      dt = dt * g.sim.tile_stride;
+    } else {
+      const int s1 = g.sim.tile_stride - 1;
+      dt = (dt / s1) * g.sim.tile_stride + 1 + (dt % s1);
+    }
+    n0 = dt * 128;
+  }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int r16 = lane & 15, q4 = lane >> 4;
@@ -58,10 +76,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     const int chunk = schunk ^ ((row >> 1) & 7);
     int64_t ra = m0 + row;
     ra = ra < g.M ? ra : g.M - 1;  // rows past the edge are computed and discarded
-    int rw = n0 + row;
-    rw = rw < g.N ? rw : g.N - 1;
+    int64_t rw = n0 + row;
+    rw = rw < g.Nrows ? rw : g.Nrows - 1;
     a_src[i] = g.A + (ra * g.lda) * 2 + chunk * 16;
-    w_src[i] = g.W + ((int64_t)rw * g.ldw) * 2 + chunk * 16;
+    w_src[i] = g.W + (rw * g.ldw) * 2 + chunk * 16;
   }
   // ---- fragment reads: lane (r16, q4) reads 16 B = k 8*q4..+7 of a 32-k half; 4 row blocks of A, 4 of W ----
   int a_off[4], b_off[4], a_sw[4], b_sw[4];
@@ -107,6 +125,70 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     __syncthreads();  // every fragment read done before the next K-step's DMA overwrites the buffer
   }
 
+  // ---- similarity epilogues: lane&15 <-> query, registers <-> 4 consecutive docs ----
+  if (EPI == 1) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int64_t q = m0 + wm * 64 + mi * 16 + r16;
+      if (q >= g.M) continue;
+      float* cv = g.sim.cand_val + q * g.sim.cap + slot_base;
+      int32_t* ci = g.sim.cand_idx + q * g.sim.cap + slot_base;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int off = wn * 64 + ni * 16 + 4 * q4;
+        const int64_t n = n0 + off;
+        float4 v;
+        int4 id;
+        v.x = n + 0 < g.Nrows ? acc[mi][ni][0] : -INFINITY, v.y = n + 1 < g.Nrows ? acc[mi][ni][1] : -INFINITY;
+        v.z = n + 2 < g.Nrows ? acc[mi][ni][2] : -INFINITY, v.w = n + 3 < g.Nrows ? acc[mi][ni][3] : -INFINITY;
+        id.x = n + 0 < g.Nrows ? (int)n : -1, id.y = n + 1 < g.Nrows ? (int)n + 1 : -1;
+        id.z = n + 2 < g.Nrows ? (int)n + 2 : -1, id.w = n + 3 < g.Nrows ? (int)n + 3 : -1;  // -1 = padding slot
+        *reinterpret_cast<float4*>(cv + off) = v;
+        *reinterpret_cast<int4*>(ci + off) = id;
+      }
+    }
+    return;
+  }
+  if (EPI == 2) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int64_t q = m0 + wm * 64 + mi * 16 + r16;
+      const bool q_ok = q < g.M;
+      const float thr = q_ok ? g.sim.thr[q] : INFINITY;
+      unsigned keep = 0u;  // bit 4*ni + r
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t n = n0 + wn * 64 + ni * 16 + 4 * q4 + r;
+          keep |= (q_ok && acc[mi][ni][r] >= thr && n < g.Nrows) ? (1u << (4 * ni + r)) : 0u;
+        }
+      // the 4 lanes that share this query (lane>>4 = 0..3) pool their counts: one returning atomic per query and tile
+      const int mine = __popc(keep);
+      const int c0 = __shfl(mine, r16), c1 = __shfl(mine, r16 + 16), c2 = __shfl(mine, r16 + 32), c3 = __shfl(mine, r16 + 48);
+      const int total = c0 + c1 + c2 + c3;
+      int base = 0;
+      if (q4 == 0 && total > 0) base = atomicAdd(g.sim.cand_cnt + q, total);
+      base = __shfl(base, r16);
+      int pos = base + (q4 > 0 ? c0 : 0) + (q4 > 1 ? c1 : 0) + (q4 > 2 ? c2 : 0);
+      if (mine) {
+        float* cv = g.sim.cand_val + q * g.sim.cap;
+        int32_t* ci = g.sim.cand_idx + q * g.sim.cap;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (keep >> (4 * ni + r) & 1u) {
+              if (pos < g.sim.cap) {
+                cv[pos] = acc[mi][ni][r];
+                ci[pos] = (int)(n0 + wn * 64 + ni * 16 + 4 * q4 + r);
+              }
+              ++pos;
+            }
+      }
+    }
+    return;
+  }
   // ---- epilogue: row m = block*16 + lane&15, columns n = block*16 + 4*(lane>>4) + 0..3 ----
   const bool interior = m0 + 128 <= g.M && n0 + 128 <= g.N && (g.ldc & 3) == 0 &&
                         (!g.has_residual || (g.ldr & 3) == 0);
@@ -115,7 +197,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     const int64_t m = m0 + wm * 64 + mi * 16 + r16;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wn * 64 + ni * 16 + 4 * q4;
+      const int n = (int)n0 + wn * 64 + ni * 16 + 4 * q4;
       float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
       if (interior) {
         if (g.has_bias) {
@@ -168,7 +250,7 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
   if (((uintptr_t)C & 15) || (has_bias && ((uintptr_t)bias & 15)) || (has_residual && ((uintptr_t)residual & 15))) return 1;
   Bf16GemmArgs g{};
   g.A = static_cast<const char*>(A), g.W = static_cast<const char*>(W), g.C = C, g.bias = bias, g.residual = residual;
-  g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr, g.M = M, g.N = N, g.K = K;
+  g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr, g.M = M, g.N = N, g.Nrows = N, g.K = K;
   g.tiles_n = (N + 127) / 128;
   g.has_bias = has_bias, g.has_residual = has_residual, g.act = act, g.out_bf16 = out_bf16;
   const int64_t blocks = ((M + 127) / 128) * g.tiles_n;
@@ -177,8 +259,31 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
     set_error("linear_bf16: grid too large");
     return GDR_EINVAL;
   }
-  hipLaunchKernelGGL(gemm_nt_bf16_glds_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  hipLaunchKernelGGL(gemm_nt_bf16_glds_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, g);
   GDR_CHECK_LAUNCH("gemm_nt_bf16_glds_kernel");
+  return 0;
+}
+
+// Similarity passes on the LDS-DMA core (bf16 corpus, bf16 queries, d % 64 == 0).  Returns 1 if not served.
+int launch_sim_bf16_glds(const void* D, int64_t N, const void* Q, int B, int d, const SimEpilogue& ep, int64_t n_doc_tiles,
+                         hipStream_t stream) {
+  if (d % 64 != 0 || ((uintptr_t)D & 15) || ((uintptr_t)Q & 15)) return 1;
+  Bf16GemmArgs g{};
+  g.A = static_cast<const char*>(Q), g.W = static_cast<const char*>(D);
+  g.lda = d, g.ldw = d, g.M = B, g.Nrows = N, g.N = 0, g.K = d;
+  g.tiles_n = (B + 127) / 128;  // query tiles
+  g.sim = ep;
+  const int64_t blocks = n_doc_tiles * g.tiles_n;
+  if (blocks <= 0) return 0;
+  if (blocks > 0x7fffffffLL) {
+    set_error("sim_bf16: grid too large");
+    return GDR_EINVAL;
+  }
+  if (ep.mode == 1)
+    hipLaunchKernelGGL(gemm_nt_bf16_glds_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  else
+    hipLaunchKernelGGL(gemm_nt_bf16_glds_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  GDR_CHECK_LAUNCH("gemm_nt_bf16_glds_kernel(sim)");
   return 0;
 }
 

@@ -803,6 +803,14 @@ int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, f
   return launch<EPI_LINEAR, true>(g, (M + BM - 1) / BM, stream);
 }
 
+static bool bf16_glds_sim() {
+  static const bool on = [] {
+    const char* e = getenv("GDR_BF16_GLDS_SIM");  // A/B knob: 0 = similarity passes on the generic core
+    return e ? atoi(e) != 0 : true;
+  }();
+  return on;
+}
+
 int launch_sim_gemm(const void* D_, int64_t N, const void* Q_, int B, int d, const SimEpilogue& ep, bool bf16,
                     hipStream_t stream) {
   const float* D = static_cast<const float*>(D_);   // opaque: the kernel addresses operands in bytes
@@ -818,11 +826,19 @@ int launch_sim_gemm(const void* D_, int64_t N, const void* Q_, int B, int d, con
     int64_t rows = n_sample_tiles * BM;
     if (rows > N) rows = N;
     ProfScope prof(PROF_SIM_SAMPLE, 2.0 * (double)rows * (double)B * (double)d, stream);
+    if (bf16 && bf16_glds_sim()) {
+      const int rc = launch_sim_bf16_glds(D_, N, Q_, B, d, ep, n_sample_tiles, stream);
+      if (rc <= 0) return rc;
+    }
     return bf16 ? launch<EPI_SIM_SAMPLE, true>(g, n_sample_tiles, stream) : launch<EPI_SIM_SAMPLE>(g, n_sample_tiles, stream);
   }
   int64_t rows = (tiles_m - n_sample_tiles) * BM;
   if (rows > N) rows = N;
   ProfScope prof(PROF_SIM_FILTER, 2.0 * (double)rows * (double)B * (double)d, stream);
+  if (bf16 && bf16_glds_sim()) {
+    const int rc = launch_sim_bf16_glds(D_, N, Q_, B, d, ep, tiles_m - n_sample_tiles, stream);
+    if (rc <= 0) return rc;
+  }
   return bf16 ? launch<EPI_SIM_FILTER, true>(g, tiles_m - n_sample_tiles, stream)
               : launch<EPI_SIM_FILTER>(g, tiles_m - n_sample_tiles, stream);
 }
