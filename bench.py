@@ -112,6 +112,9 @@ def main():
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        _t = torch.ones(1, device=dev)
+        dist.all_reduce(_t)                  # communicator set-up (RCCL connects lazily) stays out of the timed region
+        torch.cuda.synchronize()             # even with --warmup 0
     torch.set_grad_enabled(False)
 
     from gdr_amd import ops, synth, _ffi
