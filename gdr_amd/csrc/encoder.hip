@@ -46,6 +46,7 @@ namespace gdr {
 static int t5_encoder_impl(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L,
                            float* out_hidden, float* out_pooled, void* workspace, size_t workspace_bytes, bool bf16,
                            hipStream_t stream) {
+  if (B == 0) return GDR_OK;  // empty batch
   GDR_CHECK_ARG(w && ids && out_hidden && workspace, "t5_encoder: null pointer");
   const GdrT5Dims& dm = w->dims;
   GDR_CHECK_ARG(B > 0 && L > 0 && L <= 128, "t5_encoder: B=%d L=%d (L must be in [1,128])", B, L);

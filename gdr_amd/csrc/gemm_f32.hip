@@ -654,6 +654,7 @@ int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, 
 int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                          int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
                          float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream) {
+  if (M == 0) return GDR_OK;  // empty batch: nothing to do (pointers of empty tensors may be null)
   GDR_CHECK_ARG(A && W && C, "linear: null pointer");
   GDR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
   GDR_CHECK_ARG(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "linear: K, lda, ldw must be multiples of 4");
@@ -765,6 +766,7 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
 // v_mfma_f32_32x32x16_bf16; no split-K form.
 int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                        int K, int epilogue, const float* bias, const float* residual, int64_t ldr, hipStream_t stream) {
+  if (M == 0) return GDR_OK;
   GDR_CHECK_ARG(A && W && C, "linear_bf16: null pointer");
   GDR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear_bf16: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
   GDR_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "linear_bf16: K, lda, ldw must be multiples of 8");

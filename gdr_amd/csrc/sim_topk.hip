@@ -326,6 +326,7 @@ static int sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, 
 
 namespace gdr {
 int launch_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, hipStream_t stream) {
+  if (n == 0) return GDR_OK;
   GDR_CHECK_ARG(in && out_bf16 && n >= 0 && n % 4 == 0, "cast: null pointer or n %% 4 != 0");
   GDR_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)out_bf16 & 7) == 0, "cast: misaligned pointer");
   if (n == 0) return GDR_OK;
@@ -357,6 +358,7 @@ extern "C" int gdr_sim_topk_bf16(const void* Q, int B, const void* D, int64_t N,
 int gdr::sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, int k, int32_t idx_offset,
                        float* out_val, int32_t* out_idx, int32_t* status, int flags, void* workspace,
                        size_t workspace_bytes, bool bf16, hipStream_t stream) {
+  if (B == 0) return GDR_OK;  // empty query batch
   GDR_CHECK_ARG(Q && D && out_val && out_idx && workspace, "sim_topk: null pointer");
   GDR_CHECK_ARG(B > 0 && N > 0 && d > 0 && d % (bf16 ? 8 : 4) == 0, "sim_topk: bad shape B=%d N=%lld d=%d", B,
                 (long long)N, d);
@@ -406,6 +408,7 @@ extern "C" int gdr_topk_merge(const float* vals, const int32_t* idx, int G, int 
                               int32_t* out_idx, void* stream_) {
   using namespace gdr;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (B == 0) return GDR_OK;
   GDR_CHECK_ARG(vals && idx && out_val && out_idx, "topk_merge: null pointer");
   GDR_CHECK_ARG(G > 0 && B > 0 && k >= 1 && k <= 1024, "topk_merge: bad shape G=%d B=%d k=%d", G, B, k);
   const int kpad = next_pow2(k);

@@ -152,6 +152,37 @@ def test_linear_is_exact_fmaf_chain_on_integers(dev):
     assert torch.equal(out, w.T.contiguous())
 
 
+def test_empty_batches_give_empty_results(dev):
+    """An empty query batch is not an error anywhere on the path (torch semantics: empty in, empty out)."""
+    from gdr_amd import ops
+    W = torch.randn(8, 64, device=dev)
+    assert ops.linear(torch.empty(0, 64, device=dev), W).shape == (0, 8)
+    assert ops.linear_bf16(torch.empty(0, 64, device=dev), W).shape == (0, 8)
+    D = torch.randn(1000, 64, device=dev)
+    v, i = ops.sim_topk(torch.empty(0, 64, device=dev), D, 10)
+    assert v.shape == (0, 10) and i.shape == (0, 10)
+    vm, im = ops.topk_merge(torch.empty(2, 0, 10, device=dev), torch.empty(2, 0, 10, dtype=torch.int32, device=dev))
+    assert vm.shape == (0, 10) and im.shape == (0, 10)
+    cfg = GDRConfig.tiny()
+    enc = ops.T5EncoderHandle(cfg, synth.make_state_dict(cfg, seed=1, with_decoder=False), dev)
+    z = torch.empty(0, 5, dtype=torch.int64, device=dev)
+    h, pooled = enc.forward(z, z)
+    assert h.shape == (0, 5, cfg.d_model) and pooled.shape == (0, cfg.d_model)
+
+
+def test_encoder_fully_masked_row_matches_oracle(dev):
+    """A query whose attention mask is all zero: every key gets -1e9, softmax is uniform (modeling_utils.py:271-272)."""
+    from gdr_amd import ops
+    from oracle import t5_ref
+    cfg = GDRConfig.tiny()
+    sd = synth.make_state_dict(cfg, seed=3, with_decoder=False)
+    ids = torch.randint(0, cfg.vocab_size, (3, 6), generator=torch.Generator().manual_seed(1))
+    mask = torch.tensor([[1, 1, 1, 0, 0, 0], [0, 0, 0, 0, 0, 0], [1, 1, 1, 1, 1, 1]])
+    ref = t5_ref.encoder_forward(sd, cfg, ids, mask)
+    h, _ = ops.T5EncoderHandle(cfg, sd, dev).forward(ids.to(dev), mask.to(dev))
+    torch.testing.assert_close(h.cpu(), ref, rtol=TOL, atol=TOL)
+
+
 # ------------------------------------------------------------------------------------------- encoder
 def test_encoder_tiny_vs_reference_golden(dev):
     from gdr_amd import ops
