@@ -400,13 +400,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
   const int a_rd = (wm * 64 + l31) * LDS_STRIDE + 4 * h;
   const int b_rd = (wn * 64 + l31) * LDS_STRIDE + 4 * h;
   const int nk = g.K / BK;
+  const int tiles_m = (int)((g.M + BM - 1) / BM);
 
   int64_t a_ld[4];  // element offsets from g.A / g.W — kept as integers: pointers that pass through the tile-crossing
   int64_t w_ld[4];  // select lose their address space and the loads degrade to flat_load (vmcnt AND lgkmcnt)
+// tile index -> (row panel, column tile): supertiles of GM row panels x all column tiles, row-panel-fastest inside, so
+// that the 64 tiles an XCD works on at a time are ~8 row panels x 8 column tiles (16 operand panels through its L2)
+// instead of a few row panels x every column tile (N=3072: 27 panels).  GM travels in g.ksplit (unused by this kernel).
+#define P_TILE_MN(tile_, mt_, nt_)                                           \
+  {                                                                          \
+    const int per_ = g.ksplit * g.tiles_n;                                   \
+    const int grp_ = (tile_) / per_, loc_ = (tile_) - grp_ * per_;           \
+    const int gm_ = min(g.ksplit, tiles_m - grp_ * g.ksplit);                \
+    nt_ = loc_ / gm_;                                                        \
+    mt_ = grp_ * g.ksplit + (loc_ - nt_ * gm_);                              \
+  }
 #define P_SETPTRS(tile_)                                                     \
   {                                                                          \
-    const int mt_ = (tile_) / g.tiles_n;                                     \
-    const int nt_ = (tile_) - mt_ * g.tiles_n;                               \
+    int mt_, nt_;                                                            \
+    P_TILE_MN(tile_, mt_, nt_)                                               \
     _Pragma("unroll") for (int p = 0; p < 4; ++p) {                          \
       int64_t ra_ = (int64_t)mt_ * BM + lrow + 32 * p;                       \
       ra_ = ra_ < g.M ? ra_ : g.M - 1;                                       \
@@ -518,9 +530,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
     if (++kt == nk) {
       // epilogue of this tile: stores only (plus the residual / bias loads), no LDS — the other waves are already
       // in the next tile's first K-step.  Accumulator map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-      const int mt = tile / g.tiles_n;
+      int mt, nt;
+      P_TILE_MN(tile, mt, nt)
       const int64_t m0 = (int64_t)mt * BM;
-      const int n0 = (tile - mt * g.tiles_n) * BN;
+      const int n0 = nt * BN;
       if (m0 + BM <= g.M && n0 + BN <= g.N) {
         // interior tile: uniform branches only, so that the 64 residual loads go out as one batch and the 64 stores
         // as another (per-element flag tests serialise them behind a vmcnt(0) each)
@@ -588,6 +601,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
       tile += G;
     }
   }
+#undef P_TILE_MN
 #undef P_SETPTRS
 #undef P_GLOAD
 #undef P_ADVANCE
@@ -755,6 +769,16 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
     return e ? atoi(e) != 0 : true;
   }();
   if (persist_on && tiles > SLOTS && tiles < 0x7fffffff && K % BK == 0) {  // more than one round of tiles: persistent form
+    {
+      static const int gm_env = [] {
+        const char* e = getenv("GDR_GEMM_SUPERTILE");  // row panels per supertile, every shape; unset = by shape
+        return e ? atoi(e) : 0;
+      }();
+      // Measured HBM-side fetch per launch (PMC, M = 20480): N=3072 1112 -> 557 MB and N=2304 653 -> 443 MB with 8-panel
+      // supertiles, but N=768 552 -> 684 MB (its 6 column tiles already fit one XCD's L2 next to 10 row panels): wide
+      // outputs only.  Time is unchanged either way (the kernel is MFMA-bound); this is traffic and energy.
+      g.ksplit = gm_env > 0 ? gm_env : (g.tiles_n >= 12 ? 8 : 1);
+    }
     hipLaunchKernelGGL(gemm_nt_f32_persistent_kernel, dim3((unsigned)SLOTS), dim3(GEMM_THREADS), 0, stream, g, (int)tiles);
     GDR_CHECK_LAUNCH("gemm_nt_f32_persistent_kernel");
     return GDR_OK;

@@ -48,9 +48,10 @@ with open(f"profiles/{tag}_bench_pmc_hbm.md", "w") as o:
         o.write(f"| `{k[:70]}` | {t[0]} | {(t[1] + t[2]) / t[0] / 1e6:.1f} MB |\n")
         out[k] = (t[1] + t[2]) / t[0]
     o.write("\nAlgorithmic bytes of the linear GEMM, averaged over its four call shapes per layer (A + W + C (+ residual)): "
-            "290 MB/launch.  The excess is the W panel (7-9.4 MB) cycling through one XCD's 4 MiB L2 under the n-fastest tile "
-            "order and being re-read through the Infinity Cache; the kernel is MFMA-bound, so this costs energy rather than time "
-            "(an m-fastest supertile order was measured in tools/gemm_lab.hip: +3-5 % on the old loop, 0 % on the current one).\n")
+            "290 MB/launch.  The excess is operand panels re-read through the Infinity Cache when an XCD's 4 MiB L2 cannot "
+            "hold the panels of the 64 tiles it works on: wide outputs (N = 2304, 3072) run in 8-row-panel supertiles "
+            "(1112 -> 557 MB and 653 -> 443 MB fetched per launch), N = 768 keeps the column-fastest order (552 MB; supertiles "
+            "made it 684).  The kernel is MFMA-bound, so this is energy rather than time (bench identical to 0.1 %).\n")
 key = [k for k in out if "gemm_nt_f32_persistent_kernel" in k or "gemm_nt_f32_kernel<0, false>" in k][0]   # the linear GEMM (persistent form in the bench)
 json.dump({"linear_gemm_bytes_per_launch": out[key], "kernel": key, "source": f"profiles/{tag}_bench_pmc_hbm.md"},
           open("profiles/traffic.json", "w"), indent=1)
