@@ -7,7 +7,8 @@ A step = one pass of the hot path over one batch of synthetic input:
 N = 1 runs BASELINE config C2 (batch 512, whole corpus on one GPU).  N > 1 (one process per GPU, launched by
 torch.distributed.run) runs C4's layout with weak scaling: every rank encodes its own 512 queries, the corpus
 is row-sharded N ways, pooled queries are all-gathered, each rank searches its shard for all 512·N queries,
-and ONE all-gather of the per-shard (score,id)[B,k] lists precedes the local merge (gdr_amd/dist.py).
+and ONE all-to-all of the per-shard (score,id)[B,k] lists hands every rank the lists of its own 512 queries, which
+it merges (gdr_amd/dist.py; --replicated-merge: all-gather + merge of all queries on every rank).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fp32 MFMA GEMM that serves every
 encoder linear: algorithmic flops per launch / average launch duration, both measured live over the timed
@@ -43,6 +44,9 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = the reference's precision (the headline); bf16 = config C5's precision mode: bf16 linear "
                          "operands in the encoder and a bf16 corpus, fp32 accumulate (not comparable with the f32 line)")
+    ap.add_argument("--replicated-merge", action="store_true",
+                    help="N > 1: all-gather the per-shard lists and merge all queries on every rank (instead of the "
+                         "all-to-all that hands each rank the lists of its own queries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     return ap.parse_args()
@@ -138,7 +142,7 @@ def main():
     def step():
         _, pooled = enc.forward(ids, mask)
         q_all = index.gather_queries(pooled)
-        return index.search(q_all, a.k)
+        return index.search(q_all, a.k) if a.replicated_merge else index.search_own(q_all, a.k)
 
     def fence():
         torch.cuda.synchronize()
@@ -192,7 +196,7 @@ def main():
                        f": t5-base encoder on {a.batch} queries/GPU (L=40) + fused Q.D^T top-{a.k} over a "
                        f"{a.corpus}x{cfg.d_model} {'bf16' if bf16 else 'fp32'} corpus" +
                        (" [C5 precision mode: bf16 linear operands, fp32 accumulate]" if bf16 else "") + ("" if world == 1 else f" row-sharded {world} ways, "
-                       "all-gather of queries and of per-shard top-k, local merge"),
+                       "all-gather of queries, all-to-all of per-shard top-k, local merge"),
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 40,
                        "corpus_rows": a.corpus, "dim": cfg.d_model, "k": a.k, "corpus_resident_in_hbm": True},
             "roofline": {"bound": "mfma", "kernel": ("gdr::gemm_nt_bf16_glds_kernel (bf16 operands, LDS-DMA staging; every encoder linear)"

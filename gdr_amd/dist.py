@@ -5,6 +5,9 @@ given, so a cluster never straddles ranks).  A search step is
     all-gather of the per-rank query embeddings  ->  local fused sim+top-k on the shard (doc ids offset by lo)
     -> ONE all-gather of the per-shard (score fp32, id int32)[B,k] lists (RCCL over xGMI; B*k*8 bytes per rank)
     -> local merge [G,B,k] -> [B,k], bit-identical on every rank (tie rule: higher score, then lower id).
+`search_own` is the serving form: a rank only needs the answers to its OWN queries, so the per-shard lists are exchanged
+with one all-to-all (rank j receives, from every rank, the lists of j's query block: B_local*k*8 bytes per peer instead
+of B*k*8) and each rank merges [G,B_local,k] — 1/G of the traffic and of the merge work of the replicated form.
 The reference has no inference-time collective; its closest analogues are the training-time all_gather of
 reps (GDR_model/encoder.py:134-145) and the offline per-GPU partitioning of Data_process/NQ_dataset/bert/bert.py:51-61.
 
@@ -57,3 +60,19 @@ class ShardedIndex:
         dist.all_gather_into_tensor(gv, v.contiguous(), group=self.group)
         dist.all_gather_into_tensor(gi, i.contiguous(), group=self.group)
         return self.merge(gv.view(self.world, B, k), gi.view(self.world, B, k))
+
+    def search_own(self, q_all, k):
+        """q_all [B,d] identical on every rank (rank-major blocks of B/world queries) -> top-k of THIS rank's query block:
+        (values [B/world,k], global doc ids int32 [B/world,k]).  Same lists as search()[rank block]."""
+        v, i = self.local_topk(q_all, self.D, k, self.lo)
+        if not self.distributed:
+            return v, i
+        B = q_all.shape[0]
+        if B % self.world:
+            raise ValueError("search_own: the gathered batch must hold the same number of queries per rank")
+        bl = B // self.world
+        rv = torch.empty_like(v)                       # [world*bl, k]: block g = rank g's list for my queries
+        ri = torch.empty_like(i)
+        dist.all_to_all_single(rv, v.contiguous(), group=self.group)
+        dist.all_to_all_single(ri, i.contiguous(), group=self.group)
+        return self.merge(rv.view(self.world, bl, k), ri.view(self.world, bl, k))

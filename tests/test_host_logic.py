@@ -166,8 +166,11 @@ def _gloo_worker(rank, world, port, tmp):
         assert torch.equal(q_all, torch.from_numpy(Q))
         v, i = index.search(q_all, k)
         rv, ri = retrieval_ref.sim_topk(torch.from_numpy(Q), torch.from_numpy(D), k)
+        vo, io = index.search_own(q_all, k)              # all-to-all form: this rank's query block only
+        blk = slice(rank * B_local, (rank + 1) * B_local)
         np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([int(torch.equal(i.to(torch.int64), ri)),
-                                                             int(torch.allclose(v, rv, atol=1e-6))]))
+                                                             int(torch.allclose(v, rv, atol=1e-6)),
+                                                             int(torch.equal(io, i[blk]) and torch.equal(vo, v[blk]))]))
     finally:
         dist.destroy_process_group()
 
@@ -186,7 +189,7 @@ def test_sharded_search_two_ranks_gloo(tmp_path):
     s.close()
     mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
-        assert np.load(tmp_path / f"ok{r}.npy").tolist() == [1, 1]
+        assert np.load(tmp_path / f"ok{r}.npy").tolist() == [1, 1, 1]
 
 
 def test_trie_flattening_matches_reference_treebuilder_semantics():
