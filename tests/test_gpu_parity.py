@@ -428,3 +428,25 @@ def test_rerank_vs_reference_golden(dev):
     v, i = ops.rerank_topk(torch.from_numpy(g["Q"]).to(dev), torch.from_numpy(g["D"]).to(dev), offs.to(dev), ids.to(dev),
                            torch.from_numpy(g["beam_scores"]).to(dev), g["alphas"].tolist(), R, max_cand=max_cand)
     assert np.array_equal(i.cpu().numpy().astype(np.int64), g["pred"])
+
+
+def test_integration_md_stub_runs_as_written(dev):
+    """The ctypes stub printed in INTEGRATION.md §2 is executed verbatim (from the repository root, as the text says) and
+    must reproduce scores.topk(k) of the reference's `q @ p.T` (dense.py:53-54)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        ns = {}
+        exec(compile(code, "INTEGRATION.md", "exec"), ns)
+        D = synth.make_corpus(20000, 64, seed=2)
+        Q, _ = synth.make_queries(D, 9, seed=3)
+        v, i = ns["sim_topk"](torch.from_numpy(Q).to(dev), torch.from_numpy(D).to(dev), 10)
+    finally:
+        os.chdir(cwd)
+    rv, ri = (torch.from_numpy(Q) @ torch.from_numpy(D).T).topk(10)
+    order_insensitive_topk_match(rv.numpy(), ri.numpy(), v.cpu().numpy(), i.cpu().numpy(), TOL)
