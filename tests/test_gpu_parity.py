@@ -430,6 +430,52 @@ def test_rerank_vs_reference_golden(dev):
     assert np.array_equal(i.cpu().numpy().astype(np.int64), g["pred"])
 
 
+@pytest.mark.parametrize("func", ["tanh", "sigmoid"])
+def test_rerank_random_ragged_vs_oracle(dev, func):
+    """Ragged candidate segments (clusters of 1..40 docs, some empty, duplicates across clusters), values and ids against
+    the oracle for every alpha; a query with fewer than k candidates fills the tail with (-inf, -1)."""
+    from gdr_amd import ops
+    from oracle import retrieval_ref
+    rng = np.random.Generator(np.random.PCG64(17))
+    B, R, N, d, k = 7, 5, 3000, 768, 12
+    D = synth.make_corpus(N, d, seed=21)
+    Q, _ = synth.make_queries(D, B, seed=22)
+    Q *= 0.1                                      # keep tanh / sigmoid away from saturation: ties would hide id errors
+    mem_q, num_q, offs, flat = [], [], [0], []
+    for b in range(B):
+        mem, nums = [], []
+        for j in range(R):
+            n = 0 if (b + j) % 4 == 0 else int(rng.integers(1, 41))
+            if b == 3:
+                n = min(n, 2)                     # this query ends with fewer than k candidates
+            ids = rng.integers(0, N, n).tolist()
+            mem += ids
+            nums.append(n)
+            flat += ids
+            offs.append(offs[-1] + n)
+        mem_q.append(mem)
+        num_q.append(nums)
+    beam = rng.standard_normal((B, R)).astype(np.float32)
+    alphas = [0, 0.5, 1, 2, 3]
+    v, i = ops.rerank_topk(torch.from_numpy(Q).to(dev), torch.from_numpy(D).to(dev),
+                           torch.tensor(offs, dtype=torch.int32, device=dev), torch.tensor(flat, dtype=torch.int32, device=dev),
+                           torch.from_numpy(beam).to(dev), alphas, k, func=func)
+    v, i = v.cpu().numpy(), i.cpu().numpy()
+    for b in range(B):
+        n_c = len(mem_q[b])
+        kk = min(k, n_c)
+        ref = retrieval_ref.rerank(torch.from_numpy(Q[b:b + 1]), torch.from_numpy(D), [mem_q[b]], [num_q[b]],
+                                   beam[b:b + 1].tolist(), alphas, kk, func=func)[0] if kk else None
+        for a in range(len(alphas)):
+            if kk:
+                rv, ri = ref[a]
+                np.testing.assert_allclose(v[b, a, :kk], rv.numpy(), rtol=TOL, atol=TOL)
+                same = np.abs(np.diff(rv.numpy())) > 4 * TOL          # ids exact where neighbouring scores are apart
+                ok = np.r_[True, same] & np.r_[same, True]
+                assert np.array_equal(i[b, a, :kk][ok], ri.numpy()[ok])
+            assert (i[b, a, kk:] == -1).all() and np.isneginf(v[b, a, kk:]).all()
+
+
 def test_integration_md_stub_runs_as_written(dev):
     """The ctypes stub printed in INTEGRATION.md §2 is executed verbatim (from the repository root, as the text says) and
     must reproduce scores.topk(k) of the reference's `q @ p.T` (dense.py:53-54)."""
