@@ -1,0 +1,43 @@
+"""bench.py's output contract (the round driver parses this line): one JSON line on stdout with the agreed keys, the
+`roofline` and `cpu_baseline` objects, recall parity, on a reduced workload so that the test takes seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64",
+                          "--corpus", "30000", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_fp32():
+    j = _run()
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["dtype"] == "f32" and j["data"] == "synthetic" and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert j["value"] > 0 and abs(j["value"] - 64 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    rec = j["recall"]
+    assert rec["gpu"] == rec["cpu_oracle"], "Recall@{1,10,100} parity with the CPU oracle"
+
+
+def test_bench_line_contract_bf16_mode():
+    j = _run("--dtype", "bf16", "--no-cpu-baseline")
+    assert j["dtype"] == "bf16" and j["cpu_baseline"] is None and j["roofline"]["peak"] == 2500.0
