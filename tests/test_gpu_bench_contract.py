@@ -41,3 +41,23 @@ def test_bench_line_contract_fp32():
 def test_bench_line_contract_bf16_mode():
     j = _run("--dtype", "bf16", "--no-cpu-baseline")
     assert j["dtype"] == "bf16" and j["cpu_baseline"] is None and j["roofline"]["peak"] == 2500.0
+
+
+def test_bench_under_torchrun_one_rank_rccl():
+    """The N > 1 code path (process group over RCCL, query all-gather, all-to-all of the per-shard lists, barrier + max
+    over ranks) with a 1-rank group — what one GPU can exercise of it."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    for extra in ([], ["--replicated-merge"]):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                              "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64", "--corpus", "30000",
+                              "--no-cpu-baseline", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 1 and j["value"] > 0 and j["cpu_baseline"] is None
