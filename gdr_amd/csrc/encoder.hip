@@ -3,10 +3,12 @@
 //
 // Per layer (pre-norm, T5 v1.0):   h += o(attn(qkv(rms(h))))    ;    h += wo(relu(wi(rms(h))))
 //   rms           layers.hip  rmsnorm_kernel                                  (modeling_t5.py:164-171)
-//   qkv / o / wi / wo   gemm_f32.hip on v_mfma_f32_32x32x2_f32; q,k,v fused into one [3*inner,d] GEMM,
+//   qkv / o / wi / wo   gemm_f32.hip on v_mfma_f32_32x32x2_f32 (persistent form at encoder batch sizes); q,k,v fused into
+//                 one [3*inner,d] GEMM,
 //                 residual add and ReLU fused into the GEMM epilogues        (:360-364,:413,:182-185,:199)
-//   attn          layers.hip  attention_kernel: QKᵀ (no 1/sqrt(d)) + bucketed relative bias + pad mask
-//                 (1-m)*-1e9 + fp32 softmax + PV, one workgroup per (query, head)   (:384-413, :290-314)
+//   attn          layers.hip  attention_mfma16_kernel (d_kv = 64: S^T = K·Q^T and O^T = V^T·P^T on v_mfma_f32_16x16x4_f32, one
+//                 wave per 16-query tile) or attention_kernel (any d_kv): QKᵀ (no 1/sqrt(d)) + bucketed relative bias +
+//                 pad mask (1-m)*-1e9 + fp32 softmax + PV                           (:384-413, :290-314)
 // The position bias is never materialised as a [B,H,L,L] tensor: the kernel re-derives it from the
 // [buckets,H] table (layer 0's, shared by all layers as in :790-795).
 #include "layers.h"
