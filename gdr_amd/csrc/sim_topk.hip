@@ -132,6 +132,7 @@ __global__ __launch_bounds__(1024) void sim_threshold_kernel(const float* __rest
   const int q = blockIdx.x;
   const float* v = cand_val + (int64_t)q * cap;
   uint32_t lo = 0xFFFFFFFFu, hi = 0u;  // range of the real scores; -inf padding slots of a ragged tile stay below it
+#pragma unroll 4
   for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
     const float x = v[i];
     if (x > -INFINITY) {
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(1024) void sim_threshold_kernel(const float* __rest
     const int shift = 24 - 8 * pass;
     if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
+  #pragma unroll 4
+  for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
       const uint32_t raw = fkey(v[i]);
       const uint32_t key = (raw - lo) << lsh;
       const bool match = pass == 0 ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
   };
   // sweep 0: live range of the score keys
   uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll 4
   for (int i = threadIdx.x; i < count; i += blockDim.x) {
     const int64_t a = addr_of(i);
     if (idxs[a] >= 0) {
@@ -235,7 +238,8 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
     const int shift = 56 - 8 * pass;
     if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+  #pragma unroll 4
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
       const unsigned long long key = key_at(i, nullptr);
       const bool match = pass == 0 ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
       if (match && key != 0ull) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
   if (threadIdx.x == 0) n_out = 0;
   for (int i = threadIdx.x; i < kpad; i += blockDim.x) sortbuf[i] = 0ull;
   __syncthreads();
+#pragma unroll 4
   for (int i = threadIdx.x; i < count; i += blockDim.x) {
     unsigned long long raw = 0ull;
     const unsigned long long key = key_at(i, &raw);
