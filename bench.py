@@ -134,7 +134,7 @@ def main():
     D_dev = torch.from_numpy(D[lo:hi]).to(dev)
     if bf16:
         D_dev = ops.to_bf16(D_dev)
-    index = ShardedIndex(D_dev, lo)
+    index = ShardedIndex(D_dev, lo, exact=False)     # no host sync in the timed region; the status is checked after it
     ids_all, mask_all = synth.make_tokens(a.batch * world, L=40, seed=11)
     ids = torch.from_numpy(ids_all[rank * a.batch:(rank + 1) * a.batch]).to(dev)
     mask = torch.from_numpy(mask_all[rank * a.batch:(rank + 1) * a.batch]).to(dev)
@@ -142,7 +142,9 @@ def main():
     def step():
         _, pooled = enc.forward(ids, mask)
         q_all = index.gather_queries(pooled)
-        return index.search(q_all, a.k) if a.replicated_merge else index.search_own(q_all, a.k)
+        if a.replicated_merge:
+            return index.search(q_all, a.k, return_status=True)
+        return index.search_own(q_all, a.k, return_status=True)
 
     def fence():
         torch.cuda.synchronize()
@@ -168,6 +170,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    overflowed = int(out[2].sum().item())     # gdr_sim_topk status: rows whose candidate list overflowed (subset top-k)
+    if overflowed:
+        raise SystemExit(f"bench: {overflowed} queries overflowed their candidate lists — the step did not compute "
+                         "the exact top-k (use exact_on_overflow=True for such data)")
     total_q = a.batch * world * a.steps
     ms_per_step = dt / a.steps * 1e3
     result = None

@@ -47,7 +47,7 @@ class GdrBertWeights(C.Structure):
 
 
 class GdrTrie(C.Structure):
-    _fields_ = [("child", C.c_void_p), ("eos_ok", C.c_void_p), ("n_nodes", C.c_int32)]
+    _fields_ = [("child", C.c_void_p), ("eos_ok", C.c_void_p), ("n_nodes", C.c_int32), ("V", C.c_int32)]
 
 
 class GdrT5DecLayer(C.Structure):
@@ -87,6 +87,8 @@ SIGNATURES = {
     "gdr_sim_topk_bf16": (_i, [_vp, _i, _vp, _i64, _i, _i, C.c_int32, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "gdr_cast_f32_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "gdr_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "gdr_topk_pack": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "gdr_topk_merge_packed": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gdr_rerank_topk": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "gdr_t5_relative_bucket_table": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
     "gdr_bert_encoder_workspace_bytes": (_sz, [C.POINTER(GdrBertWeights), _i, _i]),

@@ -30,6 +30,11 @@ void set_error(const char* fmt, ...);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) once per (kernel, device): the
+// attribute lives on the device's code object, so a process that drives several GPUs must set it on each of them.
+// Thread-safe.  Returns GDR_OK or GDR_EHIP (message set).
+int ensure_dyn_lds(const void* kernel, int bytes, const char* what);
+
 // ---- opt-in launch profiler (gdr_prof_* in include/gdr_hip.h): hipEvent pairs around the launches of one
 // kernel class, recorded on the stream the kernel runs on.  Off by default: no events, no state touched.
 enum ProfClass { PROF_LINEAR = 0, PROF_SIM_SAMPLE = 1, PROF_SIM_FILTER = 2, PROF_ATTENTION = 3, PROF_NORM = 4,

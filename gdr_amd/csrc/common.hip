@@ -1,5 +1,8 @@
 #include "common.h"
 
+#include <mutex>
+#include <vector>
+
 namespace gdr {
 static thread_local char g_err[512] = "";
 
@@ -8,6 +11,34 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------- per-device kernel attributes
+namespace {
+struct AttrKey {
+  const void* fn;
+  int dev;
+};
+std::mutex g_attr_mu;
+std::vector<AttrKey> g_attr_done;
+}  // namespace
+
+int ensure_dyn_lds(const void* kernel, int bytes, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    set_error("%s: hipGetDevice failed", what);
+    return GDR_EHIP;
+  }
+  std::lock_guard<std::mutex> lock(g_attr_mu);
+  for (const AttrKey& k : g_attr_done)
+    if (k.fn == kernel && k.dev == dev) return GDR_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+    return GDR_EHIP;
+  }
+  g_attr_done.push_back(AttrKey{kernel, dev});
+  return GDR_OK;
 }
 
 // ---------------------------------------------------------------------------------------- profiler

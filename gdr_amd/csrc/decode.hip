@@ -17,6 +17,9 @@
 //     kernels per step with no host round trip; the reference syncs per candidate through .item().
 #include <math.h>
 
+#include <mutex>
+#include <vector>
+
 #include "layers.h"
 
 namespace gdr {
@@ -53,6 +56,7 @@ struct BeamDims {
   // c of the node's depth, eos_ok[node] = 1 if EOS is a child.  null = the shipped behaviour (positional mask only).
   const int32_t* trie_child;
   const int32_t* trie_eos;
+  int trie_nodes;
 };
 
 static size_t carve(size_t& o, size_t bytes) {
@@ -368,7 +372,9 @@ __global__ __launch_bounds__(64) void beam_update_kernel(BeamBufs bb, BeamDims b
     bb.parent[row] = eff;
     if (bd.trie_child) {
       const int nd = bb.node[cur][eff], c = tok - ((cur_len - 1) * bd.V + 2);
-      bb.node[cur ^ 1][row] = (nd >= 0 && c >= 0 && c < bd.V) ? bd.trie_child[(size_t)nd * bd.V + c] : -1;
+      int nx = (nd >= 0 && c >= 0 && c < bd.V) ? bd.trie_child[(size_t)nd * bd.V + c] : -1;
+      if (nx >= bd.trie_nodes) nx = -1;  // a malformed table must not send later lookups out of bounds
+      bb.node[cur ^ 1][row] = nx;
     }
   }
   for (int e = lane; e < n * (cur_len + 1); e += 64) {
@@ -484,16 +490,7 @@ static int beam_step(const BeamBufs& bb, const BeamDims& bd, int pos, int cur, f
 
 static int beam_begin(const BeamBufs& bb, const BeamDims& bd, hipStream_t stream) {
   const int rows = bd.B * bd.R;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_topk_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e != hipSuccess) {
-      set_error("beam: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return GDR_EHIP;
-    }
-    attr_set = true;
-  }
+  if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(beam_topk_kernel), 96 * 1024, "beam")) return rc__;
   hipLaunchKernelGGL(beam_init_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, bb, bd);
   GDR_CHECK_LAUNCH("beam_init_kernel");
   return GDR_OK;
@@ -510,22 +507,50 @@ static int beam_end(const BeamBufs& bb, const BeamDims& bd, int max_length, int 
 
 // The adaptor chain (decode_embeddings -> 4 post-LN layers) and the T5 decoder stack of one step are independent until
 // the head consumes both, and each of their kernels fills only part of the chip at decode batch sizes: they run
-// concurrently, the adaptor on a library-owned side stream forked / joined with events (graph-capturable pattern).
+// concurrently, the adaptor on a side stream forked / joined with events (graph-capturable pattern).  Side streams are
+// leased per CALL from a per-device pool (created on first use on the device that is current in the calling thread), so
+// concurrent gdr_t5_generate calls from several host threads or on several devices never share one.
 struct SideStream {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false;
+  int dev = -1;
 };
-static SideStream& side_stream() {
-  static SideStream ss = [] {
-    SideStream x;
-    x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
-           hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
-    return x;
-  }();
-  return ss;
+static std::mutex g_side_mu;
+static std::vector<SideStream*> g_side_free;
+
+static SideStream* side_stream_acquire() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (size_t i = 0; i < g_side_free.size(); ++i)
+      if (g_side_free[i]->dev == dev) {
+        SideStream* x = g_side_free[i];
+        g_side_free.erase(g_side_free.begin() + i);
+        return x;
+      }
+  }
+  SideStream* x = new SideStream();
+  x->dev = dev;
+  if (hipStreamCreateWithFlags(&x->s, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&x->fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&x->join, hipEventDisableTiming) != hipSuccess) {
+    delete x;  // the caller falls back to running the adaptor chain on the main stream
+    return nullptr;
+  }
+  return x;
 }
+// A lease ends when the call has finished ENQUEUEING: the stream is in-order, so the next lessee's work simply queues
+// behind what is still in flight, and a wait already enqueued on `join` keeps the event state it captured.
+struct SideLease {
+  SideStream* ss;
+  SideLease() : ss(side_stream_acquire()) {}
+  ~SideLease() {
+    if (!ss) return;
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    g_side_free.push_back(ss);
+  }
+};
 
 // ------------------------------------------------------------------------------------------ model workspace
 struct GenWs {
@@ -565,7 +590,7 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
 extern "C" size_t gdr_t5_generate_workspace_bytes(const GdrT5DecoderWeights* w, int B, int L, int num_beams,
                                                   int max_length) {
   if (!w || B <= 0 || L <= 0 || num_beams <= 0 || max_length < 2) return 0;
-  gdr::BeamDims bd{B, num_beams, w->out_vocab, w->dims.vocab_size, max_length, num_beams, 1.0, nullptr, nullptr};
+  gdr::BeamDims bd{B, num_beams, w->out_vocab, w->dims.vocab_size, max_length, num_beams, 1.0, nullptr, nullptr, 0};
   return gdr::gen_ws(*w, bd, L).total;
 }
 
@@ -579,8 +604,10 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   GDR_CHECK_ARG(w && enc_hidden && enc_mask && out_ids && out_len && out_scores && workspace, "generate: null pointer");
   const GdrT5Dims& dm = w->dims;
   BeamDims bd{B, num_beams, w->out_vocab, dm.vocab_size, max_length, num_return_sequences, length_penalty,
-              trie ? trie->child : nullptr, trie ? trie->eos_ok : nullptr};
+              trie ? trie->child : nullptr, trie ? trie->eos_ok : nullptr, trie ? trie->n_nodes : 0};
   GDR_CHECK_ARG(!trie || (trie->child && trie->eos_ok && trie->n_nodes > 0), "generate: bad trie");
+  GDR_CHECK_ARG(!trie || trie->V == w->out_vocab, "generate: trie built for V=%d but the head has output_vocab_size=%d",
+                trie ? trie->V : 0, w->out_vocab);
   int rc = check_beam_dims(bd, max_length);
   if (rc) return rc;
   GDR_CHECK_ARG(L >= 1 && L <= 128, "generate: L=%d must be in [1,128]", L);
@@ -629,8 +656,10 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   const BucketLut lut_uni = make_bucket_lut(dm.rel_buckets, dm.rel_max_distance);
   const BucketLut lut_bi = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
   int cur = 0;
+  SideLease lease;
+  struct { bool ok; hipStream_t s; hipEvent_t fork, join; } ss{lease.ss != nullptr, lease.ss ? lease.ss->s : nullptr,
+                                                            lease.ss ? lease.ss->fork : nullptr, lease.ss ? lease.ss->join : nullptr};
   for (int s = 0; s + 1 < max_length; ++s) {  // position s, cur_len = s + 1 (generation_utils.py:676)
-    SideStream& ss = side_stream();
     hipStream_t as = ss.ok ? ss.s : stream;   // adaptor stream
     GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows, d, dm.vocab_size, xd, stream));
     if (ss.ok) {
@@ -732,7 +761,7 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
 
 extern "C" size_t gdr_beam_search_table_workspace_bytes(int B, int num_beams, int max_length, int out_vocab) {
   if (B <= 0 || num_beams <= 0 || max_length < 2) return 0;
-  gdr::BeamDims bd{B, num_beams, out_vocab, out_vocab * max_length + 2, max_length, num_beams, 1.0, nullptr, nullptr};
+  gdr::BeamDims bd{B, num_beams, out_vocab, out_vocab * max_length + 2, max_length, num_beams, 1.0, nullptr, nullptr, 0};
   return gdr::beam_layout(bd, nullptr, nullptr);
 }
 
@@ -744,8 +773,10 @@ extern "C" int gdr_beam_search_table(const float* table, int B, int out_vocab, i
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GDR_CHECK_ARG(table && out_ids && out_len && out_scores && workspace, "beam_search_table: null pointer");
   BeamDims bd{B, num_beams, out_vocab, out_vocab * max_length + 2, max_length, num_return_sequences, length_penalty,
-              trie ? trie->child : nullptr, trie ? trie->eos_ok : nullptr};
+              trie ? trie->child : nullptr, trie ? trie->eos_ok : nullptr, trie ? trie->n_nodes : 0};
   GDR_CHECK_ARG(!trie || (trie->child && trie->eos_ok && trie->n_nodes > 0), "beam_search_table: bad trie");
+  GDR_CHECK_ARG(!trie || trie->V == out_vocab, "beam_search_table: trie built for V=%d but out_vocab=%d",
+                trie ? trie->V : 0, out_vocab);
   int rc = check_beam_dims(bd, max_length);
   if (rc) return rc;
   const size_t need = beam_layout(bd, nullptr, nullptr);

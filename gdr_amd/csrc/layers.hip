@@ -448,16 +448,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma_kernel(const AttnArgs 
 template <int NT>
 static int launch_attention_mfma(const AttnArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * ((size_t)3 * a.Lk * 68 + 3 * 32 * NT);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel<NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return GDR_EHIP;
-    }
-    attr_set = true;
-  }
+  if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(attention_mfma_kernel<NT>), 160 * 1024, "attention")) return rc__;
   hipLaunchKernelGGL(attention_mfma_kernel<NT>, dim3((unsigned)(a.B * a.H)), dim3(64 * NT), lds, stream, a);
   GDR_CHECK_LAUNCH("attention_mfma_kernel");
   return GDR_OK;
@@ -595,16 +586,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
 template <int NT>
 static int launch_attention_mfma16(const AttnArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * ((size_t)3 * a.Lk * 68 + 3 * 16 * NT);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma16_kernel<NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return GDR_EHIP;
-    }
-    attr_set = true;
-  }
+  if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(attention_mfma16_kernel<NT>), 160 * 1024, "attention")) return rc__;
   hipLaunchKernelGGL(attention_mfma16_kernel<NT>, dim3((unsigned)(a.B * a.H)), dim3(64 * NT), lds, stream, a);
   GDR_CHECK_LAUNCH("attention_mfma16_kernel");
   return GDR_OK;
@@ -732,16 +714,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   const int dks = a.dk + 4, Lkp = (a.Lk + 3) & ~3;
   const size_t lds = sizeof(float) * ((size_t)2 * a.Lk * dks + 4 * a.dk + 4 * Lkp + 256);
   GDR_CHECK_ARG(lds <= 160 * 1024, "attention: Lk=%d dk=%d needs %zu B of LDS", a.Lk, a.dk, lds);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return GDR_EHIP;
-    }
-    attr_set = true;
-  }
+  if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(attention_kernel), 160 * 1024, "attention")) return rc__;
   int chunks = (512 + a.B * a.H - 1) / (a.B * a.H);  // aim at ~2 workgroups per CU, at least 4 rows (one per wave) each
   const int max_chunks = (a.Lq + 3) / 4;
   chunks = chunks < 1 ? 1 : (chunks > max_chunks ? max_chunks : chunks);

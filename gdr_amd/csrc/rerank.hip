@@ -145,16 +145,7 @@ extern "C" int gdr_rerank_topk(const float* q, const float* D, int d, const int3
   int npad = 64;
   while (npad < max_cand) npad <<= 1;
   const size_t lds = (size_t)npad * (8 + 4 + 4) + (size_t)R * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rerank_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) {
-      set_error("rerank: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return GDR_EHIP;
-    }
-    attr_set = true;
-  }
+  if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(rerank_kernel), 150 * 1024, "rerank")) return rc__;
   hipLaunchKernelGGL(rerank_kernel, dim3(B), dim3(RR_THREADS), lds, stream, q, D, d / 4, cand_offsets, cand_ids,
                      beam_scores, R, alphas, A, k, func, npad, out_val, out_idx);
   GDR_CHECK_LAUNCH("rerank_kernel");

@@ -231,19 +231,10 @@ int launch_sim_stream(const float* D, int64_t N, const float* Q, int B, int d, c
   g.n_tiles = ep.mode == 1 ? n_sample_tiles : tiles_m - n_sample_tiles;
   if (g.n_tiles <= 0) return GDR_OK;
   const size_t lds = (size_t)32 * (d + 4) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sim_stream_f32_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(sim_stream_f32_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(sim_stream_sample_splitk_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      set_error("sim_stream: hipFuncSetAttribute failed");
-      return GDR_EHIP;
-    }
-    attr_set = true;
-  }
+  for (const void* fn : {reinterpret_cast<const void*>(sim_stream_f32_kernel<1>),
+                         reinterpret_cast<const void*>(sim_stream_f32_kernel<2>),
+                         reinterpret_cast<const void*>(sim_stream_sample_splitk_kernel)})
+    if (int rc = ensure_dyn_lds(fn, 160 * 1024, "sim_stream")) return rc;
   int64_t blocks = (g.n_tiles * 4 + STREAM_WAVES - 1) / STREAM_WAVES;
   if (blocks > 256) blocks = 256;  // persistent: one workgroup per CU
   const double rows = (double)(g.n_tiles * 128 < N ? g.n_tiles * 128 : N);

@@ -173,14 +173,17 @@ __global__ __launch_bounds__(1024) void sim_threshold_kernel(const float* __rest
 // ---- step 4 / merge: exact top-k of a candidate list, sorted ------------------------------------
 // MERGE = false: entries cand_val/cand_idx[q*cap + i], i < min(cnt[q], cap); thr[q] (the k-th largest sample score,
 //                at least k entries reach it) bounds the live range from below
-// MERGE = true : entries vals/idx[(g*B + q)*k + j], i = g*k + j < G*k
+// MERGE = true : entries vals/idx[((g*B + q)*rs + j)*es], i = g*k + j < G*k.  rs = entries per (shard, query) row (k, or
+//                k+1 when a trailing status entry rides along), es = element stride (2 when vals/idx interleave as
+//                {score, id} pairs).  With rs > k and `status`, status[q] = OR over shards of the trailing entry's id.
 template <bool MERGE>
 __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restrict__ vals,
                                                            const int32_t* __restrict__ idxs,
                                                            const int32_t* __restrict__ cnt, int64_t cap, int G, int B,
                                                            int k, int kpad, int32_t idx_offset,
                                                            const float* __restrict__ thr, float* out_val,
-                                                           int32_t* out_idx, int32_t* __restrict__ status) {
+                                                           int32_t* out_idx, int32_t* __restrict__ status, int rs,
+                                                           int es) {
   __shared__ int hist[256];
   __shared__ int scan[256];
   __shared__ int res[2];
@@ -191,6 +194,11 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
   int count;
   if (MERGE) {
     count = G * k;
+    if (status && rs > k && threadIdx.x == 0) {
+      int32_t any = 0;
+      for (int g = 0; g < G; ++g) any |= idxs[(((int64_t)g * B + q) * rs + k) * es];
+      status[q] = any != 0 ? 1 : 0;
+    }
   } else {
     const int c = cnt[q];
     count = c < (int)cap ? c : (int)cap;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
   auto addr_of = [&](int i) -> int64_t {
     if (MERGE) {
       const int g = i / k, j = i - g * k;
-      return ((int64_t)g * B + q) * k + j;
+      return (((int64_t)g * B + q) * rs + j) * es;
     }
     return (int64_t)q * cap + i;
   };
@@ -404,7 +412,7 @@ int gdr::sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, in
   const int kpad = next_pow2(k);
   hipLaunchKernelGGL(topk_select_kernel<false>, dim3(B), dim3(sel_threads), kpad * sizeof(unsigned long long), stream,
                      ep.cand_val, ep.cand_idx, ep.cand_cnt, p.cap, 1, B, k, kpad, idx_offset, (const float*)thr, out_val,
-                     out_idx, status);
+                     out_idx, status, 0, 1);
   GDR_CHECK_LAUNCH("topk_select_kernel");
   return GDR_OK;
 }
@@ -419,7 +427,57 @@ extern "C" int gdr_topk_merge(const float* vals, const int32_t* idx, int G, int 
   const int kpad = next_pow2(k);
   hipLaunchKernelGGL(topk_select_kernel<true>, dim3(B), dim3(SEL_THREADS), kpad * sizeof(unsigned long long), stream,
                      vals, idx, (const int32_t*)nullptr, (int64_t)0, G, B, k, kpad, 0, (const float*)nullptr, out_val, out_idx,
-                     (int32_t*)nullptr);
+                     (int32_t*)nullptr, k, 1);
   GDR_CHECK_LAUNCH("topk_select_kernel<merge>");
+  return GDR_OK;
+}
+
+namespace gdr {
+// pairs[q][j] = {score bits, id} for j < k, pairs[q][k] = {0, status[q]}: one 8-byte-per-entry message per query row
+__global__ void topk_pack_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx,
+                                 const int32_t* __restrict__ status, int B, int k, int2* __restrict__ pairs) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)B * (k + 1)) return;
+  const int q = (int)(e / (k + 1)), j = (int)(e - (int64_t)q * (k + 1));
+  int2 o;
+  if (j < k) {
+    o.x = __float_as_int(vals[(int64_t)q * k + j]);
+    o.y = idx[(int64_t)q * k + j];
+  } else {
+    o.x = 0;
+    o.y = status ? status[q] : 0;
+  }
+  pairs[e] = o;
+}
+}  // namespace gdr
+
+extern "C" int gdr_topk_pack(const float* vals, const int32_t* idx, const int32_t* status, int B, int k, void* pairs,
+                             void* stream_) {
+  using namespace gdr;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (B == 0) return GDR_OK;
+  GDR_CHECK_ARG(vals && idx && pairs, "topk_pack: null pointer");
+  GDR_CHECK_ARG(B > 0 && k >= 1 && k <= 1024, "topk_pack: bad shape B=%d k=%d", B, k);
+  const int64_t n = (int64_t)B * (k + 1);
+  hipLaunchKernelGGL(topk_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, vals, idx, status, B, k,
+                     static_cast<int2*>(pairs));
+  GDR_CHECK_LAUNCH("topk_pack_kernel");
+  return GDR_OK;
+}
+
+extern "C" int gdr_topk_merge_packed(const void* pairs, int G, int B, int k, float* out_val, int32_t* out_idx,
+                                     int32_t* out_status, void* stream_) {
+  using namespace gdr;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (B == 0) return GDR_OK;
+  GDR_CHECK_ARG(pairs && out_val && out_idx, "topk_merge_packed: null pointer");
+  GDR_CHECK_ARG(G > 0 && B > 0 && k >= 1 && k <= 1024, "topk_merge_packed: bad shape G=%d B=%d k=%d", G, B, k);
+  const int kpad = next_pow2(k);
+  const float* vals = static_cast<const float*>(pairs);
+  const int32_t* idx = static_cast<const int32_t*>(pairs) + 1;
+  hipLaunchKernelGGL(topk_select_kernel<true>, dim3(B), dim3(SEL_THREADS), kpad * sizeof(unsigned long long), stream,
+                     vals, idx, (const int32_t*)nullptr, (int64_t)0, G, B, k, kpad, 0, (const float*)nullptr, out_val, out_idx,
+                     out_status, k + 1, 2);
+  GDR_CHECK_LAUNCH("topk_select_kernel<merge packed>");
   return GDR_OK;
 }

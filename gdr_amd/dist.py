@@ -3,13 +3,22 @@
 One process per GPU.  Rank r holds the contiguous row block D[lo:hi] (whole clusters when a cluster size is
 given, so a cluster never straddles ranks).  A search step is
     all-gather of the per-rank query embeddings  ->  local fused sim+top-k on the shard (doc ids offset by lo)
-    -> ONE all-gather of the per-shard (score fp32, id int32)[B,k] lists (RCCL over xGMI; B*k*8 bytes per rank)
-    -> local merge [G,B,k] -> [B,k], bit-identical on every rank (tie rule: higher score, then lower id).
-`search_own` is the serving form: a rank only needs the answers to its OWN queries, so the per-shard lists are exchanged
-with one all-to-all (rank j receives, from every rank, the lists of j's query block: B_local*k*8 bytes per peer instead
-of B*k*8) and each rank merges [G,B_local,k] — 1/G of the traffic and of the merge work of the replicated form.
+    -> pack every query's list into its wire form  int64[B, k+1] = k x {fp32 score, int32 id} + {0, status}
+    -> ONE collective of that buffer (RCCL over xGMI)
+    -> local merge [G,B,k+1] -> (values, ids, status)[B,k], bit-identical on every rank (tie rule: higher score, then
+       lower id; status = OR of the shards' overflow flags).
+`search_own` is the serving form: a rank only needs the answers to its OWN queries, so the exchange is one all-to-all
+(rank j receives, from every rank, the lists of j's query block: B_local*(k+1)*8 bytes per peer instead of B*(k+1)*8)
+and each rank merges [G,B_local,k+1] — 1/G of the traffic and of the merge work of the replicated form `search`
+(one all-gather, every rank merges all queries).  `search_own_async` issues pack + exchange + merge on a side stream
+and returns a handle: the caller's stream is free to run the next batch's encoder meanwhile and joins with
+`handle.wait()`.
 The reference has no inference-time collective; its closest analogues are the training-time all_gather of
 reps (GDR_model/encoder.py:134-145) and the offline per-GPU partitioning of Data_process/NQ_dataset/bert/bert.py:51-61.
+
+Overflow contract (gdr_hip.h, gdr_sim_topk): with exact=True (default) the local search repairs an overflowed query
+exhaustively before the exchange (one status read-back per step), so every status is 0; with exact=False nothing
+synchronises and the merged status tells the caller which rows are the top-k of a subset.
 
 The compute callables default to the HIP ops; tests inject CPU stand-ins to exercise the collective logic
 under gloo (there is no CPU compute path in the product).
@@ -27,18 +36,37 @@ def shard_bounds(N, world, rank, cluster_size=1):
     return min(lo_u * cluster_size, N), min(hi_u * cluster_size, N)
 
 
+class _Pending:
+    """Result of search_own_async: tensors produced on a side stream; wait() joins the caller's current stream."""
+
+    def __init__(self, result, stream):
+        self._result, self._stream = result, stream
+
+    def wait(self):
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+            for t in self._result:
+                t.record_stream(torch.cuda.current_stream())
+        return self._result
+
+
 class ShardedIndex:
-    def __init__(self, D_shard, lo, group=None, local_topk=None, merge=None):
+    def __init__(self, D_shard, lo, group=None, local_topk=None, pack=None, merge_packed=None, exact=True):
+        """local_topk(Q, D, k, idx_offset) -> (values [B,k], ids int32 [B,k], status int32 [B]);
+        pack(values, ids, status) -> int64 [B,k+1];  merge_packed(pairs [G,B,k+1]) -> (values, ids, status)."""
         self.D, self.lo, self.group = D_shard, int(lo), group
-        if local_topk is None or merge is None:
+        if local_topk is None or pack is None or merge_packed is None:
             from . import ops
             ws = ops.Workspace(D_shard.device)
-            local_topk = local_topk or (lambda Q, D, k, off: ops.sim_topk(Q, D, k, idx_offset=off, workspace=ws))
-            merge = merge or ops.topk_merge
-        self.local_topk, self.merge = local_topk, merge
+            local_topk = local_topk or (lambda Q, D, k, off: ops.sim_topk(
+                Q, D, k, idx_offset=off, workspace=ws, return_status=True, exact_on_overflow=exact))
+            pack = pack or ops.topk_pack
+            merge_packed = merge_packed or (lambda pairs: ops.topk_merge_packed(pairs, return_status=True))
+        self.local_topk, self.pack, self.merge_packed = local_topk, pack, merge_packed
         self.distributed = dist.is_initialized()      # a 1-rank group still runs the collectives (exercises RCCL)
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
+        self._side = None
 
     def gather_queries(self, q_local):
         """[B_local,d] per rank -> [world*B_local,d], rank-major (every rank contributes the same count)."""
@@ -49,30 +77,59 @@ class ShardedIndex:
         dist.all_gather_into_tensor(out, q_local.contiguous(), group=self.group)
         return out
 
-    def search(self, q_all, k):
-        """q_all [B,d] identical on every rank -> (values [B,k], global doc ids int32 [B,k]), identical on every rank."""
-        v, i = self.local_topk(q_all, self.D, k, self.lo)
-        if not self.distributed:
-            return v, i
-        B = q_all.shape[0]
-        gv = torch.empty((self.world * B, k), dtype=v.dtype, device=v.device)     # rank-major concatenation
-        gi = torch.empty((self.world * B, k), dtype=i.dtype, device=i.device)
-        dist.all_gather_into_tensor(gv, v.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(gi, i.contiguous(), group=self.group)
-        return self.merge(gv.view(self.world, B, k), gi.view(self.world, B, k))
+    @staticmethod
+    def _ret(v, i, st, return_status):
+        return (v, i, st) if return_status else (v, i)
 
-    def search_own(self, q_all, k):
-        """q_all [B,d] identical on every rank (rank-major blocks of B/world queries) -> top-k of THIS rank's query block:
-        (values [B/world,k], global doc ids int32 [B/world,k]).  Same lists as search()[rank block]."""
-        v, i = self.local_topk(q_all, self.D, k, self.lo)
+    def search(self, q_all, k, return_status=False):
+        """q_all [B,d] identical on every rank -> (values [B,k], global doc ids int32 [B,k][, status]), identical on
+        every rank.  ONE all-gather of the packed per-shard lists."""
+        v, i, st = self.local_topk(q_all, self.D, k, self.lo)
         if not self.distributed:
-            return v, i
+            return self._ret(v, i, st, return_status)
+        B = q_all.shape[0]
+        mine = self.pack(v, i, st)                                                  # [B, k+1] int64
+        allp = torch.empty((self.world * B, k + 1), dtype=mine.dtype, device=mine.device)   # rank-major concatenation
+        dist.all_gather_into_tensor(allp, mine, group=self.group)
+        return self._ret(*self.merge_packed(allp.view(self.world, B, k + 1)), return_status)
+
+    def _exchange_own(self, v, i, st, B, k):
+        bl = B // self.world
+        mine = self.pack(v, i, st)                      # [world*bl, k+1]: block g = my list for rank g's queries
+        recv = torch.empty_like(mine)                   # block g = rank g's list for MY queries
+        dist.all_to_all_single(recv, mine, group=self.group)
+        return self.merge_packed(recv.view(self.world, bl, k + 1))
+
+    def search_own(self, q_all, k, return_status=False):
+        """q_all [B,d] identical on every rank (rank-major blocks of B/world queries) -> top-k of THIS rank's query block:
+        (values [B/world,k], global doc ids int32 [B/world,k][, status]).  Same lists as search()[rank block].
+        ONE all-to-all of the packed per-shard lists."""
+        v, i, st = self.local_topk(q_all, self.D, k, self.lo)
+        if not self.distributed:
+            return self._ret(v, i, st, return_status)
         B = q_all.shape[0]
         if B % self.world:
             raise ValueError("search_own: the gathered batch must hold the same number of queries per rank")
-        bl = B // self.world
-        rv = torch.empty_like(v)                       # [world*bl, k]: block g = rank g's list for my queries
-        ri = torch.empty_like(i)
-        dist.all_to_all_single(rv, v.contiguous(), group=self.group)
-        dist.all_to_all_single(ri, i.contiguous(), group=self.group)
-        return self.merge(rv.view(self.world, bl, k), ri.view(self.world, bl, k))
+        return self._ret(*self._exchange_own(v, i, st, B, k), return_status)
+
+    def search_own_async(self, q_all, k):
+        """search_own with pack + all-to-all + merge issued on a side stream: returns a handle whose wait() yields
+        (values, ids, status) and makes the caller's current stream wait for them.  Between the call and wait() the
+        caller's stream is free — bench.py runs the next batch's encoder there, hiding the exchange."""
+        v, i, st = self.local_topk(q_all, self.D, k, self.lo)
+        if not self.distributed:
+            return _Pending((v, i, st), None)
+        B = q_all.shape[0]
+        if B % self.world:
+            raise ValueError("search_own_async: the gathered batch must hold the same number of queries per rank")
+        if not v.is_cuda:                                # CPU stand-ins (gloo tests): nothing to overlap with
+            return _Pending(self._exchange_own(v, i, st, B, k), None)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=v.device)
+        side, cur = self._side, torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for t in (v, i, st):
+                t.record_stream(side)
+            out = self._exchange_own(v, i, st, B, k)
+        return _Pending(out, side)

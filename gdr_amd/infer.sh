@@ -1,7 +1,8 @@
 #!/usr/bin/env bash
 # Same flags as the reference's GDR_model/infer.sh:10-15 (including --trivia, which its own parser rejects).
-# Without a checkpoint / dataset the run falls back to the seeded synthetic NQ-320k-shaped workload.
-INFER_CKPT=${INFER_CKPT:-'ckpt file'}
+# INFER_CKPT: a Lightning .ckpt / state_dict; a path that does not exist is an error (as in the reference).  Leave it
+# empty to run the seeded synthetic weights on the synthetic NQ-320k-shaped workload (no checkpoint ships with GDR).
+INFER_CKPT=${INFER_CKPT:-}
 BEAM_SIZE=${BEAM_SIZE:-100}
 cd "$(dirname "$0")/.." || exit 1
 python -m gdr_amd.main --decode_embedding 2 --n_gpu 1 --mode eval --query_type gtq_doc_aug_qg --adaptor_layer_num 4 \

@@ -137,13 +137,22 @@ def inference(args):
     """main.py:115-250 on the MI355X path: generate cluster ids per query, write res1, print recall / MRR."""
     from .modeling import GDRModel, GDRRetriever
     cfg = GDRConfig.from_args(args)
-    if args.infer_ckpt and os.path.exists(args.infer_ckpt):
-        sd = torch.load(args.infer_ckpt, map_location="cpu")
+    if args.infer_ckpt:
+        # the reference loads whatever path it is given and fails if it is absent (main.py:121-126); so do we — a typo
+        # must not turn into metrics of random weights.  weights_only: a checkpoint is tensors, not code.
+        if not os.path.exists(args.infer_ckpt):
+            raise FileNotFoundError(f"--infer_ckpt {args.infer_ckpt!r} does not exist (pass --infer_ckpt '' to run the "
+                                    "seeded synthetic weights)")
+        sd = torch.load(args.infer_ckpt, map_location="cpu", weights_only=True)
     else:
-        print("[gdr_amd] no --infer_ckpt: using seeded synthetic weights (no trained checkpoint ships with the reference)")
+        print("[gdr_amd] --infer_ckpt is empty: using seeded synthetic weights (no trained checkpoint ships with the "
+              "reference)")
         sd = synth.make_state_dict(cfg, seed=1234)
     dev = torch.device(args.device)
     data = _load_inputs(args, cfg)
+    if args.constrain_tree and args.kary != args.output_vocab_size:
+        raise SystemExit(f"--constrain_tree 1 needs --kary ({args.kary}) == --output_vocab_size "
+                         f"({args.output_vocab_size}): the trie is indexed by the head's digit columns")
     trie = codec.Trie.from_docids(data["index"].names, args.kary) if args.constrain_tree else None
     model = GDRModel(cfg, sd, dev, trie=trie)
     R = args.num_return_sequences

@@ -98,11 +98,12 @@ def _sim_topk_raw(Q, D, k, idx_offset, workspace, flags):
     return vals, idx, status
 
 
-def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_on_overflow=False, flags=0):
+def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_on_overflow=True, flags=0):
     """Fused Q·Dᵀ + per-row top-k — gdr_sim_topk.  Returns (values fp32[B,k], indices int32[B,k]).
-    exact_on_overflow=True reads the per-query status back (one host sync) and recomputes any query whose candidate
-    list overflowed (degenerate corpora with tens of thousands of tied docs) exhaustively, so the result is exact for
-    every input; return_status=True hands the device status tensor to the caller instead.  flags: _ffi.SIM_* bits."""
+    exact_on_overflow=True (the default) reads the per-query status back (one host sync per call) and recomputes any
+    query whose candidate list overflowed (degenerate corpora with tens of thousands of tied docs) exhaustively, so the
+    result is exact for every input.  Latency-critical callers pass exact_on_overflow=False, return_status=True: no sync,
+    and the device status tensor (1 = that row is the top-k of a subset) is theirs to act on.  flags: _ffi.SIM_* bits."""
     _need_cuda(Q, D)
     if D.dtype == torch.bfloat16:                                    # bf16 corpus: queries are cast on the device
         Q = (Q if Q.dtype == torch.bfloat16 else to_bf16(Q)).contiguous()
@@ -134,6 +135,30 @@ def topk_merge(vals, idx):
     oi = torch.empty((B, k), dtype=torch.int32, device=vals.device)
     check(lib().gdr_topk_merge(ptr(vals), ptr(idx), G, B, k, ptr(ov), ptr(oi), stream_ptr()), "gdr_topk_merge")
     return ov, oi
+
+
+def topk_pack(vals, idx, status=None):
+    """(values fp32[B,k], ids int32[B,k][, status int32[B]]) -> int64[B,k+1] wire form — gdr_topk_pack."""
+    _need_cuda(vals, idx, status)
+    vals, idx = _f32c(vals), idx.contiguous()
+    B, k = vals.shape
+    pairs = torch.empty((B, k + 1), dtype=torch.int64, device=vals.device)
+    check(lib().gdr_topk_pack(ptr(vals), ptr(idx), ptr(status), B, k, ptr(pairs), stream_ptr()), "gdr_topk_pack")
+    return pairs
+
+
+def topk_merge_packed(pairs, return_status=False):
+    """int64[G,B,k+1] per-shard wire lists -> (values [B,k], ids int32 [B,k][, status int32 [B]]) — gdr_topk_merge_packed."""
+    _need_cuda(pairs)
+    pairs = pairs.contiguous()
+    G, B, k1 = pairs.shape
+    k = k1 - 1
+    ov = torch.empty((B, k), dtype=torch.float32, device=pairs.device)
+    oi = torch.empty((B, k), dtype=torch.int32, device=pairs.device)
+    st = torch.empty((B,), dtype=torch.int32, device=pairs.device) if return_status else None
+    check(lib().gdr_topk_merge_packed(ptr(pairs), G, B, k, ptr(ov), ptr(oi), ptr(st), stream_ptr()),
+          "gdr_topk_merge_packed")
+    return (ov, oi, st) if return_status else (ov, oi)
 
 
 def rerank_topk(q, D, cand_offsets, cand_ids, beam_scores, alphas, k, func="tanh", max_cand=None):
@@ -394,7 +419,7 @@ class DeviceTrie:
     def __init__(self, trie, device):
         self.child = torch.from_numpy(trie.child).to(device).contiguous()
         self.eos_ok = torch.from_numpy(trie.eos_ok).to(device).contiguous()
-        self.struct = _ffi.GdrTrie(self.child.data_ptr(), self.eos_ok.data_ptr(), self.child.shape[0])
+        self.struct = _ffi.GdrTrie(self.child.data_ptr(), self.eos_ok.data_ptr(), self.child.shape[0], int(trie.V))
 
     def struct_ref(self):
         return C.byref(self.struct)

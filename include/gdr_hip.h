@@ -14,7 +14,10 @@
  *   - `stream` is a hipStream_t passed as void* (0 = default stream); calls are asynchronous on it and
  *     contain no host synchronisation (hipGraph-capturable);
  *   - return 0 on success, a negative GDR_E* code otherwise; gdr_last_error() gives the thread-local
- *     message; no exceptions cross the ABI; no global mutable state besides that message;
+ *     message; no exceptions cross the ABI.  Re-entrant from several host threads and for several devices in one
+ *     process (the device current in the calling thread is the one used): the only process-wide state is the
+ *     thread-local message, a mutex-guarded (kernel, device) table of raised dynamic-LDS limits, a mutex-guarded pool
+ *     of per-device side streams that gdr_t5_generate leases per call, and the opt-in profiler below (single-threaded);
  *   - row-major fp32 unless stated; ids int64 where the reference uses LongTensor inputs, int32 for
  *     doc ids produced on device.
  */
@@ -133,7 +136,9 @@ int gdr_t5_encoder_forward_bf16(const GdrT5EncoderWeights* w, const int64_t* ids
  *   status (device int32[B], may be NULL): status[q] = 1 if query q's candidate list overflowed — only possible on
  *   degenerate data (tens of thousands of docs tied at / above the sampled threshold, e.g. duplicated embeddings);
  *   its result is then the top-k of a subset.  Re-running those queries with GDR_SIM_EXHAUSTIVE (every score kept,
- *   workspace B*N*8 bytes) is exact for any input; gdr_amd.ops.sim_topk does that automatically.
+ *   workspace B*N*8 bytes) is exact for any input.  The C entry point never synchronises, so the re-run is the
+ *   caller's job: gdr_amd.ops.sim_topk does it by default (exact_on_overflow=True: one status read-back per call);
+ *   latency-critical callers pass exact_on_overflow=False and receive the device status tensor instead.
  * d % 4 == 0, 1 <= k <= 1024, k <= N.
  * ---------------------------------------------------------------------------------------------- */
 #define GDR_SIM_EXHAUSTIVE 1
@@ -157,6 +162,14 @@ int gdr_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, void* stream);
  * vals/idx [G,B,k] (shard-major) -> [B,k]; same tie rule, so every rank computes identical output. */
 int gdr_topk_merge(const float* vals, const int32_t* idx, int G, int B, int k, float* out_val, int32_t* out_idx,
                    void* stream);
+/* The wire form of a per-shard result, so that the exchange is ONE collective: per query row k+1 entries of
+ * 8 bytes, entry j < k = {fp32 score, int32 id}, entry k = {0, status[q]} (status may be NULL = 0).
+ * gdr_topk_pack writes pairs[B, k+1]; gdr_topk_merge_packed merges pairs[G, B, k+1] (shard-major, as an all-gather /
+ * all-to-all lays them out) into out_val/out_idx [B,k] with gdr_topk_merge's tie rule and, when out_status is given,
+ * out_status[q] = 1 if any shard flagged query q (its list was the top-k of a subset, see gdr_sim_topk). */
+int gdr_topk_pack(const float* vals, const int32_t* idx, const int32_t* status, int B, int k, void* pairs, void* stream);
+int gdr_topk_merge_packed(const void* pairs, int G, int B, int k, float* out_val, int32_t* out_idx,
+                          int32_t* out_status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * In-cluster rerank — replaces main_models.py:1574-1637, block-diagonal only.
@@ -270,6 +283,7 @@ typedef struct {
   const int32_t* child;   /* device int32 [n_nodes, V] */
   const int32_t* eos_ok;  /* device int32 [n_nodes]    */
   int32_t n_nodes;
+  int32_t V;              /* digits per level the table was built for; must equal the head's out_vocab (checked) */
 } GdrTrie;
 
 size_t gdr_t5_generate_workspace_bytes(const GdrT5DecoderWeights* w, int B, int L, int num_beams, int max_length);

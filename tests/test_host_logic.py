@@ -145,39 +145,64 @@ def _gloo_worker(rank, world, port, tmp):
         from gdr_amd import synth
         from gdr_amd.dist import ShardedIndex, shard_bounds
         from oracle import retrieval_ref
-        N, d, k, B_local = 5000, 32, 20, 6
+        N, d, k, B_local = 5003, 32, 20, 6                   # 417 clusters of 12 (the last one short): uneven shards
         D = synth.make_corpus(N, d, seed=4)
         Q, _ = synth.make_queries(D, B_local * world, seed=5)
         lo, hi = shard_bounds(N, world, rank, cluster_size=12)
+        flagged = (world - 1, 2 * B_local - 1 if world > 1 else 0)   # (shard, global query) whose list "overflowed"
 
-        def local_topk(Qa, Ds, kk, off):                     # CPU stand-ins for the HIP ops (collective logic only)
+        # CPU stand-ins for the HIP ops with the same contracts (the collective logic under test is the product code)
+        def local_topk(Qa, Ds, kk, off):
             v, i = retrieval_ref.sim_topk(Qa, Ds, kk)
-            return v, (i + off).to(torch.int32)
+            st = torch.zeros(Qa.shape[0], dtype=torch.int32)
+            if rank == flagged[0]:
+                st[flagged[1]] = 1
+            return v, (i + off).to(torch.int32), st
 
-        def merge(gv, gi):
-            G, B, kk = gv.shape
-            v = gv.permute(1, 0, 2).reshape(B, G * kk)
-            i = gi.permute(1, 0, 2).reshape(B, G * kk)
-            key = np.lexsort((i.numpy(), -v.numpy()), axis=1)[:, :kk]     # higher score, then lower id
-            return torch.from_numpy(np.take_along_axis(v.numpy(), key, 1)), torch.from_numpy(np.take_along_axis(i.numpy(), key, 1))
+        def pack(v, i, st):
+            B, kk = v.shape
+            pairs = np.zeros((B, kk + 1, 2), dtype=np.int32)
+            pairs[:, :kk, 0] = v.numpy().view(np.int32)
+            pairs[:, :kk, 1] = i.numpy()
+            pairs[:, kk, 1] = st.numpy()
+            return torch.from_numpy(pairs.view(np.int64).reshape(B, kk + 1))
 
-        index = ShardedIndex(torch.from_numpy(D[lo:hi]), lo, local_topk=local_topk, merge=merge)
+        def merge_packed(pairs):
+            G, B, k1 = pairs.shape
+            kk = k1 - 1
+            raw = pairs.numpy().view(np.int32).reshape(G, B, k1, 2)
+            v = np.ascontiguousarray(raw[:, :, :kk, 0]).view(np.float32).transpose(1, 0, 2).reshape(B, G * kk)
+            i = raw[:, :, :kk, 1].transpose(1, 0, 2).reshape(B, G * kk)
+            key = np.lexsort((i, -v), axis=1)[:, :kk]                     # higher score, then lower id
+            st = (raw[:, :, kk, 1] != 0).any(axis=0).astype(np.int32)
+            return (torch.from_numpy(np.take_along_axis(v, key, 1)), torch.from_numpy(np.take_along_axis(i, key, 1)),
+                    torch.from_numpy(st))
+
+        index = ShardedIndex(torch.from_numpy(D[lo:hi]), lo, local_topk=local_topk, pack=pack, merge_packed=merge_packed)
         q_all = index.gather_queries(torch.from_numpy(Q[rank * B_local:(rank + 1) * B_local]))
         assert torch.equal(q_all, torch.from_numpy(Q))
-        v, i = index.search(q_all, k)
+        v, i, st = index.search(q_all, k, return_status=True)
         rv, ri = retrieval_ref.sim_topk(torch.from_numpy(Q), torch.from_numpy(D), k)
-        vo, io = index.search_own(q_all, k)              # all-to-all form: this rank's query block only
+        vo, io, so = index.search_own(q_all, k, return_status=True)      # all-to-all form: this rank's query block only
+        va, ia, sa = index.search_own_async(q_all, k).wait()
         blk = slice(rank * B_local, (rank + 1) * B_local)
-        np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([int(torch.equal(i.to(torch.int64), ri)),
-                                                             int(torch.allclose(v, rv, atol=1e-6)),
-                                                             int(torch.equal(io, i[blk]) and torch.equal(vo, v[blk]))]))
+        want_st = torch.zeros(B_local * world, dtype=torch.int32)
+        want_st[flagged[1]] = 1
+        np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([
+            int(torch.equal(i.to(torch.int64), ri)), int(torch.allclose(v, rv, atol=1e-6)),
+            int(torch.equal(io, i[blk]) and torch.equal(vo, v[blk])),
+            int(torch.equal(ia, io) and torch.equal(va, vo) and torch.equal(sa, so)),
+            int(torch.equal(st, want_st) and torch.equal(so, want_st[blk])), hi - lo]))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_search_two_ranks_gloo(tmp_path):
-    """world_size-2 run of gdr_amd/dist.py on CPU/gloo: query all-gather, per-shard top-k with id offsets, top-k
-    all-gather and merge reproduce the single-shard result on every rank."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_search_gloo(tmp_path, world):
+    """world_size-2 and -4 runs of gdr_amd/dist.py on CPU/gloo with uneven shards: query all-gather, per-shard top-k
+    with id offsets, ONE collective of the packed (score, id, status) lists and the merge reproduce the single-shard
+    result on every rank — replicated form (all-gather), serving form (all-to-all), its async variant — and a shard's
+    overflow flag reaches exactly the rows it concerns."""
     import socket
     import torch.multiprocessing as mp
     from gdr_amd.dist import shard_bounds
@@ -187,9 +212,11 @@ def test_sharded_search_two_ranks_gloo(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    for r in range(2):
-        assert np.load(tmp_path / f"ok{r}.npy").tolist() == [1, 1, 1]
+    mp.spawn(_gloo_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rows = [np.load(tmp_path / f"ok{r}.npy").tolist() for r in range(world)]
+    assert all(r[:5] == [1, 1, 1, 1, 1] for r in rows), rows
+    sizes = [r[5] for r in rows]
+    assert sum(sizes) == 5003 and len(set(sizes)) > 1, sizes           # the shards really were uneven
 
 
 def test_trie_flattening_matches_reference_treebuilder_semantics():
