@@ -4,6 +4,8 @@ Mirrors the reference's names and argument meaning so call sites read the same:
   encode_single_newid / decode_token   GDR_model/main_models.py:297-346
   dec_2d                               GDR_model/main_utils.py:70-76
   recall / MRR100                      GDR_model/main_metrics.py:194-267
+  cal_recall / cal_accuracy / cal_MRR / cal_MAP, validation_epoch_end
+                                       GDR_model/main_models.py:1643-1908 (multi-gt macro/micro metrics per alpha)
   id_mapping (cluster -> doc ids)      GDR_model/main_models.py:874-889  -> flat CSR here
 Both call styles are accepted: the reference's `f(args, x)` with an argparse namespace, or `f(x, kary=..)`.
 """
@@ -190,3 +192,119 @@ def MRR100(args=None, rows=None, verbose=True):
     if verbose:
         print("MRR100: {}".format(mrr))
     return mrr
+
+
+# ------------------------------------------------------------------------------------------ validation_epoch_end metrics
+def cal_recall(q_pred, q_gt, k):
+    """(macro, micro) recall@k over multi-gt queries (main_models.py:1730-1743): macro = mean over queries of
+    hits/len(gt); micro = total hits / total gt."""
+    total_hit = total_positive = 0
+    total_recall = 0
+    for q in q_pred:
+        top = q_pred[q][:k]
+        is_hit = sum(1 for p in q_gt[q] if p in top)
+        total_positive += len(q_gt[q])
+        total_recall += is_hit / len(q_gt[q])
+        total_hit += is_hit
+    return total_recall / len(q_pred), total_hit / total_positive
+
+
+def cal_accuracy(q_pred, q_gt, k):
+    """Share of queries with any gt among their first k predictions (main_models.py:1745-1756)."""
+    return sum(1 for q in q_pred if any(p in q_gt[q] for p in q_pred[q][:k])) / len(q_pred)
+
+
+def cal_MRR(q_pred, q_gt, k):
+    """Mean reciprocal rank of the first gt hit within k (main_models.py:1758-1772)."""
+    total = 0
+    for q in q_pred:
+        for rank, p in enumerate(q_pred[q][:k], start=1):
+            if p in q_gt[q]:
+                total += 1 / rank
+                break
+    return total / len(q_pred)
+
+
+def cal_MAP(q_pred, q_gt, k):
+    """The reference's MAP@k (main_models.py:1774-1789): sum over hits of (hit number / rank), divided by k (not by the
+    number of relevant docs) — kept as written."""
+    total = 0
+    for q in q_pred:
+        pred_true, local = 1, 0
+        for rank, p in enumerate(q_pred[q][:k], start=1):
+            if p in q_gt[q]:
+                local += pred_true / rank
+                pred_true += 1
+        total += local / k
+    return total / len(q_pred)
+
+
+def _group_rows(rows, gt_as_list):
+    """The q_pred / q_gt dictionaries validation_epoch_end builds from consecutive rows (main_models.py:1697-1728).
+    Cluster rows keep the first row's gt LIST and `.add` on a repeat (an AttributeError in the reference, reached only
+    when a query text repeats); doc rows append."""
+    q_gt, q_pred, prev = {}, {}, ""
+    for row in rows:
+        query, pred, gt = row[0], row[1], row[2]
+        if query != prev:
+            q_pred[query] = pred.split(",")
+            prev = query
+        if query in q_gt:
+            if len(q_gt[query]) <= 100:
+                if gt_as_list:
+                    q_gt[query].append(gt)
+                else:
+                    q_gt[query].add(gt)          # the reference calls set.add on a list here (main_models.py:1708)
+        else:
+            q_gt[query] = list(set(gt.split(",")))
+    return q_pred, q_gt
+
+
+def validation_epoch_end(outputs, args, verbose=False):
+    """The metric block of T5FineTuner.validation_epoch_end (main_models.py:1643-1908) for multiple_decoder=0.
+    outputs: list of validation_step_i results {"inf_result_batch": [[query, pred_csv, gt, rank], ...],
+    "inf_result_batch_prob": [...], "inf_index_batch": [batch][alpha] -> [[query, pred_csv, gt]]}.
+    Returns the dict of everything the reference passes to self.log (same names, e.g. "cluster_recall10",
+    "recall5_0.5", "MRR100_3", "MAP100_1.5"; without is_train_encoder: "recall1" ... "MAP100")."""
+    logged = {}
+    n_alpha = len(outputs[0]["inf_index_batch"][0]) if args.is_train_encoder else 1
+    for index in range(n_alpha):
+        appendix = args.score_rate[index]
+        rows = [item for sub in outputs for item in sub["inf_result_batch"]]
+        rows = sorted((r for r in rows), key=lambda r: (r[0], r[3]))         # sort_values(by=['query','rank'])
+        q_pred, q_gt = _group_rows([r for r in rows if r[3] == 1], gt_as_list=False)
+        ks = (1, 5, 10, 20, 50, 100)
+        if args.is_train_encoder:
+            index_rows = [item for sub in outputs for b in range(args.eval_batch_size)
+                          for item in sub["inf_index_batch"][b][index]]
+            q_pred_i, q_gt_i = _group_rows(index_rows, gt_as_list=True)
+            for k in ks:
+                logged[f"cluster_recall{k}"] = cal_recall(q_pred, q_gt, k)[0]
+            for k in (1, 20, 100):
+                logged[f"cluster_accuracy{k}"] = cal_accuracy(q_pred, q_gt, k)
+            logged["cluster_MRR100"], logged["cluster_MRR10"] = cal_MRR(q_pred, q_gt, 100), cal_MRR(q_pred, q_gt, 10)
+            logged["cluster_MAP100"] = cal_MAP(q_pred, q_gt, 100)
+            for k in ks:
+                logged[f"recall{k}_{appendix}"] = cal_recall(q_pred_i, q_gt_i, k)[0]
+            if appendix == 0:
+                logged["recall1"] = logged[f"recall1_{appendix}"]
+            for k in (1, 20, 100):
+                logged[f"accuracy{k}_{appendix}"] = cal_accuracy(q_pred_i, q_gt_i, k)
+            logged[f"MRR100_{appendix}"], logged[f"MRR10_{appendix}"] = cal_MRR(q_pred_i, q_gt_i, 100), cal_MRR(q_pred_i, q_gt_i, 10)
+            logged[f"MAP100_{appendix}"] = cal_MAP(q_pred_i, q_gt_i, 100)
+            if verbose:
+                for k in ks:
+                    print(f"recall@{k}_{appendix}:{logged[f'recall{k}_{appendix}']}")
+                print(f"MRR100_{appendix}:{logged[f'MRR100_{appendix}']}")
+        else:
+            for k in ks:
+                logged[f"recall{k}"] = cal_recall(q_pred, q_gt, k)[0]
+            for k in (1, 20, 100):
+                logged[f"accuracy{k}"] = cal_accuracy(q_pred, q_gt, k)
+            logged["MRR100"], logged["MRR10"] = cal_MRR(q_pred, q_gt, 100), cal_MRR(q_pred, q_gt, 10)
+            logged["MAP100"] = cal_MAP(q_pred, q_gt, 100)
+            if verbose:
+                for k in ks:
+                    print(f"recall@{k}:{logged[f'recall{k}']}")
+                print(f"MRR100:{logged['MRR100']}")
+    return logged

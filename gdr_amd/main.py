@@ -160,7 +160,8 @@ def inference(args):
     retr = GDRRetriever(model, torch.from_numpy(np.ascontiguousarray(data["doc_embed"], dtype=np.float32)).to(dev),
                         data["index"], args) if two_stage else None
     n = data["source_ids"].shape[0] if args.n_test < 0 else min(args.n_test, data["source_ids"].shape[0])
-    rows1, rows2 = [], []
+    texts = data.get("texts") or ["q%d" % i for i in range(data["source_ids"].shape[0])]
+    inf_result_cache, outputs = [], []
     t_model = 0.0
     for lo in range(0, n, args.eval_batch_size):
         hi = min(n, lo + args.eval_batch_size)
@@ -169,31 +170,54 @@ def inference(args):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if two_stage:
-            out = retr.validation_step_i({"source_ids": ids, "source_mask": mask})
-            dec = out["clusters"]
+            out = retr.validation_step_i({"source_ids": ids, "source_mask": mask, "texts": texts[lo:hi],
+                                          "gt": data["gt_cluster"][lo:hi], "oldid": data["gt_doc"][lo:hi]})
+            outputs.append(out)
+            inf_result_cache.extend(out["inf_result_batch"])
         else:
             outs, _ = model.generate(ids, attention_mask=mask, use_cache=False, max_length=args.max_output_length,
                                      num_beams=R, length_penalty=args.length_penalty, num_return_sequences=R,
                                      early_stopping=False, decode_embedding=args.decode_embedding,
                                      decode_vocab_size=args.output_vocab_size * args.max_output_length + 2)
             dec = codec.dec_2d(codec.decode_token(args, outs.cpu().numpy()), R)
+            for j, pred in enumerate(dec):                       # main.py:227-238
+                inf_result_cache.append([texts[lo + j], ",".join(pred), data["gt_cluster"][lo + j], 1])
         torch.cuda.synchronize()
         t_model += time.perf_counter() - t0
-        for j, pred in enumerate(dec):
-            q = "q%d" % (lo + j)
-            rows1.append((q, ",".join(pred), data["gt_cluster"][lo + j], 1))
-            if two_stage:
-                best_alpha = len(args.score_rate) // 2
-                rows2.append((q, ",".join(out["inf_index_batch"][j][best_alpha]), data["gt_doc"][lo + j], 1))
+    # main.py:243-247: sort by (query, rank), keep rank 1, write the TSV
+    res1 = sorted((r for r in inf_result_cache if r[3] == 1), key=lambda r: (r[0], r[3]))
     os.makedirs(os.path.dirname(args.res1_save_path) or ".", exist_ok=True)
-    codec.write_res1(args.res1_save_path, rows1)
+    codec.write_res1(args.res1_save_path, res1)
     print(f"[gdr_amd] {n} queries, beam {R}: {n / max(t_model, 1e-9):.1f} queries/s (model time only)")
-    print("cluster-id recall (stage 1):")
     recall_value = codec.recall(args)
     mrr_value = codec.MRR100(args)
     if two_stage:
-        print("doc recall after in-cluster rerank (stage 2, alpha=%g):" % args.score_rate[len(args.score_rate) // 2])
-        codec.recall(rows=rows2, recall_num=args.recall_num)
+        # what Lightning validation adds on top of main.py's stage-1 numbers: the doc-level lists per alpha
+        # (validation_step_i) and their metrics (validation_epoch_end, main_models.py:1643-1908)
+        path2 = args.res1_save_path + ".docs.tsv"
+        with open(path2, "w") as f:                              # query \t alpha \t doc ids csv \t gold doc
+            for out in outputs:
+                for per_alpha in out["inf_index_batch"]:
+                    for ai, rows in enumerate(per_alpha):
+                        for q, pred, gt in rows:
+                            f.write(f"{q}\t{args.score_rate[ai]}\t{pred}\t{gt}\n")
+        eargs = argparse.Namespace(**vars(args))
+        by_size = {}                                             # the last batch may be short
+        for out in outputs:
+            by_size.setdefault(len(out["inf_index_batch"]), []).append(out)
+        if len(by_size) == 1:
+            eargs.eval_batch_size = next(iter(by_size))
+            logged = codec.validation_epoch_end(outputs, eargs)
+        else:                                                    # re-batch to size 1 so that one pass covers all rows
+            flat = [{"inf_result_batch": [o["inf_result_batch"][b]], "inf_result_batch_prob": [],
+                     "inf_index_batch": [o["inf_index_batch"][b]]} for o in outputs for b in range(len(o["inf_index_batch"]))]
+            eargs.eval_batch_size = 1
+            logged = codec.validation_epoch_end(flat, eargs)
+        print("stage 2 (in-cluster rerank) doc-level metrics per alpha:")
+        for al in args.score_rate:
+            print("  alpha=%g  recall@1 %.4f  recall@10 %.4f  recall@100 %.4f  MRR100 %.4f" % (
+                al, logged[f"recall1_{al}"], logged[f"recall10_{al}"], logged[f"recall100_{al}"], logged[f"MRR100_{al}"]))
+        inference.last_logged = logged
     return recall_value, mrr_value
 
 

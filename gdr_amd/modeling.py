@@ -212,6 +212,15 @@ class DenseModel:
         """scores = q_reps @ p_reps.T (dense.py:53-54) — materialises [B,N]; prefer search() for top-k."""
         return ops.linear(q_reps.contiguous(), p_reps.contiguous())
 
+    def __call__(self, query=None, passage=None):
+        """EncoderModel.forward, eval branch (encoder.py:77-113): EncoderOutput(q_reps, p_reps[, scores], loss=None)."""
+        q_reps, p_reps = self.encode_query(query), self.encode_passage(passage)
+        if q_reps is None or p_reps is None:
+            return ModelOutput(q_reps=q_reps, p_reps=p_reps, loss=None, scores=None)
+        return ModelOutput(loss=None, scores=self.compute_similarity(q_reps, p_reps), q_reps=q_reps, p_reps=p_reps)
+
+    forward = __call__
+
     def search(self, q_reps, p_reps, k):
         """compute_similarity + topk(k) fused (never writes the score matrix). Returns (values, int64 indices)."""
         if self._ws is None:
@@ -247,6 +256,12 @@ class GDRRetriever:
 
     @torch.no_grad()
     def validation_step_i(self, batch, i=-1, reencode=False):
+        """batch: {"source_ids", "source_mask"} (+ optionally what the reference's dataset adds for the metric rows:
+        "texts" list[str] (the reference decodes them from source_ids with the T5 tokenizer — out of scope here),
+        "gt" list[str] gold cluster ids, "rank" list[int], "oldid" list[str] gold doc ids).
+        Returns the reference's step output {"inf_result_batch", "inf_result_batch_prob", "inf_index_batch"}
+        (main_models.py:1640-1641; rows are filled when "texts" is given) plus the raw pieces: "clusters" [B][R] decoded
+        cluster strings, "doc_ids" [B][A][R] doc ids as strings, "rerank_values" fp32[B,A,R]."""
         a = self.args
         R = a.num_return_sequences
         decode_vocab_size = a.output_vocab_size * a.max_output_length + 2
@@ -274,6 +289,15 @@ class GDRRetriever:
                                         beam_scores, list(a.score_rate), R, func=getattr(a, "loss_func", "tanh"),
                                         max_cand=max_cand)
         idx_h = idx.cpu().tolist()
-        inf_index = [[[str(x) for x in idx_h[b][ai]] for ai in range(len(a.score_rate))] for b in range(B)]
-        return {"clusters": dec, "inf_result_batch_prob": scores, "inf_index_batch": inf_index,
-                "rerank_values": vals}
+        doc_ids = [[[str(x) for x in idx_h[b][ai]] for ai in range(len(a.score_rate))] for b in range(B)]
+        inf_result, inf_index = [], []
+        texts = batch.get("texts")
+        if texts is not None:
+            gts = batch.get("gt", [""] * B)
+            ranks = batch.get("rank", [1] * B)
+            old = batch.get("oldid", [""] * B)
+            for b in range(B):                                   # main_models.py:1421-1432 and :1626-1637
+                inf_result.append([texts[b], ",".join(dec[b]), gts[b], int(ranks[b])])
+                inf_index.append([[[texts[b], ",".join(doc_ids[b][ai]), old[b]]] for ai in range(len(a.score_rate))])
+        return {"inf_result_batch": inf_result, "inf_result_batch_prob": scores, "inf_index_batch": inf_index,
+                "clusters": dec, "doc_ids": doc_ids, "rerank_values": vals}

@@ -146,7 +146,7 @@ def beam_search(step_fn, batch_size, num_beams, vocab_size, max_length, length_p
 
 
 def generate(sd, cfg, input_ids, attention_mask, num_beams, max_length=None, length_penalty=0.8,
-             num_return_sequences=None, restricted_head=False, trace=None):
+             num_return_sequences=None, restricted_head=False, trace=None, decode_tree=None):
     """GenerationMixin.generate as GDR calls it (generation_utils.py:110-527; main_models.py:1380-1397):
     encoder once, expand per beam, full decoder recompute every step (use_cache=False).
     Returns ((decoded, scores), enc_expanded[B*R,L,d])."""
@@ -164,5 +164,5 @@ def generate(sd, cfg, input_ids, attention_mask, num_beams, max_length=None, len
 
     out = beam_search(step, B, R, cfg.decode_vocab_size, max_length, length_penalty,
                       num_return_sequences or R, cfg.eos_token_id, cfg.pad_token_id,
-                      cfg.decoder_start_token_id, trace=trace)
+                      cfg.decoder_start_token_id, trace=trace, decode_tree=decode_tree)
     return out, enc_x

@@ -51,3 +51,26 @@ def order_insensitive_topk_match(ref_vals, ref_idx, got_vals, got_idx, tol):
                 permuted += int((a != b).sum())
             j = e + 1
     return permuted
+
+
+def ranked_lists_match(ref_items, ref_scores, got_items, tol):
+    """The same rule for ranked lists of arbitrary hashable items (cluster strings, doc-id strings): positions agree
+    exactly wherever neighbouring reference scores are more than 2*tol apart; inside a tolerance-tie group the same
+    item set in any order; the last group may be cut by the list length.  Returns the number of permuted slots."""
+    assert len(ref_items) == len(got_items), (len(ref_items), len(got_items))
+    if list(ref_items) == list(got_items):
+        return 0
+    sc = np.asarray(ref_scores, dtype=np.float64)
+    k, j, permuted = len(ref_items), 0, 0
+    while j < k:
+        e = j
+        while e + 1 < k and abs(sc[e] - sc[e + 1]) <= 2 * tol * (1 + abs(sc[e])):
+            e += 1
+        a, b = list(ref_items[j:e + 1]), list(got_items[j:e + 1])
+        if e == k - 1:
+            permuted += (e - j + 1) - len(set(a) & set(b))
+        else:
+            assert sorted(a) == sorted(b), (j, e, a, b)
+            permuted += sum(1 for x, y in zip(a, b) if x != y)
+        j = e + 1
+    return permuted

@@ -192,6 +192,47 @@ def g_sim_topk():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def g_dense_model():
+    """G13: dense.DenseModel end to end (dense.py:30-54, encoder.py:77-113 eval branch) over the reference T5 encoder
+    (tiny shape): encode_query / encode_passage with a DensePooler (separate q / p linears, L2 normalise) and without,
+    forward(query=, passage=).scores, and topk over the scores."""
+    tmp = tempfile.mkdtemp()
+    try:
+        os.makedirs(tmp + "/refdense2")
+        open(tmp + "/refdense2/__init__.py", "w").close()
+        for f in ("dense.py", "encoder.py"):
+            shutil.copy(REF + "/" + f, tmp + "/refdense2/" + f)     # temp dir only, never the repo
+        builtins.ModelArguments = builtins.TrainingArguments = object
+        sys.path.insert(0, tmp)
+        try:
+            dense = importlib.import_module("refdense2.dense")
+        finally:
+            sys.path.remove(tmp)
+        cfg = GDRConfig.tiny()
+        sd = synth.make_state_dict(cfg, seed=1234)
+        enc = ref_t5(cfg, sd).get_encoder()
+        qi, qm = synth.make_tokens(5, L=8, vocab_hi=cfg.vocab_size, seed=21, min_len=2)
+        pi, pm = synth.make_tokens(9, L=12, vocab_hi=cfg.vocab_size, seed=22, min_len=3)
+        qry = {"input_ids": torch.from_numpy(qi), "attention_mask": torch.from_numpy(qm)}
+        psg = {"input_ids": torch.from_numpy(pi), "attention_mask": torch.from_numpy(pm)}
+        torch.manual_seed(9)
+        pool = dense.DensePooler(cfg.d_model, 32, normalize=True)
+        out = {}
+        with torch.no_grad():
+            for name, pooler in (("pool", pool), ("cls", None)):
+                m = dense.DenseModel(enc, enc, pooler=pooler).eval()
+                o = m(query=qry, passage=psg)
+                assert o.loss is None
+                assert torch.equal(o.q_reps, m.encode_query(qry)) and torch.equal(o.p_reps, m.encode_passage(psg))
+                v, i = o.scores.topk(3, dim=1, largest=True, sorted=True)
+                out.update({f"{name}_q_reps": o.q_reps, f"{name}_p_reps": o.p_reps, f"{name}_scores": o.scores,
+                            f"{name}_top_v": v, f"{name}_top_i": i.to(torch.int32)})
+        save("g13_dense_model", seed=1234, q_ids=qi, q_mask=qm, p_ids=pi, p_mask=pm,
+             wq=pool.linear_q.weight, bq=pool.linear_q.bias, wp=pool.linear_p.weight, bp=pool.linear_p.bias, **out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def g_decode_logits_tiny():
     """G8: T5ForConditionalGeneration.forward decode branch (decoder + adaptor head + positional mask), tiny."""
     cfg = GDRConfig.tiny()
@@ -370,6 +411,58 @@ def g_metrics(main_metrics):
     os.unlink(tmp.name)
     save("g7_metrics", rows=np.array(rows), recall_k=np.array(sorted(rec)), recall_v=np.array([rec[k] for k in sorted(rec)]),
          mrr100=np.array(mrr))
+
+
+def _epoch_end_outputs(seed, n_batches, eval_batch_size, R, n_alpha, multi_gt):
+    """Harness-built `outputs` of validation_step_i (main_models.py:1640-1641): cluster rows + per-alpha doc rows."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    outputs = []
+    for bi in range(n_batches):
+        res, idx = [], []
+        for b in range(eval_batch_size):
+            text = f"query {bi}-{b}"
+            clusters = [f"{int(a)}-{int(c)}" for a, c in zip(g.integers(0, 6, R), g.integers(0, 6, R))]
+            sel = int(g.integers(0, 3))
+            gt = clusters[int(g.integers(0, R))] if sel == 0 else (clusters[0] if sel == 1 else "9-9")
+            if multi_gt and b % 2:
+                gt = gt + "," + clusters[int(g.integers(0, R))]
+            res.append([text, ",".join(clusters), gt, 1])
+            per_alpha = []
+            for a in range(n_alpha):
+                docs = [str(int(x)) for x in g.permutation(60)[:R]]
+                gtd = docs[int(g.integers(0, R))] if (bi + b + a) % 3 else "999"
+                if multi_gt and b % 2:
+                    gtd = gtd + "," + docs[int(g.integers(0, R))]
+                per_alpha.append([[text, ",".join(docs), gtd]])
+            idx.append(per_alpha)
+        outputs.append({"inf_result_batch": res, "inf_result_batch_prob": [float(x) for x in g.standard_normal(eval_batch_size * R)],
+                        "inf_index_batch": idx})
+    return outputs
+
+
+def g_epoch_metrics(main_models):
+    """G12: T5FineTuner.validation_epoch_end (main_models.py:1643-1908) — cal_recall / cal_accuracy / cal_MRR / cal_MAP per
+    alpha — run from the reference on harness-built step outputs; everything it passes to self.log is recorded."""
+    import json
+    cases = {}
+    for name, (ite, multi) in {"two_stage": (1, True), "cluster_only": (0, True), "single_gt": (1, False)}.items():
+        score_rate = [0, 0.5, 1.5]
+        outputs = _epoch_end_outputs(seed=31 + len(name), n_batches=5, eval_batch_size=2, R=10,
+                                     n_alpha=len(score_rate), multi_gt=multi)
+        obj = main_models.T5FineTuner.__new__(main_models.T5FineTuner)
+        torch.nn.Module.__init__(obj)
+        logged = {}
+        obj.log = lambda k, v, **kw: logged.__setitem__(k, float(v))
+        obj.epoch = 0
+        obj.l1_query_train_dataset = types.SimpleNamespace(epoch=0)
+        obj.args = types.SimpleNamespace(begin_val_epoch=0, multiple_decoder=0, eval_batch_size=2, score_rate=score_rate,
+                                         is_train_encoder=ite, train_encoder_epoch=51)
+        quiet(obj.validation_epoch_end, json.loads(json.dumps(outputs)))
+        cases[name + "_outputs"] = json.dumps(outputs)
+        cases[name + "_args"] = json.dumps({"eval_batch_size": 2, "score_rate": score_rate, "is_train_encoder": ite})
+        cases[name + "_keys"] = np.array(sorted(logged))
+        cases[name + "_vals"] = np.array([logged[k] for k in sorted(logged)], np.float64)
+    save("g12_epoch_metrics", **cases)
 
 
 def g_rerank(main_models):
@@ -581,7 +674,7 @@ def g_cli():
 
 
 FIXTURES = ["buckets", "encoder_tiny", "encoder_base", "sim_topk", "decode_logits_tiny", "generate_tiny",
-            "generate_base", "beam_table", "codec", "metrics", "rerank", "cli", "doc_tower", "beam_trie"]
+            "generate_base", "beam_table", "codec", "metrics", "rerank", "cli", "doc_tower", "beam_trie", "epoch_metrics", "dense_model"]
 
 
 def main():
@@ -599,6 +692,8 @@ def main():
             g_metrics(main_metrics)
         elif name == "rerank":
             g_rerank(main_models)
+        elif name == "epoch_metrics":
+            g_epoch_metrics(main_models)
         else:
             globals()["g_" + name]()
 

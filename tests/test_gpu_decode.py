@@ -159,7 +159,7 @@ def test_two_stage_retrieval_vs_oracle(dev):
                                np.array(rs, np.float32).reshape(B, R).tolist(), args.score_rate, R)
     for b in range(B):
         for a in range(len(args.score_rate)):
-            assert out["inf_index_batch"][b][a] == [str(x) for x in ref[b][a][1].tolist()]
+            assert out["doc_ids"][b][a] == [str(x) for x in ref[b][a][1].tolist()]
 
 
 def test_doc_tower_vs_reference_golden(dev):
@@ -264,4 +264,4 @@ def test_two_stage_with_reencode_vs_oracle(dev):
                                args.score_rate, R)
     for b in range(B):
         for a in range(len(args.score_rate)):
-            assert out["inf_index_batch"][b][a] == [str(x) for x in ref[b][a][1].tolist()]
+            assert out["doc_ids"][b][a] == [str(x) for x in ref[b][a][1].tolist()]

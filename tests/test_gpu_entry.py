@@ -1,0 +1,317 @@
+"""GPU parity of the named surface at the reference's own entry points and at BASELINE.json's configuration shapes:
+
+  * `python -m gdr_amd.main --mode eval` with infer.sh's flags (GDR_model/main.py:115-250, infer.sh:10-15): the res1 TSV
+    (and the doc-level TSV of the two-stage path) row for row against the oracle composition
+    beam_ref.generate -> codec_ref.decode_token -> retrieval_ref.rerank;
+  * dense.DenseModel / DensePooler (dense.py:10-54) through encode_query -> compute_similarity -> search, against
+    fixtures made by running the reference classes (g13, g3);
+  * config C2 — all 512 query rows of the 320 000 x 768 top-100 against the oracle;
+  * config C4 — 4096 queries x 8 shards of 40 000 rows: packed exchange form + merge == single-shard search, rows vs oracle;
+  * config C3 at full size — 320 000 docs, 64 queries, beam 10, t5-base two-stage retrieval, two queries vs the oracle;
+  * a Lightning-style checkpoint dict ({"state_dict": {"model.…", "encoder.model.…"}}, main.py:121-126) through
+    GDRModel / EncoderModel.from_state_dict and through `--infer_ckpt`.
+"""
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, golden, order_insensitive_topk_match, ranked_lists_match
+from gdr_amd.config import GDRConfig
+from gdr_amd import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+TOL = 1e-4
+
+# GDR_model/infer.sh:10-15 as written (BEAM_SIZE / INFER_CKPT substituted per test)
+INFER_SH = ("--decode_embedding 2 --n_gpu 1 --mode eval --query_type gtq_doc_aug_qg --adaptor_layer_num 4 "
+            "--tree 1 --model_info base --train_batch_size 64 --test1000 0 --dropout_rate 0.1 --Rdrop 0.1 "
+            "--adaptor_decode 1 --adaptor_efficient 1 --aug_query 1 --aug_query_type corrupted_query --input_dropout 1 "
+            "--id_class bert_k30_c30_1 --kary 30 --output_vocab_size 30 --doc_length 64 --denoising 0 "
+            "--max_output_length 10 --trivia 0 --nq 1").split()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _run_main(argv, timeout=1500):
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, "-m", "gdr_amd.main"] + argv, cwd=REPO, env=env, timeout=timeout,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout[-4000:]
+    return p.stdout
+
+
+def _read_tsv(path):
+    return [line.rstrip("\n").split("\t") for line in open(path)]
+
+
+@pytest.fixture(scope="module")
+def base_weights():
+    cfg = GDRConfig.base()
+    return cfg, synth.make_state_dict(cfg, seed=1234)
+
+
+@pytest.mark.parametrize("R,n_q,bs,constrain", [(10, 8, 4, 0), (10, 8, 4, 1), (100, 2, 1, 0)])
+def test_main_eval_entry_point_vs_oracle_composition(tmp_path, base_weights, R, n_q, bs, constrain):
+    """The entry point the reference names (main.py --mode eval with infer.sh's flags) on a reduced synthetic corpus
+    (30 000 docs): stage-1 rows of the res1 TSV == oracle beam decode + decode_token, and with the trie constraint
+    (valid cluster ids -> real candidates) the doc-level rows for every alpha == the oracle rerank.  Rows may permute
+    only inside tolerance-tie groups of the oracle's scores."""
+    from oracle import beam_ref, codec_ref, retrieval_ref
+    cfg, sd = base_weights
+    N = 30000
+    res1 = str(tmp_path / "res1.tsv")
+    out = _run_main(INFER_SH + ["--infer_ckpt", "", "--num_return_sequences", str(R), "--eval_batch_size", str(bs),
+                                "--corpus_rows", str(N), "--n_queries", str(n_q), "--constrain_tree", str(constrain),
+                                "--res1_save_path", res1])
+    assert "recall@1:" in out and "MRR100:" in out
+    # ---- oracle composition on the same seeded inputs
+    names, depth, offsets, members = synth.make_cluster_ids(N, cluster_size=12, V=30)
+    ids, mask = synth.make_tokens(n_q, L=40, seed=11)
+    tree = beam_ref.build_trie([codec_ref.encode_single_newid(s, kary=30) for s in names]) if constrain else None
+    (rd, rs), enc_x = beam_ref.generate(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask), R, max_length=10,
+                                        restricted_head=True, decode_tree=tree)
+    dec = codec_ref.dec_2d(codec_ref.decode_token(rd.numpy(), output_vocab_size=30, kary=30), R)
+    rs2 = np.array(rs, np.float64).reshape(n_q, R)
+    D = synth.make_corpus(N, cfg.d_model)
+    _, gold = synth.make_queries(D, n_q)
+    rows = {r[0]: r for r in _read_tsv(res1)}
+    assert [r[0] for r in _read_tsv(res1)] == sorted(rows), "res1 is sorted by query like the reference's sort_values"
+    assert len(rows) == n_q
+    for q in range(n_q):
+        r = rows[f"q{q}"]
+        ranked_lists_match(dec[q], rs2[q], r[1].split(","), TOL)
+        assert r[2] == names[int(gold[q]) // 12] and r[3] == "1"
+    if not constrain:
+        return
+    # ---- stage 2: every decoded cluster is a real one, so the rerank sees R * 12 candidates per query
+    look = {n: i for i, n in enumerate(names)}
+    mem_q = [[m for s in row for m in members[offsets[look[s]]:offsets[look[s] + 1]].tolist()] for row in dec]
+    num_q = [[12] * R for _ in dec]
+    alphas = [0, 0.5, 1, 1.5, 2, 2.5, 3]
+    ref = retrieval_ref.rerank(enc_x[::R][:, 0], torch.from_numpy(D), mem_q, num_q, rs2.astype(np.float32).tolist(),
+                               alphas, R)
+    docs = _read_tsv(res1 + ".docs.tsv")
+    assert len(docs) == n_q * len(alphas)
+    got = {(r[0], float(r[1])): r for r in docs}
+    for q in range(n_q):
+        for ai, al in enumerate(alphas):
+            r = got[(f"q{q}", float(al))]
+            ranked_lists_match([str(x) for x in ref[q][ai][1].tolist()], ref[q][ai][0].numpy(), r[2].split(","), TOL)
+            assert r[3] == str(int(gold[q]))
+    assert "stage 2 (in-cluster rerank)" in out
+
+
+def test_main_eval_missing_checkpoint_is_an_error(tmp_path):
+    """A non-empty --infer_ckpt that does not exist must fail (the reference's torch.load raises, main.py:121), not fall
+    back to random weights."""
+    env = dict(os.environ, PYTHONPATH=REPO)
+    p = subprocess.run([sys.executable, "-m", "gdr_amd.main"] + INFER_SH + ["--infer_ckpt", "ckpt file", "--n_queries", "1"],
+                       cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode != 0 and "does not exist" in p.stdout
+
+
+def test_dense_model_and_pooler_vs_reference_golden(dev):
+    """dense.DenseModel(lm_q, lm_p, pooler) of the reference (g13: run from dense.py / encoder.py over the reference T5
+    encoder) vs the product classes on the GPU: encode_query / encode_passage / forward().scores / search()."""
+    from gdr_amd.modeling import DenseModel, DensePooler, GDRModel
+    g = golden("g13_dense_model")
+    cfg = GDRConfig.tiny()
+    lm = GDRModel(cfg, synth.make_state_dict(cfg, seed=int(g["seed"])), dev, with_decoder=False).get_encoder()
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+    qry = {"input_ids": T(g["q_ids"]), "attention_mask": T(g["q_mask"])}
+    psg = {"input_ids": T(g["p_ids"]), "attention_mask": T(g["p_mask"])}
+    pool = DensePooler(T(g["wq"]), T(g["bq"]), T(g["wp"]), T(g["bp"]), normalize=True)
+    for mode, pooler in (("pool", pool), ("cls", None)):
+        m = DenseModel(lm, lm, pooler=pooler)
+        o = m(query=qry, passage=psg)
+        assert o.loss is None
+        np.testing.assert_allclose(o.q_reps.cpu().numpy(), g[mode + "_q_reps"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(o.p_reps.cpu().numpy(), g[mode + "_p_reps"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(o.scores.cpu().numpy(), g[mode + "_scores"], rtol=1e-4, atol=2e-5)
+        assert torch.equal(m.encode_query(qry), o.q_reps) and torch.equal(m.encode_passage(psg), o.p_reps)
+        v, i = m.search(o.q_reps, o.p_reps, 3)                            # compute_similarity + topk fused
+        assert i.dtype == torch.int64
+        order_insensitive_topk_match(g[mode + "_top_v"], g[mode + "_top_i"].astype(np.int64), v.cpu().numpy(),
+                                     i.cpu().numpy(), TOL)
+        only_q = m(query=qry)
+        assert only_q.p_reps is None and only_q.scores is None and torch.equal(only_q.q_reps, o.q_reps)
+    # the pooler alone on the g3 fixture (random hidden states through dense.DensePooler)
+    g3 = golden("g3_sim_topk")
+    p3 = DensePooler(T(g3["pool_w"]), T(g3["pool_b"]), normalize=True)
+    np.testing.assert_allclose(p3(q=T(g3["pool_hidden"])).cpu().numpy(), g3["pool_out"], rtol=1e-4, atol=2e-5)
+    with pytest.raises(ValueError):
+        p3()
+
+
+def test_c2_all_512_rows_vs_oracle(dev):
+    """Config C2 at its own size: every one of the 512 query rows of the 320 000 x 768 top-100 against the oracle
+    (the CPU product is a few seconds); ids may permute only inside tolerance-tie groups."""
+    from gdr_amd import ops
+    from oracle import retrieval_ref
+    D = synth.make_corpus(320000, 768)
+    Q, gold = synth.make_queries(D, 512)
+    v, i, st = ops.sim_topk(torch.from_numpy(Q).to(dev), torch.from_numpy(D).to(dev), 100, return_status=True)
+    assert int(st.sum().item()) == 0
+    rv, ri = retrieval_ref.sim_topk(torch.from_numpy(Q), torch.from_numpy(D), 100, block=128)
+    gi = i.cpu().numpy().astype(np.int64)
+    permuted = order_insensitive_topk_match(rv.numpy(), ri.numpy(), v.cpu().numpy(), gi, TOL)
+    identical = int((gi == ri.numpy()).all(axis=1).sum())
+    assert identical >= 480 and permuted <= 64, (identical, permuted)     # near-ties are rare, not the rule
+    hit = lambda idx, k: float(np.mean([gold[b] in idx[b, :k] for b in range(512)]))   # noqa: E731
+    for k in (1, 10, 100):
+        assert abs(hit(gi, k) - hit(ri.numpy(), k)) * 100 <= 0.1          # Recall@k within +-0.1 (north_star)
+
+
+def test_c4_shape_4096_queries_8_shards_packed_merge(dev):
+    """Config C4's shape on one GPU: 4096 queries against 8 row shards of 40 000 docs (cluster-aligned), each shard's
+    (values, ids, status) in the packed wire form, merged — must equal the single-shard search over all 320 000 rows
+    (rows are independent: same scores, same tie rule), and 8 spread rows must match the oracle."""
+    from gdr_amd import ops
+    from gdr_amd.dist import shard_bounds
+    from oracle import retrieval_ref
+    N, G, B, k = 320000, 8, 4096, 100
+    D = synth.make_corpus(N, 768)
+    Q, _ = synth.make_queries(D, B, seed=13)
+    Dd, Qd = torch.from_numpy(D).to(dev), torch.from_numpy(Q).to(dev)
+    ws = ops.Workspace(dev)
+    packs = []
+    for r in range(G):
+        lo, hi = shard_bounds(N, G, r, cluster_size=12)
+        assert 39996 <= hi - lo <= 40008
+        v, i, st = ops.sim_topk(Qd, Dd[lo:hi], k, idx_offset=lo, workspace=ws, return_status=True)
+        assert int(i.min()) >= lo and int(i.max()) < hi
+        packs.append(ops.topk_pack(v, i, st))
+    mv, mi, ms = ops.topk_merge_packed(torch.stack(packs), return_status=True)
+    assert int(ms.sum().item()) == 0
+    fv, fi, fs = ops.sim_topk(Qd, Dd, k, workspace=ws, return_status=True)
+    assert int(fs.sum().item()) == 0
+    order_insensitive_topk_match(fv.cpu().numpy(), fi.cpu().numpy().astype(np.int64), mv.cpu().numpy(),
+                                 mi.cpu().numpy().astype(np.int64), 1e-6)
+    assert float((mi == fi).all(dim=1).float().mean()) > 0.99
+    rows = np.linspace(0, B - 1, 8).astype(np.int64)
+    rv, ri = retrieval_ref.sim_topk(torch.from_numpy(Q[rows]), torch.from_numpy(D), k)
+    order_insensitive_topk_match(rv.numpy(), ri.numpy(), mv[rows].cpu().numpy(), mi[rows].cpu().numpy().astype(np.int64), TOL)
+    # a flagged shard reaches the merged status of exactly that query
+    st2 = torch.zeros(B, dtype=torch.int32, device=dev)
+    st2[77] = 1
+    lo3, hi3 = shard_bounds(N, G, 3, cluster_size=12)
+    v3, i3 = ops.sim_topk(Qd, Dd[lo3:hi3], k, idx_offset=lo3, workspace=ws)
+    packs[3] = ops.topk_pack(v3, i3, st2)
+    _, mi2, ms2 = ops.topk_merge_packed(torch.stack(packs), return_status=True)
+    assert ms2.nonzero().flatten().tolist() == [77] and torch.equal(mi2, mi)
+
+
+def test_c3_full_size_two_stage_vs_oracle(dev, base_weights):
+    """Config C3 at full size: 320 000 docs, a batch of 64 queries, beam 10, t5-base: validation_step_i (decode ->
+    id_mapping -> in-cluster rerank) vs the oracle composition on two of the queries.  Random weights decode
+    full-length rows that name no cluster, so every decoded string is given a real 12-doc cluster of the corpus."""
+    from gdr_amd import codec
+    from gdr_amd.modeling import GDRModel, GDRRetriever
+    from oracle import beam_ref, codec_ref, retrieval_ref
+    cfg, sd = base_weights
+    N, B, R = 320000, 64, 10
+    names, depth, offsets, members = synth.make_cluster_ids(N, cluster_size=12, V=30)
+    Dn = synth.make_corpus(N, cfg.d_model)
+    D = torch.from_numpy(Dn).to(dev)
+    ids, mask = synth.make_tokens(B, L=40, seed=11)
+    batch = {"source_ids": torch.from_numpy(ids).to(dev), "source_mask": torch.from_numpy(mask).to(dev)}
+    args = types.SimpleNamespace(num_return_sequences=R, output_vocab_size=30, max_output_length=10, length_penalty=0.8,
+                                 kary=30, position=1, score_rate=[0, 0.5, 1, 1.5, 2, 2.5, 3], loss_func="tanh")
+    model = GDRModel(cfg, sd, dev)
+    (outs, _), _ = model.generate(batch["source_ids"], attention_mask=batch["source_mask"], max_length=10, num_beams=R,
+                                  length_penalty=0.8, num_return_sequences=R, output_scores=True)
+    first = {"clusters": codec.dec_2d(codec.decode_token(args, outs.cpu().numpy()), R)}
+    strs = sorted({s for row in first["clusters"] for s in row})
+    assert len(strs) > B                                      # the batch really decodes many different ids
+    stride = len(names) // len(strs)                          # spread the decoded ids over the whole corpus
+    renamed = list(names)
+    for j, s in enumerate(strs):
+        renamed[j * stride] = s
+    index = codec.ClusterIndex(renamed, offsets, members)
+    out = GDRRetriever(model, D, index, args).validation_step_i(batch)
+    assert out["clusters"] == first["clusters"]
+    nq = 2
+    (rd, rs), enc_x = beam_ref.generate(sd, cfg, torch.from_numpy(ids[:nq]), torch.from_numpy(mask[:nq]), R,
+                                        max_length=10, restricted_head=True)
+    dec = codec_ref.dec_2d(codec_ref.decode_token(rd.numpy(), output_vocab_size=30, kary=30), R)
+    rs2 = np.array(rs, np.float64).reshape(nq, R)
+    look = {n: i for i, n in enumerate(renamed)}
+    for q in range(nq):
+        ranked_lists_match(dec[q], rs2[q], out["clusters"][q], TOL)
+    np.testing.assert_allclose(np.array(out["inf_result_batch_prob"]).reshape(B, R)[:nq], rs2, rtol=1e-4, atol=1e-4)
+    if [out["clusters"][q] for q in range(nq)] != dec:
+        pytest.skip("beam order differs inside a tolerance tie: the rerank candidates are laid out differently")
+    mem_q = [[m for s in row for m in members[offsets[look[s]]:offsets[look[s] + 1]].tolist()] for row in dec]
+    num_q = [[12] * R for _ in dec]
+    ref = retrieval_ref.rerank(enc_x[::R][:, 0], torch.from_numpy(Dn), mem_q, num_q, rs2.astype(np.float32).tolist(),
+                               args.score_rate, R)
+    for q in range(nq):
+        for a in range(len(args.score_rate)):
+            ranked_lists_match([str(x) for x in ref[q][a][1].tolist()], ref[q][a][0].numpy(), out["doc_ids"][q][a], TOL)
+            np.testing.assert_allclose(out["rerank_values"][q, a].cpu().numpy(), ref[q][a][0].numpy(), rtol=1e-4, atol=1e-4)
+
+
+def _lightning_ckpt(t5_sd, bert_sd):
+    """The layout main.py:121-126 loads: {"state_dict": {...}} with the T5 under `model.` (main_models.py:794) and the doc
+    tower under `encoder.model.` (main_models.py:797, :62-78), plus entries a real checkpoint also carries."""
+    sd = {"model." + k: v for k, v in t5_sd.items()}
+    sd.update({"encoder.model." + k: v for k, v in bert_sd.items()})
+    return {"state_dict": sd, "epoch": 3, "global_step": 1234}
+
+
+def test_lightning_checkpoint_roundtrip_through_product_classes(dev, tmp_path):
+    """A Lightning-style checkpoint saved with torch.save and loaded as main.py does: GDRModel (T5 part) and
+    EncoderModel.from_state_dict (doc tower) give bit-identical outputs to the models built from the bare state_dicts,
+    and the T5 part matches the oracle."""
+    from gdr_amd.modeling import EncoderModel, GDRModel
+    from oracle import beam_ref
+    cfg = GDRConfig.tiny()
+    sd = synth.make_state_dict(cfg, seed=77)
+    bc = synth.bert_config(tiny=True)
+    bsd = synth.make_bert_state_dict(bc, seed=78)
+    path = str(tmp_path / "epoch=3.ckpt")
+    torch.save(_lightning_ckpt(sd, bsd), path)
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    ids, mask = synth.make_tokens(3, L=9, vocab_hi=cfg.vocab_size, seed=2, min_len=2)
+    idt, mt = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    kw = dict(attention_mask=mt, max_length=cfg.max_output_length, num_beams=4, length_penalty=0.8, num_return_sequences=4,
+              output_scores=True)
+    (d1, s1), _ = GDRModel(cfg, ckpt, dev).generate(idt, **kw)
+    (d0, s0), _ = GDRModel(cfg, sd, dev).generate(idt, **kw)
+    assert torch.equal(d1, d0) and s1 == s0
+    (rd, rs), _ = beam_ref.generate(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask), 4, restricted_head=True)
+    assert np.array_equal(d1.cpu().numpy(), rd.numpy())
+    np.testing.assert_allclose(np.array(s1), np.array(rs), rtol=1e-4, atol=1e-4)
+    pids, pmask = synth.make_tokens(4, L=20, vocab_hi=bc["vocab_size"], seed=3, min_len=5)
+    psg = {"input_ids": torch.from_numpy(pids).to(dev), "attention_mask": torch.from_numpy(pmask).to(dev)}
+    e1 = EncoderModel.from_state_dict(bc, ckpt, dev)(passage=psg)
+    e0 = EncoderModel.from_state_dict(bc, bsd, dev)(passage=psg)
+    assert torch.equal(e1, e0)
+
+
+def test_main_eval_with_infer_ckpt_equals_synthetic_weights(tmp_path):
+    """`--infer_ckpt file.ckpt` (a Lightning checkpoint of the same seeded weights, t5-small sizes) gives the same res1
+    TSV as the synthetic-weights run: the checkpoint path of the entry point loads what it is given."""
+    from gdr_amd.main import parsers_parser
+    base = [a if a != "base" else "small" for a in INFER_SH] + ["--num_return_sequences", "6", "--eval_batch_size", "3",
+                                                               "--corpus_rows", "6000", "--n_queries", "5",
+                                                               "--is_train_encoder", "0"]
+    args = parsers_parser(base + ["--infer_ckpt", ""])
+    cfg = GDRConfig.from_args(args)
+    sd = synth.make_state_dict(cfg, seed=1234)
+    path = str(tmp_path / "small.ckpt")
+    torch.save(_lightning_ckpt(sd, {}), path)
+    a, b = str(tmp_path / "a.tsv"), str(tmp_path / "b.tsv")
+    _run_main(base + ["--infer_ckpt", path, "--res1_save_path", a])
+    _run_main(base + ["--infer_ckpt", "", "--res1_save_path", b])
+    assert open(a).read() == open(b).read() and len(_read_tsv(a)) == 5

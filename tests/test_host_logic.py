@@ -97,6 +97,33 @@ def test_product_metrics_known_answers(tmp_path):
     assert codec.MRR100(types.SimpleNamespace(res1_save_path=str(p)), verbose=False) == pytest.approx(float(g["mrr100"]), abs=1e-15)
 
 
+@pytest.mark.parametrize("case", ["two_stage", "cluster_only", "single_gt"])
+def test_epoch_metrics_match_reference_validation_epoch_end(case):
+    """cal_recall / cal_accuracy / cal_MRR / cal_MAP and the per-alpha grouping of validation_epoch_end
+    (main_models.py:1643-1908): every value the reference passed to self.log on these step outputs, by name."""
+    import json
+    import types
+    from gdr_amd import codec
+    g = golden("g12_epoch_metrics")
+    outputs = json.loads(str(g[case + "_outputs"]))
+    args = types.SimpleNamespace(**json.loads(str(g[case + "_args"])))
+    logged = codec.validation_epoch_end(outputs, args)
+    keys = [str(k) for k in g[case + "_keys"]]
+    assert sorted(logged) == keys
+    np.testing.assert_allclose([logged[k] for k in keys], g[case + "_vals"], rtol=0, atol=1e-12)
+    assert any(0 < v < 1 for v in logged.values())                      # the fixture is not degenerate
+
+
+def test_cal_metrics_small_known_answers():
+    from gdr_amd import codec
+    q_pred = {"a": ["1", "2", "3", "4"], "b": ["9", "8", "7", "6"]}
+    q_gt = {"a": ["3", "1"], "b": ["5"]}
+    assert codec.cal_recall(q_pred, q_gt, 2) == (0.25, 1 / 3)           # macro (1/2 + 0)/2, micro 1/3
+    assert codec.cal_accuracy(q_pred, q_gt, 1) == 0.5
+    assert codec.cal_MRR(q_pred, q_gt, 4) == 0.5
+    assert codec.cal_MAP(q_pred, q_gt, 4) == pytest.approx(((1 / 1 + 2 / 3) / 4) / 2)
+
+
 def test_cluster_index_csr_matches_reference_lookup():
     from gdr_amd import codec
     g = golden("g4_rerank")

@@ -59,6 +59,29 @@ def test_pooler_contract():
     np.testing.assert_allclose(out.numpy(), g["pool_out"], rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode", ["pool", "cls"])
+def test_dense_model_matches_reference(mode):
+    """dense.DenseModel(lm_q, lm_p, pooler).eval()(query=, passage=) run from the reference (g13): the oracle's encoder +
+    cls_pool + compute_similarity + topk reproduce q_reps / p_reps / scores / top-3."""
+    g = golden("g13_dense_model")
+    cfg = GDRConfig.tiny()
+    sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
+    hq = t5_ref.encoder_forward(sd, cfg, torch.from_numpy(g["q_ids"]), torch.from_numpy(g["q_mask"]))
+    hp = t5_ref.encoder_forward(sd, cfg, torch.from_numpy(g["p_ids"]), torch.from_numpy(g["p_mask"]))
+    T = torch.from_numpy
+    if mode == "pool":
+        q = retrieval_ref.cls_pool(hq, T(g["wq"]), T(g["bq"]), normalize=True)
+        p = retrieval_ref.cls_pool(hp, T(g["wp"]), T(g["bp"]), normalize=True)
+    else:
+        q, p = retrieval_ref.cls_pool(hq), retrieval_ref.cls_pool(hp)
+    torch.testing.assert_close(q, T(g[mode + "_q_reps"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(p, T(g[mode + "_p_reps"]), rtol=1e-4, atol=1e-5)
+    sc = retrieval_ref.compute_similarity(q, p)
+    torch.testing.assert_close(sc, T(g[mode + "_scores"]), rtol=1e-4, atol=1e-5)
+    v, i = sc.topk(3, dim=1)
+    assert np.array_equal(i.numpy(), g[mode + "_top_i"])
+
+
 def test_decode_logits_tiny_matches_reference():
     g = golden("g8_decode_logits_tiny")
     cfg = GDRConfig.tiny()
