@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--replicated-merge", action="store_true",
                     help="N > 1: all-gather the per-shard lists and merge all queries on every rank (instead of the "
                          "all-to-all that hands each rank the lists of its own queries)")
+    ap.add_argument("--encoder", choices=["ragged", "padded"], default="ragged",
+                    help="ragged (default): PAD token rows are not computed and only the CLS rows go through the last "
+                         "block (exact: pooled output bit-identical to the padded form); padded: every one of the "
+                         "batch x 40 rows through all 48 linears, as the reference does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     return ap.parse_args()
@@ -139,8 +143,11 @@ def main():
     ids = torch.from_numpy(ids_all[rank * a.batch:(rank + 1) * a.batch]).to(dev)
     mask = torch.from_numpy(mask_all[rank * a.batch:(rank + 1) * a.batch]).to(dev)
 
+    ragged = a.encoder == "ragged" and not bf16
+    live_rows = int(mask_all[rank * a.batch:(rank + 1) * a.batch].sum())      # token rows that are not PAD (host-side metadata)
+
     def step():
-        _, pooled = enc.forward(ids, mask)
+        _, pooled = enc.forward(ids, mask, want_hidden=False, ragged=ragged, live_rows_hint=live_rows)
         q_all = index.gather_queries(pooled)
         if a.replicated_merge:
             return index.search(q_all, a.k, return_status=True)
@@ -201,10 +208,14 @@ def main():
             "config": {"workload": ("C2" if world == 1 else "C4-layout") +
                        f": t5-base encoder on {a.batch} queries/GPU (L=40) + fused Q.D^T top-{a.k} over a "
                        f"{a.corpus}x{cfg.d_model} {'bf16' if bf16 else 'fp32'} corpus" +
-                       (" [C5 precision mode: bf16 linear operands, fp32 accumulate]" if bf16 else "") + ("" if world == 1 else f" row-sharded {world} ways, "
+                       (" [C5 precision mode: bf16 linear operands, fp32 accumulate]" if bf16 else "") +
+                       (f" [ragged encoder: the {live_rows} non-PAD token rows of {a.batch * 40} are computed, last block "
+                        "on the CLS rows only; pooled output bit-identical to the padded form]" if ragged else
+                        " [padded encoder: all batch x 40 rows]") + ("" if world == 1 else f" row-sharded {world} ways, "
                        "all-gather of queries, all-to-all of per-shard top-k, local merge"),
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 40,
-                       "corpus_rows": a.corpus, "dim": cfg.d_model, "k": a.k, "corpus_resident_in_hbm": True},
+                       "corpus_rows": a.corpus, "dim": cfg.d_model, "k": a.k, "corpus_resident_in_hbm": True,
+                       "encoder_rows": "ragged" if ragged else "padded", "live_token_rows_per_gpu": live_rows},
             "roofline": {"bound": "mfma", "kernel": ("gdr::gemm_nt_bf16_glds_kernel (bf16 operands, LDS-DMA staging; every encoder linear)"
                                                      if bf16 else "gdr::gemm_nt_f32_persistent_kernel (every encoder linear)"),
                          "achieved": lin["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS if bf16 else F32_MFMA_PEAK_TFLOPS,

@@ -65,6 +65,9 @@ int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, 
 int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                          int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
                          float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream);
+int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M_max,
+                          const int64_t* m_dev, int N, int K, int epilogue, const float* bias, const float* residual,
+                          int64_t ldr, int64_t prof_rows, hipStream_t stream);
 // docs D[N,d] take the GEMM's row role, queries Q[B,d] the column role: a lane owns one query.
 int launch_sim_gemm(const void* D, int64_t N, const void* Q, int B, int d, const SimEpilogue& ep, bool bf16,
                     hipStream_t stream);

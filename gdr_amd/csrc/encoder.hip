@@ -147,6 +147,149 @@ extern "C" int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_
                               static_cast<hipStream_t>(stream_));
 }
 
+// ------------------------------------------------------------------------------------------------ ragged form
+// The same forward over the token rows that can influence the requested outputs (include/gdr_hip.h):
+//   * PAD rows are never computed: the live rows of the batch are packed front to back (launch_pack_plan), every linear /
+//     norm / residual runs over the packed rows, attention works per sequence on its own length.  A row's arithmetic is
+//     unchanged — GEMM rows are independent and keep their k order, a PAD key contributes exp(-1e9 - max) = 0 to a live
+//     query's softmax in the padded form and is simply absent here — so live rows are BIT-IDENTICAL to the padded form.
+//   * pooled-only calls (out_hidden == NULL: config C2, EncoderModel.encode_query) stop computing non-CLS rows after the
+//     last layer's attention: its o / wi / wo and the final norm run on the B CLS rows alone.
+// The row count is a device-side value (the mask lives on the device): grids are sized for B*L and kernels read the count,
+// so the call stays free of host synchronisation.
+namespace gdr {
+struct RagWs {
+  size_t seq_len, seq_off, row_src, rows_total, ctx_cls, h_cls, nx_cls, ff_cls, total;
+};
+static RagWs rag_ws(const GdrT5Dims& dm, int B, int L, size_t base) {
+  RagWs r{};
+  const size_t inner = (size_t)dm.num_heads * dm.d_kv;
+  size_t o = base;
+  r.seq_len = o, o += align_up((size_t)B * 4, 256);
+  r.seq_off = o, o += align_up((size_t)(B + 1) * 4, 256);
+  r.row_src = o, o += align_up((size_t)B * L * 4, 256);
+  r.rows_total = o, o += 256;
+  r.ctx_cls = o, o += align_up((size_t)B * inner * 4, 256);
+  r.h_cls = o, o += align_up((size_t)B * dm.d_model * 4, 256);
+  r.nx_cls = o, o += align_up((size_t)B * dm.d_model * 4, 256);
+  r.ff_cls = o, o += align_up((size_t)B * dm.d_ff * 4, 256);
+  r.total = o;
+  return r;
+}
+// The packed form needs the d_kv = 64 attention kernel and a 128x128 tile grid that fills the chip without split-K
+// (the narrowest linear has N = d_model): smaller problems run the padded form.
+static bool ragged_packs(const GdrT5Dims& dm, int B, int L) {
+  const int64_t tiles = (((int64_t)B * L + 127) / 128) * ((dm.d_model + 127) / 128);
+  return dm.d_kv == 64 && tiles >= 192 && dm.d_model % 32 == 0 && dm.d_ff % 32 == 0 && (dm.num_heads * dm.d_kv) % 32 == 0;
+}
+}  // namespace gdr
+
+extern "C" size_t gdr_t5_encoder_ragged_workspace_bytes(const GdrT5Dims* dims, int B, int L) {
+  if (!dims || B <= 0 || L <= 0) return 0;
+  return gdr::rag_ws(*dims, B, L, gdr::enc_ws(*dims, (int64_t)B * L).total).total;
+}
+
+extern "C" int gdr_t5_encoder_forward_ragged(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B,
+                                             int L, float* out_hidden, float* out_pooled, int64_t live_rows_hint,
+                                             void* workspace, size_t workspace_bytes, void* stream_) {
+  using namespace gdr;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (B == 0) return GDR_OK;
+  GDR_CHECK_ARG(w && ids && mask && workspace && (out_hidden || out_pooled), "t5_encoder_ragged: null pointer");
+  const GdrT5Dims& dm = w->dims;
+  GDR_CHECK_ARG(B > 0 && L > 0 && L <= 128, "t5_encoder_ragged: B=%d L=%d (L must be in [1,128])", B, L);
+  GDR_CHECK_ARG(dm.d_model % 4 == 0 && dm.d_kv % 4 == 0 && dm.d_ff % 4 == 0, "t5_encoder_ragged: dims must be multiples of 4");
+  GDR_CHECK_ARG(w->embed && w->rel_bias && w->final_ln && w->layers, "t5_encoder_ragged: null weight pointer");
+  const int64_t M = (int64_t)B * L;
+  const EncWs ws = enc_ws(dm, M);
+  const RagWs rw = rag_ws(dm, B, L, ws.total);
+  if (workspace_bytes < rw.total) {
+    set_error("t5_encoder_ragged: workspace %zu < required %zu", workspace_bytes, rw.total);
+    return GDR_ENOSPC;
+  }
+  GDR_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "t5_encoder_ragged: workspace must be 256-byte aligned");
+  char* base = static_cast<char*>(workspace);
+  const int d = dm.d_model, H = dm.num_heads, dk = dm.d_kv, inner = H * dk;
+  int rc;
+  int32_t* seq_len = reinterpret_cast<int32_t*>(base + rw.seq_len);
+  int32_t* seq_off = reinterpret_cast<int32_t*>(base + rw.seq_off);
+  int32_t* row_src = reinterpret_cast<int32_t*>(base + rw.row_src);
+  int64_t* rows_dev = reinterpret_cast<int64_t*>(base + rw.rows_total);
+  if ((rc = launch_pack_plan(mask, B, L, seq_len, seq_off, row_src, rows_dev, stream))) return rc;
+  if (!ragged_packs(dm, B, L)) {
+    // small problem / other head size: the padded forward, then the rows that the packed form would not have computed
+    // are zeroed so that the output contract does not depend on which form ran
+    float* full = out_hidden ? out_hidden : reinterpret_cast<float*>(base + ws.off_ff);  // ff is dead when the final norm runs
+    if ((rc = t5_encoder_impl(w, ids, mask, B, L, full, out_pooled, workspace, ws.total, false, stream))) return rc;
+    return out_hidden ? launch_zero_dead_rows(out_hidden, seq_len, B, L, d, stream) : GDR_OK;
+  }
+  float* h = reinterpret_cast<float*>(base + ws.off_h);
+  float* nx = reinterpret_cast<float*>(base + ws.off_nx);
+  float* qkv = reinterpret_cast<float*>(base + ws.off_qkv);
+  float* ctx = reinterpret_cast<float*>(base + ws.off_ctx);
+  float* ff = reinterpret_cast<float*>(base + ws.off_ff);
+  float* ctx_cls = reinterpret_cast<float*>(base + rw.ctx_cls);
+  float* h_cls = reinterpret_cast<float*>(base + rw.h_cls);
+  float* nx_cls = reinterpret_cast<float*>(base + rw.nx_cls);
+  float* ff_cls = reinterpret_cast<float*>(base + rw.ff_cls);
+  auto linear = [&](const float* A, int64_t lda, const float* W, float* C, int64_t ldc, int N, int K, int epi,
+                    const float* residual) -> int {
+    return launch_linear_f32_dev(A, lda, W, K, C, ldc, M, rows_dev, N, K, epi, nullptr, residual, ldc, live_rows_hint, stream);
+  };
+  if ((rc = launch_embed_packed(w->embed, ids, row_src, rows_dev, M, d, dm.vocab_size, h, stream))) return rc;
+
+  AttnArgs at{};
+  at.q = qkv, at.k = qkv + inner, at.v = qkv + 2 * inner, at.out = ctx;
+  at.ldq = at.ldk = at.ldv = 3 * inner, at.ldo = inner;
+  at.q_bstride = at.k_bstride = at.o_bstride = L;
+  at.B = B, at.H = H, at.dk = dk, at.Lq = L, at.Lk = L;
+  at.q_pos0 = 0, at.scale = 1.0f;
+  at.rel_bias = w->rel_bias, at.bidirectional = 1, at.num_buckets = dm.rel_buckets;
+  at.lut = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
+  at.key_mask = mask, at.mask_bstride = L, at.causal = 0, at.causal_neg_inf = 0;
+  at.kv_rows = nullptr, at.kv_group = 1;
+  at.seq_off = seq_off, at.seq_len = seq_len;
+
+  const bool pooled_only = out_hidden == nullptr;
+  for (int i = 0; i < dm.num_layers; ++i) {
+    const GdrT5EncLayer& ly = w->layers[i];
+    GDR_CHECK_ARG(ly.ln_attn && ly.wqkv && ly.wo && ly.ln_ff && ly.wi && ly.wo_ff, "t5_encoder_ragged: layer %d null weight", i);
+    if ((rc = launch_rmsnorm_dev(h, ly.ln_attn, nx, rows_dev, M, d, dm.eps, stream))) return rc;
+    if ((rc = linear(nx, d, ly.wqkv, qkv, 3 * inner, 3 * inner, d, GDR_EPI_NONE, nullptr))) return rc;
+    if ((rc = launch_attention(at, stream))) return rc;
+    if (pooled_only && i == dm.num_layers - 1) {
+      // only h[:,0] leaves this call: the rest of the block on the B CLS rows (packed row seq_off[b]); unsplit kernels,
+      // so the k order — and with it every bit of the result — is that of the full-batch GEMMs
+      if ((rc = launch_gather_rows(ctx, seq_off, B, inner, ctx_cls, stream))) return rc;
+      if ((rc = launch_gather_rows(h, seq_off, B, d, h_cls, stream))) return rc;
+      if ((rc = launch_linear_f32(ctx_cls, inner, ly.wo, inner, h_cls, d, B, d, inner, GDR_EPI_RESIDUAL, nullptr, h_cls, d, stream)))
+        return rc;
+      if ((rc = launch_rmsnorm(h_cls, ly.ln_ff, nx_cls, B, d, dm.eps, nullptr, 1, stream))) return rc;
+      if ((rc = launch_linear_f32(nx_cls, d, ly.wi, d, ff_cls, dm.d_ff, B, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0, stream)))
+        return rc;
+      if ((rc = launch_linear_f32(ff_cls, dm.d_ff, ly.wo_ff, dm.d_ff, h_cls, d, B, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, h_cls, d,
+                                  stream)))
+        return rc;
+      return launch_rmsnorm(h_cls, w->final_ln, out_pooled, B, d, dm.eps, nullptr, 1, stream);
+    }
+    if ((rc = linear(ctx, inner, ly.wo, h, d, d, inner, GDR_EPI_RESIDUAL, h))) return rc;
+    if ((rc = launch_rmsnorm_dev(h, ly.ln_ff, nx, rows_dev, M, d, dm.eps, stream))) return rc;
+    if ((rc = linear(nx, d, ly.wi, ff, dm.d_ff, dm.d_ff, d, GDR_EPI_RELU, nullptr))) return rc;
+    if ((rc = linear(ff, dm.d_ff, ly.wo_ff, h, d, d, dm.d_ff, GDR_EPI_RESIDUAL, h))) return rc;
+  }
+  // final_layer_norm over the live rows, then back into the [B,L,d] layout (PAD rows zero) and / or the CLS pool
+  if ((rc = launch_rmsnorm_dev(h, w->final_ln, nx, rows_dev, M, d, dm.eps, stream))) return rc;
+  if (out_pooled && (rc = launch_gather_rows(nx, seq_off, B, d, out_pooled, stream))) return rc;
+  if (out_hidden) {
+    if (hipMemsetAsync(out_hidden, 0, (size_t)M * d * sizeof(float), stream) != hipSuccess) {
+      set_error("t5_encoder_ragged: memset failed");
+      return GDR_EHIP;
+    }
+    if ((rc = launch_scatter_rows(nx, row_src, rows_dev, M, d, out_hidden, stream))) return rc;
+  }
+  return GDR_OK;
+}
+
 extern "C" size_t gdr_t5_encoder_bf16_workspace_bytes(const GdrT5Dims* dims, int B, int L) {
   if (!dims || B <= 0 || L <= 0) return 0;
   return gdr::enc_ws(*dims, (int64_t)B * L, true).total;

@@ -43,6 +43,8 @@ struct GemmArgs {
   int ksplit, kchunk;               // split-K: block handles K range [s*kchunk, (s+1)*kchunk) of its tile and stores a raw
                                     // 128x128 partial at C[(local_tile*ksplit + s)][128][128] (C = scratch)
   int tile_base;                    // first linear tile index of this launch (tail launches start past the full rounds)
+  const int64_t* m_dev;             // linear only, may be null: the row count lives on the device (*m_dev <= M, ragged
+                                    // batches, encoder.hip); the grid is sized for M and tiles past *m_dev exit at once
   SimEpilogue sim;
 };
 
@@ -87,6 +89,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
   }
   const int64_t m0 = mt * BM;
   const int n0 = nt * BN;
+  int64_t Mrows = g.M;
+  if (EPI == EPI_LINEAR && g.m_dev) {
+    Mrows = *g.m_dev;
+    if (m0 >= Mrows) return;  // uniform: a tile past the device-side row count
+  }
 
   const int tid = threadIdx.x;
   // ---- staging map: 8 lanes cover one 128-B row segment, 32 rows per pass, 4 passes ----
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     int64_t ra = m0 + lrow + 32 * p;
-    ra = ra < g.M ? ra : g.M - 1;  // clamp: rows past the edge are computed and discarded
+    ra = ra < Mrows ? ra : Mrows - 1;  // clamp: rows past the edge are computed and discarded
     int rw = n0 + lrow + 32 * p;
     rw = rw < g.N ? rw : g.N - 1;
     a_src[p] = reinterpret_cast<const char*>(g.A) + (ra * g.lda + lcole + split * g.kchunk) * ES;
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= g.M) continue;
+        if (m >= Mrows) continue;
         float v = acc[mi][ni][r] + bia;
         if (g.has_residual) v += g.residual[m * g.ldr + n];
         if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
 // Here a workgroup owns a strided list of tiles and runs ONE flattened K-step stream across them: the operand prefetch
 // (two K-steps ahead) simply continues into the next tile while the current one finishes, and the epilogue is a burst
 // of stores issued between two K-steps that drains in the background under the next tile's MFMAs.
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel(const GemmArgs g, const int total_tiles) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel(const GemmArgs g, const int total_tiles_host) {
   __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDS_STRIDE + 2 * BN * LDS_STRIDE];
   float* const As = smem;
   float* const Bs = smem + 2 * BM * LDS_STRIDE;
@@ -400,7 +407,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
   const int a_rd = (wm * 64 + l31) * LDS_STRIDE + 4 * h;
   const int b_rd = (wn * 64 + l31) * LDS_STRIDE + 4 * h;
   const int nk = g.K / BK;
-  const int tiles_m = (int)((g.M + BM - 1) / BM);
+  const int64_t Mrows = g.m_dev ? *g.m_dev : g.M;  // ragged batches: the row count is a device-side value <= g.M
+  const int tiles_m = (int)((Mrows + BM - 1) / BM);
+  const int total_tiles = g.m_dev ? tiles_m * g.tiles_n : total_tiles_host;
 
   int64_t a_ld[4];  // element offsets from g.A / g.W — kept as integers: pointers that pass through the tile-crossing
   int64_t w_ld[4];  // select lose their address space and the loads degrade to flat_load (vmcnt AND lgkmcnt)
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
     P_TILE_MN(tile_, mt_, nt_)                                               \
     _Pragma("unroll") for (int p = 0; p < 4; ++p) {                          \
       int64_t ra_ = (int64_t)mt_ * BM + lrow + 32 * p;                       \
-      ra_ = ra_ < g.M ? ra_ : g.M - 1;                                       \
+      ra_ = ra_ < Mrows ? ra_ : Mrows - 1;                                   \
       int rw_ = nt_ * BN + lrow + 32 * p;                                    \
       rw_ = rw_ < g.N ? rw_ : g.N - 1;                                       \
       a_ld[p] = ra_ * g.lda + lcol;                                          \
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
   if (++ld_kt == nk) { /* the load stream crosses into the workgroup's next tile (or parks on its first) */ \
     ld_kt = 0;                                                               \
     ld_tile += G;                                                            \
-    const int t_ = ld_tile < total_tiles ? ld_tile : (int)bid;               \
+    const int t_ = ld_tile < total_tiles ? ld_tile : park;                   \
     P_SETPTRS(t_)                                                            \
   } else {                                                                   \
     _Pragma("unroll") for (int p = 0; p < 4; ++p) a_ld[p] += BK, w_ld[p] += BK; \
@@ -473,8 +482,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
 #define P_MFMA16(A0, A1, B0, B1) \
   P_MFMA4(A0, A1, B0, B1, x) P_MFMA4(A0, A1, B0, B1, y) P_MFMA4(A0, A1, B0, B1, z) P_MFMA4(A0, A1, B0, B1, w)
 
+  // a workgroup whose list is exhausted (or empty: with a device-side row count the grid may exceed the tile count)
+  // parks its load stream on a valid tile
+  const int park = (int)bid < total_tiles ? (int)bid : 0;
   int ld_tile = (int)bid, ld_kt = 0;
-  P_SETPTRS(ld_tile)
+  P_SETPTRS(park)
   P_GLOAD
   P_ADVANCE
   P_LSTORE(0)
@@ -534,7 +546,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
       P_TILE_MN(tile, mt, nt)
       const int64_t m0 = (int64_t)mt * BM;
       const int n0 = nt * BN;
-      if (m0 + BM <= g.M && n0 + BN <= g.N) {
+      if (m0 + BM <= Mrows && n0 + BN <= g.N) {
         // interior tile: uniform branches only, so that the 64 residual loads go out as one batch and the 64 stores
         // as another (per-element flag tests serialise them behind a vmcnt(0) each)
         const int64_t mrow = m0 + wm * 64 + 4 * h;
@@ -588,7 +600,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
               const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
               float v = acc[mi][ni][r] + bia;
               acc[mi][ni][r] = 0.f;
-              if (!n_ok || m >= g.M) continue;
+              if (!n_ok || m >= Mrows) continue;
               if (g.has_residual) v += g.residual[m * g.ldr + n];
               if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
               if (g.act == ACT_GELU) v = gelu_erf(v);
@@ -781,6 +793,47 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
     }
     hipLaunchKernelGGL(gemm_nt_f32_persistent_kernel, dim3((unsigned)SLOTS), dim3(GEMM_THREADS), 0, stream, g, (int)tiles);
     GDR_CHECK_LAUNCH("gemm_nt_f32_persistent_kernel");
+    return GDR_OK;
+  }
+  return launch<EPI_LINEAR>(g, tiles_m, stream);
+}
+
+// The linear over a device-side row count (ragged batches): rows [0, *m_dev) of A, *m_dev <= M_max.  The grid is sized for
+// M_max and the kernels read the count themselves, so there is no host round trip.  No split-K / small-tile forms (their
+// k order differs: a row's result must not depend on how many rows happen to be live) — callers use this at encoder
+// batch sizes, where the 128x128 grid fills the chip anyway.  prof_rows: the live-row count if the host happens to
+// know it (< 0: unknown, M_max is used) — only the opt-in profiler's flop accounting reads it.
+int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M_max,
+                          const int64_t* m_dev, int N, int K, int epilogue, const float* bias, const float* residual,
+                          int64_t ldr, int64_t prof_rows, hipStream_t stream) {
+  if (M_max == 0) return GDR_OK;
+  GDR_CHECK_ARG(A && W && C && m_dev, "linear(dev rows): null pointer");
+  GDR_CHECK_ARG(M_max > 0 && N > 0 && K > 0 && K % BK == 0, "linear(dev rows): bad shape M<=%lld N=%d K=%d (K %% 32 == 0)",
+                (long long)M_max, N, K);
+  GDR_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= K && ldc >= N, "linear(dev rows): bad leading dimension");
+  GDR_CHECK_ARG(aligned16(A) && aligned16(W), "linear(dev rows): A and W must be 16-byte aligned");
+  GDR_CHECK_ARG(epilogue >= GDR_EPI_NONE && epilogue <= GDR_EPI_BIAS_GELU, "linear(dev rows): unknown epilogue %d", epilogue);
+  const bool needs_bias = epilogue == GDR_EPI_BIAS || epilogue == GDR_EPI_BIAS_RELU ||
+                          epilogue == GDR_EPI_BIAS_RESIDUAL || epilogue == GDR_EPI_BIAS_GELU;
+  const bool needs_res = epilogue == GDR_EPI_RESIDUAL || epilogue == GDR_EPI_BIAS_RESIDUAL;
+  GDR_CHECK_ARG(!needs_bias || bias, "linear(dev rows): epilogue %d needs bias", epilogue);
+  GDR_CHECK_ARG(!needs_res || (residual && ldr >= N), "linear(dev rows): epilogue %d needs residual", epilogue);
+  GemmArgs g{};
+  g.A = A, g.W = W, g.C = C, g.bias = bias, g.residual = residual;
+  g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr;
+  g.M = M_max, g.N = N, g.K = K, g.m_dev = m_dev;
+  g.tiles_n = (N + BN - 1) / BN;
+  g.has_bias = needs_bias, g.has_residual = needs_res;
+  g.act = (epilogue == GDR_EPI_RELU || epilogue == GDR_EPI_BIAS_RELU) ? ACT_RELU
+          : epilogue == GDR_EPI_BIAS_GELU                             ? ACT_GELU
+                                                                      : ACT_NONE;
+  const int64_t tiles_m = (M_max + BM - 1) / BM, tiles = tiles_m * g.tiles_n;
+  GDR_CHECK_ARG(tiles < 0x7fffffff, "linear(dev rows): grid too large");
+  ProfScope prof(PROF_LINEAR, 2.0 * (double)(prof_rows >= 0 ? prof_rows : M_max) * (double)N * (double)K, stream);
+  if (tiles > 512) {
+    g.ksplit = g.tiles_n >= 12 ? 8 : 1;  // supertile height, as in launch_linear_f32_ws
+    hipLaunchKernelGGL(gemm_nt_f32_persistent_kernel, dim3(512), dim3(GEMM_THREADS), 0, stream, g, (int)tiles);
+    GDR_CHECK_LAUNCH("gemm_nt_f32_persistent_kernel(dev rows)");
     return GDR_OK;
   }
   return launch<EPI_LINEAR>(g, tiles_m, stream);

@@ -35,15 +35,40 @@ struct AttnArgs {
   const int32_t* kv_rows;      // int32 [B, Lk]: absolute row of key j of batch entry b in k/v (beam-ancestor cache)
   int kv_group;                // batch entries sharing one K/V block: K/V batch index = b / kv_group (beams of a query)
   int q_same_pos;              // all Lq query rows of a batch entry sit at position q_pos0 (beam rows of one decode step)
+  // packed (ragged) self-attention: batch entry b owns rows seq_off[b] .. seq_off[b] + seq_len[b] - 1 of q/k/v/out
+  // (instead of b*bstride + i) and attends over its seq_len[b] keys; Lq = Lk = the longest possible sequence.  Only the
+  // dk = 64 full self-attention form (attention_mfma16_kernel) reads these.
+  const int32_t* seq_off;
+  const int32_t* seq_len;
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 
 int launch_embed(const float* table, const int64_t* ids, int64_t rows, int d, int vocab, float* out,
                  hipStream_t stream);
+// Ragged batches (encoder.hip): which token rows of a [B,L] batch are computed at all.
+//   seq_len[b] = number of leading ones of mask row b when the row is a non-empty prefix of ones (right padding, what the
+//                tokenizer produces), else L: such a sequence keeps all its positions and its mask (a fully masked row
+//                attends uniformly over PAD keys too, modeling_utils.py:271-272, so nothing of it may be dropped);
+//   seq_off[b] = exclusive prefix sum (seq_off[B] = total), row_src[r] = b*L + pos of packed row r, *rows_total = total.
+int launch_pack_plan(const int64_t* mask, int B, int L, int32_t* seq_len, int32_t* seq_off, int32_t* row_src,
+                     int64_t* rows_total, hipStream_t stream);
+// out[r] = table[ids[row_src[r]]] for r < *rows_dev (grid sized for max_rows)
+int launch_embed_packed(const float* table, const int64_t* ids, const int32_t* row_src, const int64_t* rows_dev,
+                        int64_t max_rows, int d, int vocab, float* out, hipStream_t stream);
+// dst[i] = src[idx[i]] (rows of d floats), i < n
+int launch_gather_rows(const float* src, const int32_t* idx, int n, int d, float* dst, hipStream_t stream);
+// dst[row_src[r]] = src[r] for r < *rows_dev: packed rows back into the [B*L, d] layout (dst pre-zeroed by the caller)
+int launch_scatter_rows(const float* src, const int32_t* row_src, const int64_t* rows_dev, int64_t max_rows, int d,
+                        float* dst, hipStream_t stream);
 // y = x / sqrt(mean(x^2) + eps) * w     (T5LayerNorm, modeling_t5.py:164-171); optional second output
 // `pooled` receives rows r with r % pool_every == 0 (CLS pool h[:,0]) when non-null.
 int launch_rmsnorm(const float* x, const float* w, float* y, int64_t rows, int d, float eps, float* pooled,
                    int pool_every, hipStream_t stream);
+// x[b, j, :] = 0 for j >= seq_len[b]  (x is [B, L, d])
+int launch_zero_dead_rows(float* x, const int32_t* seq_len, int B, int L, int d, hipStream_t stream);
+// same over the first *rows_dev rows (a device-side count; the grid is sized for max_rows)
+int launch_rmsnorm_dev(const float* x, const float* w, float* y, const int64_t* rows_dev, int64_t max_rows, int d, float eps,
+                       hipStream_t stream);
 // same, output rounded to bf16 (RNE): the activation operand of a bf16-mode linear
 int launch_rmsnorm_bf16(const float* x, const float* w, void* y_bf16, int64_t rows, int d, float eps, hipStream_t stream);
 // y = (x - mean) / sqrt(var + eps) * w + b   (torch.nn.LayerNorm; BERT / nn.TransformerDecoderLayer)

@@ -64,6 +64,143 @@ int launch_embed(const float* table, const int64_t* ids, int64_t rows, int d, in
   return GDR_OK;
 }
 
+// ------------------------------------------------------------------------------------------ ragged batches
+// One workgroup plans the whole batch: a wave per mask row (length + prefix test), then a block-wide exclusive scan of
+// the lengths, then every sequence writes the source rows of its packed rows.
+__global__ __launch_bounds__(1024) void pack_plan_kernel(const int64_t* __restrict__ mask, int B, int L,
+                                                         int32_t* __restrict__ seq_len, int32_t* __restrict__ seq_off,
+                                                         int32_t* __restrict__ row_src, int64_t* __restrict__ rows_total) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int b = wave; b < B; b += 16) {
+    int cnt = 0, last = -1;
+    for (int j = lane; j < L; j += 64) {
+      const bool on = mask[(int64_t)b * L + j] != 0;
+      cnt += on ? 1 : 0;
+      last = on ? j : last;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      cnt += __shfl_xor(cnt, o);
+      last = max(last, __shfl_xor(last, o));
+    }
+    if (lane == 0) seq_len[b] = (cnt > 0 && last + 1 == cnt) ? cnt : L;   // a non-empty prefix of ones, else keep all
+  }
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < B; base += 1024) {
+    const int b = base + tid;
+    const int v = b < B ? seq_len[b] : 0;
+    int inc = v;  // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (b < B) seq_off[b] = before + inc - v;
+    __syncthreads();
+    if (tid == 1023) carry = before + inc;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    seq_off[B] = carry;
+    *rows_total = carry;
+  }
+  for (int b = wave; b < B; b += 16) {
+    const int o = seq_off[b], n = seq_len[b];
+    for (int j = lane; j < n; j += 64) row_src[o + j] = b * L + j;
+  }
+}
+
+int launch_pack_plan(const int64_t* mask, int B, int L, int32_t* seq_len, int32_t* seq_off, int32_t* row_src,
+                     int64_t* rows_total, hipStream_t stream) {
+  GDR_CHECK_ARG(mask && seq_len && seq_off && row_src && rows_total, "pack_plan: null pointer");
+  GDR_CHECK_ARG((int64_t)B * L < 0x7fffffffLL, "pack_plan: batch too large");
+  hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(1024), 0, stream, mask, B, L, seq_len, seq_off, row_src, rows_total);
+  GDR_CHECK_LAUNCH("pack_plan_kernel");
+  return GDR_OK;
+}
+
+__global__ __launch_bounds__(256) void embed_packed_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids,
+                                                           const int32_t* __restrict__ row_src,
+                                                           const int64_t* __restrict__ rows_dev, int d4, int vocab,
+                                                           float* __restrict__ out) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= *rows_dev) return;
+  int64_t id = ids[row_src[row]];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float4* src = reinterpret_cast<const float4*>(table) + id * d4;
+  float4* dst = reinterpret_cast<float4*>(out) + row * d4;
+  for (int c = threadIdx.x & 63; c < d4; c += 64) dst[c] = src[c];
+}
+
+int launch_embed_packed(const float* table, const int64_t* ids, const int32_t* row_src, const int64_t* rows_dev,
+                        int64_t max_rows, int d, int vocab, float* out, hipStream_t stream) {
+  GDR_CHECK_ARG(d % 4 == 0, "embed: d %% 4 != 0");
+  if (max_rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(embed_packed_kernel, dim3((unsigned)((max_rows + 3) / 4)), dim3(256), 0, stream, table, ids, row_src,
+                     rows_dev, d / 4, vocab, out);
+  GDR_CHECK_LAUNCH("embed_packed_kernel");
+  return GDR_OK;
+}
+
+// SCATTER = false: dst[i] = src[map[i]];  SCATTER = true: dst[map[i]] = src[i]   (rows of d4 float4), i < n or *n_dev
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void move_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ map,
+                                                        int64_t n, const int64_t* __restrict__ n_dev, int d4,
+                                                        float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n_dev) n = *n_dev;
+  if (i >= n) return;
+  const int64_t m = map[i];
+  const float4* s = reinterpret_cast<const float4*>(src) + (SCATTER ? i : m) * d4;
+  float4* o = reinterpret_cast<float4*>(dst) + (SCATTER ? m : i) * d4;
+  for (int c = threadIdx.x & 63; c < d4; c += 64) o[c] = s[c];
+}
+
+int launch_gather_rows(const float* src, const int32_t* idx, int n, int d, float* dst, hipStream_t stream) {
+  GDR_CHECK_ARG(d % 4 == 0, "gather_rows: d %% 4 != 0");
+  if (n == 0) return GDR_OK;
+  hipLaunchKernelGGL(move_rows_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, src, idx, (int64_t)n,
+                     (const int64_t*)nullptr, d / 4, dst);
+  GDR_CHECK_LAUNCH("gather_rows");
+  return GDR_OK;
+}
+
+int launch_scatter_rows(const float* src, const int32_t* row_src, const int64_t* rows_dev, int64_t max_rows, int d,
+                        float* dst, hipStream_t stream) {
+  GDR_CHECK_ARG(d % 4 == 0, "scatter_rows: d %% 4 != 0");
+  if (max_rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(move_rows_kernel<true>, dim3((unsigned)((max_rows + 3) / 4)), dim3(256), 0, stream, src, row_src,
+                     max_rows, rows_dev, d / 4, dst);
+  GDR_CHECK_LAUNCH("scatter_rows");
+  return GDR_OK;
+}
+
+__global__ __launch_bounds__(256) void zero_dead_rows_kernel(float* __restrict__ x, const int32_t* __restrict__ seq_len,
+                                                             int64_t rows, int L, int d4) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int b = (int)(row / L), j = (int)(row - (int64_t)b * L);
+  if (j < seq_len[b]) return;
+  float4* o = reinterpret_cast<float4*>(x) + row * d4;
+  for (int c = threadIdx.x & 63; c < d4; c += 64) o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+int launch_zero_dead_rows(float* x, const int32_t* seq_len, int B, int L, int d, hipStream_t stream) {
+  GDR_CHECK_ARG(d % 4 == 0, "zero_dead_rows: d %% 4 != 0");
+  const int64_t rows = (int64_t)B * L;
+  if (rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(zero_dead_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, seq_len, rows, L, d / 4);
+  GDR_CHECK_LAUNCH("zero_dead_rows_kernel");
+  return GDR_OK;
+}
+
 // ------------------------------------------------------------------------------------------ norms
 __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
   union {
@@ -77,8 +214,10 @@ __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d)
 template <bool BF16OUT>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       float* __restrict__ y, int64_t rows, int d4, float eps,
-                                                      float* __restrict__ pooled, int pool_every) {
+                                                      float* __restrict__ pooled, int pool_every,
+                                                      const int64_t* __restrict__ rows_dev) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rows_dev) rows = *rows_dev;
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   const float4* xr = reinterpret_cast<const float4*>(x) + row * d4;
@@ -111,8 +250,18 @@ int launch_rmsnorm(const float* x, const float* w, float* y, int64_t rows, int d
   GDR_CHECK_ARG(d % 4 == 0, "rmsnorm: d %% 4 != 0");
   if (rows == 0) return GDR_OK;
   hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, y, rows, d / 4, eps,
-                     pooled, pool_every > 0 ? pool_every : 1);
+                     pooled, pool_every > 0 ? pool_every : 1, (const int64_t*)nullptr);
   GDR_CHECK_LAUNCH("rmsnorm_kernel");
+  return GDR_OK;
+}
+
+int launch_rmsnorm_dev(const float* x, const float* w, float* y, const int64_t* rows_dev, int64_t max_rows, int d, float eps,
+                       hipStream_t stream) {
+  GDR_CHECK_ARG(d % 4 == 0, "rmsnorm: d %% 4 != 0");
+  if (max_rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((unsigned)((max_rows + 3) / 4)), dim3(256), 0, stream, x, w, y, max_rows,
+                     d / 4, eps, (float*)nullptr, 1, rows_dev);
+  GDR_CHECK_LAUNCH("rmsnorm_kernel(dev rows)");
   return GDR_OK;
 }
 
@@ -120,7 +269,7 @@ int launch_rmsnorm_bf16(const float* x, const float* w, void* y_bf16, int64_t ro
   GDR_CHECK_ARG(d % 4 == 0, "rmsnorm: d %% 4 != 0");
   if (rows == 0) return GDR_OK;
   hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w,
-                     static_cast<float*>(y_bf16), rows, d / 4, eps, (float*)nullptr, 1);
+                     static_cast<float*>(y_bf16), rows, d / 4, eps, (float*)nullptr, 1, (const int64_t*)nullptr);
   GDR_CHECK_LAUNCH("rmsnorm_kernel<bf16>");
   return GDR_OK;
 }
@@ -474,7 +623,10 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
   float* RelB = Vs + Lr * DS;   // [2*LP]
   float* Mk = RelB + 2 * LP;    // [LP]
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-  const int L = a.Lk, tid = threadIdx.x;
+  const int L = a.seq_len ? a.seq_len[b] : a.Lk, tid = threadIdx.x;  // ragged: this sequence's own length
+  const int64_t qrow0 = a.seq_off ? a.seq_off[b] : (int64_t)b * a.q_bstride;
+  const int64_t krow0 = a.seq_off ? a.seq_off[b] : (int64_t)b * a.k_bstride;
+  const int64_t orow0 = a.seq_off ? a.seq_off[b] : (int64_t)b * a.o_bstride;
   for (int e = tid; e < 2 * LP; e += NTHR) {
     float v = 0.f;
     if (a.rel_bias) {
@@ -499,9 +651,9 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
   }
   for (int e = tid; e < L * (DK / 4); e += NTHR) {
     const int r = e >> 4, c = e & 15;
-    float4 q = *reinterpret_cast<const float4*>(a.q + ((int64_t)b * a.q_bstride + r) * a.ldq + h * DK + 4 * c);
-    const float4 k = *reinterpret_cast<const float4*>(a.k + ((int64_t)b * a.k_bstride + r) * a.ldk + h * DK + 4 * c);
-    const float4 v = *reinterpret_cast<const float4*>(a.v + ((int64_t)b * a.k_bstride + r) * a.ldv + h * DK + 4 * c);
+    float4 q = *reinterpret_cast<const float4*>(a.q + (qrow0 + r) * a.ldq + h * DK + 4 * c);
+    const float4 k = *reinterpret_cast<const float4*>(a.k + (krow0 + r) * a.ldk + h * DK + 4 * c);
+    const float4 v = *reinterpret_cast<const float4*>(a.v + (krow0 + r) * a.ldv + h * DK + 4 * c);
     q.x *= a.scale, q.y *= a.scale, q.z *= a.scale, q.w *= a.scale;
     *reinterpret_cast<float4*>(Qs + r * DS + 4 * c) = q;
     *reinterpret_cast<float4*>(Ks + r * DS + 4 * c) = k;
@@ -510,6 +662,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
   __syncthreads();
 
   const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, q4 = lane >> 4;
+  if (16 * w >= L) return;  // ragged: a query tile past this sequence's end (no barrier follows)
   f32x4_t st[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) st[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -573,7 +726,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
       }
     }
     if (i < L) {
-      const int64_t off = ((int64_t)b * a.o_bstride + i) * a.ldo + h * DK + 16 * dt + 4 * q4;
+      const int64_t off = (orow0 + i) * a.ldo + h * DK + 16 * dt + 4 * q4;
       const float4 ov = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
       if (a.out_bf16)
         *reinterpret_cast<uint2*>(static_cast<__bf16*>(a.out_bf16) + off) = pack_bf16x4(ov.x, ov.y, ov.z, ov.w);
@@ -687,12 +840,16 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     GDR_CHECK_LAUNCH("attention_decode_kernel");
     return GDR_OK;
   }
+  const bool packed = a.seq_off != nullptr;
+  GDR_CHECK_ARG(!packed || (a.seq_len && a.Lq == a.Lk && a.q_pos0 == 0 && !a.kv_rows && a.kv_group == 1 && !a.q_same_pos &&
+                            a.dk == 64 && a.ldo % 4 == 0),
+                "attention: the packed (ragged) form serves full self-attention with d_kv = 64 only");
   if (a.Lq == a.Lk && a.q_pos0 == 0 && !a.kv_rows && a.kv_group == 1 && !a.q_same_pos && a.dk == 64 && a.ldo % 4 == 0) {
     static const bool tiles16 = [] {
       const char* e = getenv("GDR_ATTN_MFMA16");  // A/B knob: 0 = 32x32x2 tiles
       return e ? atoi(e) != 0 : true;
     }();
-    if (tiles16) {
+    if (tiles16 || packed) {
       switch ((a.Lk + 15) / 16) {
         case 1: return launch_attention_mfma16<1>(a, stream);
         case 2: return launch_attention_mfma16<2>(a, stream);

@@ -60,9 +60,13 @@ class GDRModel:
     """T5ForConditionalGeneration of the reference (GDR config: decode_embedding=2, adaptor_efficient),
     inference only.  Construct from a reference-style state_dict (SURVEY Appendix C key names)."""
 
-    def __init__(self, cfg: GDRConfig, state_dict, device="cuda:0", with_decoder=True, trie=None):
+    def __init__(self, cfg: GDRConfig, state_dict, device="cuda:0", with_decoder=True, trie=None, ragged=False):
         """trie: optional codec.Trie — enables the NCI trie constraint of the reference's earlier
-        generation_utils_previous.py:714-729 (the shipped generate() ignores `decode_tree`)."""
+        generation_utils_previous.py:714-729 (the shipped generate() ignores `decode_tree`).
+        ragged: generate() skips the PAD rows of the encoder (gdr_t5_encoder_forward_ragged).  Decoded ids, scores and the
+        CLS rows are unchanged (cross-attention masks PAD keys, kept rows are bit-identical); only the PAD positions of the
+        `last_hidden_state` returned with output_encoder_embedding=True are zero instead of the reference's values there,
+        hence opt-in.  get_encoder() always computes every row."""
         self.config = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -71,6 +75,7 @@ class GDRModel:
         self.enc = ops.T5EncoderHandle(cfg, sd, self.device)
         self.dec = ops.T5DecoderHandle(cfg, sd, self.device) if with_decoder else None
         self.trie = ops.DeviceTrie(trie, self.device) if trie is not None else None
+        self.ragged = bool(ragged)
         self.training = False
 
     def eval(self):
@@ -118,7 +123,7 @@ class GDRModel:
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         input_ids, attention_mask = input_ids.to(self.device), attention_mask.to(self.device)
-        enc_h, _ = self.enc.forward(input_ids, attention_mask, want_pooled=False)
+        enc_h, _ = self.enc.forward(input_ids, attention_mask, want_pooled=False, ragged=self.ragged)
         ids, lens, scores = self.dec.generate(enc_h, attention_mask, num_beams, max_length, length_penalty,
                                               num_return_sequences, trie=self.trie)
         decoded, score_list = ops.finish_generate_output(ids, lens, scores, max_length)

@@ -236,7 +236,13 @@ class T5EncoderHandle:
                                                self.final_ln.data_ptr(), self._layers)
         self.ws = Workspace(device)
 
-    def forward(self, input_ids, attention_mask=None, want_pooled=True):
+    def forward(self, input_ids, attention_mask=None, want_pooled=True, want_hidden=True, ragged=False,
+                live_rows_hint=-1):
+        """Returns (last_hidden_state fp32[B,L,d] | None, pooled fp32[B,d] | None).
+        ragged=False: gdr_t5_encoder_forward — every row, PAD positions included, exactly as the reference computes them.
+        ragged=True : gdr_t5_encoder_forward_ragged — PAD rows are not computed (kept rows bit-identical, PAD rows of the
+        returned hidden states are zero); with want_hidden=False only h[:,0] is carried through the last block.
+        live_rows_hint: number of kept token rows if the caller knows it (profiler accounting only)."""
         _need_cuda(input_ids, attention_mask)
         ids = input_ids.to(torch.int64).contiguous()
         B, L = ids.shape
@@ -244,15 +250,28 @@ class T5EncoderHandle:
             attention_mask = torch.ones_like(ids)
         mask = attention_mask.to(torch.int64).contiguous()
         bf = self.dtype == torch.bfloat16
+        if not (want_hidden or want_pooled):
+            raise ValueError("T5EncoderHandle.forward: nothing requested")
+        d = self.cfg.d_model
+        pooled = torch.empty((B, d), dtype=torch.float32, device=ids.device) if want_pooled else None
+        if ragged:
+            if bf:
+                raise _ffi.GdrError("the ragged encoder form is fp32 only")
+            need = lib().gdr_t5_encoder_ragged_workspace_bytes(C.byref(self.dims), B, L)
+            ws = self.ws.get(need)
+            out = torch.empty((B, L, d), dtype=torch.float32, device=ids.device) if want_hidden else None
+            check(lib().gdr_t5_encoder_forward_ragged(C.byref(self.struct), ptr(ids), ptr(mask), B, L, ptr(out), ptr(pooled),
+                                                      int(live_rows_hint), ptr(ws), ws.numel(), stream_ptr()),
+                  "gdr_t5_encoder_forward_ragged")
+            return out, pooled
         need = (lib().gdr_t5_encoder_bf16_workspace_bytes if bf else lib().gdr_t5_encoder_workspace_bytes)(
             C.byref(self.dims), B, L)
         ws = self.ws.get(need)
-        out = torch.empty((B, L, self.cfg.d_model), dtype=torch.float32, device=ids.device)
-        pooled = torch.empty((B, self.cfg.d_model), dtype=torch.float32, device=ids.device) if want_pooled else None
+        out = torch.empty((B, L, d), dtype=torch.float32, device=ids.device)
         fn = lib().gdr_t5_encoder_forward_bf16 if bf else lib().gdr_t5_encoder_forward
         check(fn(C.byref(self.struct), ptr(ids), ptr(mask), B, L, ptr(out), ptr(pooled), ptr(ws), ws.numel(),
                  stream_ptr()), "gdr_t5_encoder_forward")
-        return out, pooled
+        return (out if want_hidden else None), pooled
 
 
 class BertEncoderHandle:

@@ -116,6 +116,25 @@ int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_t* ids, con
                            float* out_hidden, float* out_pooled, void* workspace, size_t workspace_bytes,
                            void* stream);
 
+/* Ragged form of the same forward: only the token rows that can reach the requested outputs are computed.
+ *   - PAD rows are dropped: a sequence whose mask row is a non-empty prefix of ones (right padding, what the reference's
+ *     tokenizer emits) keeps its first sum(mask) positions; any other mask row (empty, holes, left padding) keeps all L
+ *     positions and its mask, so every case the reference handles is still handled.  Kept rows are bit-identical to
+ *     gdr_t5_encoder_forward (GEMM rows are independent; a PAD key adds exp(-1e9 - max) = 0 to a live query's softmax).
+ *   - out_hidden (may be NULL): kept rows exact, dropped rows ZERO — they are not the reference's values there, which is
+ *     why model.get_encoder() / gdr_t5_encoder_forward stay the exact default; the decode path (cross-attention masks
+ *     those keys) and the CLS pool never read them.
+ *   - out_pooled (may be NULL; one of the two must be given) = hidden[:,0].  With out_hidden == NULL the last block's
+ *     o / wi / wo and the final norm run on the B CLS rows only.
+ *   - the live-row count is derived from the mask ON THE DEVICE; kernels read it, the call never synchronises.
+ *     live_rows_hint: that count if the host happens to know it, else -1 — read only by the opt-in profiler's flop
+ *     accounting (gdr_prof_*), never by the computation.
+ * Batches too small to fill the chip without split-K, or d_kv != 64, run the padded form internally (same outputs). */
+size_t gdr_t5_encoder_ragged_workspace_bytes(const GdrT5Dims* dims, int B, int L);
+int gdr_t5_encoder_forward_ragged(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L,
+                                  float* out_hidden, float* out_pooled, int64_t live_rows_hint, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
 /* bf16 precision mode (BASELINE config C5): the SAME structs, but the four linear weights of every layer (wqkv, wo, wi,
  * wo_ff) point to bf16 [N,K] matrices (round-to-nearest-even of the fp32 checkpoint, e.g. gdr_cast_f32_bf16); the
  * `const float*` field type is nominal for them.  Each linear rounds its activation operand to bf16 and accumulates in

@@ -187,7 +187,7 @@ def test_c4_shape_4096_queries_8_shards_packed_merge(dev):
     packs = []
     for r in range(G):
         lo, hi = shard_bounds(N, G, r, cluster_size=12)
-        assert 39996 <= hi - lo <= 40008
+        assert 39990 <= hi - lo <= 40008 and lo % 12 == 0
         v, i, st = ops.sim_topk(Qd, Dd[lo:hi], k, idx_offset=lo, workspace=ws, return_status=True)
         assert int(i.min()) >= lo and int(i.max()) < hi
         packs.append(ops.topk_pack(v, i, st))

@@ -368,10 +368,12 @@ def test_sim_topk_degenerate_corpus_overflow_is_detected_and_repaired(dev):
     D[12345] = base[1] * 3.0                                  # one doc that is not a duplicate
     Q, _ = synth.make_queries(base[:2], 3, seed=6)
     Qd, Dd = torch.from_numpy(Q).to(dev), torch.from_numpy(np.ascontiguousarray(D)).to(dev)
-    _, _, st = ops.sim_topk(Qd, Dd, 50, return_status=True)
+    _, _, st = ops.sim_topk(Qd, Dd, 50, return_status=True, exact_on_overflow=False)   # the no-sync form: status only
     assert int(st.sum().item()) == 3, "every query should report overflow"
-    v, i, st2 = ops.sim_topk(Qd, Dd, 50, return_status=True, exact_on_overflow=True)
+    v, i, st2 = ops.sim_topk(Qd, Dd, 50, return_status=True)                           # the default repairs
     assert int(st2.sum().item()) == 0
+    v3, i3 = ops.sim_topk(Qd, Dd, 50)
+    assert torch.equal(i3, i) and torch.equal(v3, v)
     s = Q @ D.T
     for b in range(3):
         order = np.lexsort((np.arange(D.shape[0]), -s[b]))[:50]
