@@ -50,6 +50,11 @@ class GdrTrie(C.Structure):
     _fields_ = [("child", C.c_void_p), ("eos_ok", C.c_void_p), ("n_nodes", C.c_int32), ("V", C.c_int32)]
 
 
+class GdrPrefixTable(C.Structure):
+    _fields_ = [("child", C.c_void_p), ("n_nodes", C.c_int32), ("V", C.c_int32), ("n_table", C.c_int32),
+                ("kv", C.c_void_p), ("W", C.c_void_p)]
+
+
 class GdrT5DecLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln_self", "wqkv", "wo", "ln_cross", "wq_c", "wkv_c", "wo_c", "ln_ff", "wi",
                                           "wo_ff")]
@@ -97,7 +102,10 @@ SIGNATURES = {
     "gdr_bert_encoder_forward": (_i, [C.POINTER(GdrBertWeights), _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "gdr_t5_generate_workspace_bytes": (_sz, [C.POINTER(GdrT5DecoderWeights), _i, _i, _i, _i]),
     "gdr_t5_generate": (_i, [C.POINTER(GdrT5DecoderWeights), _vp, _vp, _i, _i, _i, _i, C.c_double, _i, C.POINTER(GdrTrie),
-                             _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                             C.POINTER(GdrPrefixTable), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gdr_t5_prefix_table_workspace_bytes": (_sz, [C.POINTER(GdrT5DecoderWeights), _i]),
+    "gdr_t5_prefix_table_build": (_i, [C.POINTER(GdrT5DecoderWeights), _i, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp, _vp,
+                                       _sz, _vp]),
     "gdr_beam_search_table_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "gdr_beam_search_table": (_i, [_vp, _i, _i, _i, _i, C.c_double, _i, C.POINTER(GdrTrie), _vp, _vp, _vp, _vp, _sz,
                                    _vp]),

@@ -132,6 +132,34 @@ class Trie:
     def from_docids(docids, V):
         return Trie.from_sequences([encode_single_newid(s, kary=V) for s in docids], V)
 
+    def breadth_first(self):
+        """The same trie with nodes renumbered in breadth-first order (root = 0, every depth a contiguous id range — what
+        the device prefix table needs, gdr_hip.h GdrPrefixTable) plus its level structure:
+        (trie, level_off int32[n_levels+1], parent int32[n], tok int64[n]) where tok[node] is the token that leads to
+        the node (depth_of_parent*V + c + 2; root: START = 0)."""
+        V, n = self.V, self.child.shape[0]
+        order, parent, tok, level_off = [0], [-1], [0], [0, 1]
+        new_id = np.full(n, -1, dtype=np.int64)
+        new_id[0] = 0
+        lo, depth = 0, 0
+        while lo < len(order):
+            hi = len(order)
+            for pos in range(lo, hi):
+                kids = self.child[order[pos]]
+                for c in np.nonzero(kids >= 0)[0]:
+                    new_id[kids[c]] = len(order)
+                    order.append(int(kids[c]))
+                    parent.append(pos)
+                    tok.append(depth * V + int(c) + 2)
+            if len(order) > hi:
+                level_off.append(len(order))
+            lo, depth = hi, depth + 1
+        order = np.asarray(order)
+        child = self.child[order]
+        child = np.where(child >= 0, new_id[np.maximum(child, 0)], -1).astype(np.int32)
+        t = Trie(np.ascontiguousarray(child), np.ascontiguousarray(self.eos_ok[order]).astype(np.int32), V)
+        return t, np.asarray(level_off, np.int32), np.asarray(parent, np.int32), np.asarray(tok, np.int64)
+
 
 # ------------------------------------------------------------------------------------------ metrics / res1 TSV
 def write_res1(path, rows):

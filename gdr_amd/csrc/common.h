@@ -65,6 +65,12 @@ int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, 
 int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                          int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
                          float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream);
+// Decode-time linear over a device-side row count (*m_dev <= M_max live rows; grids sized for M_max): the same kernel
+// choice as launch_linear_f32_ws makes for M_max — small-tile / split-K forms included, so its results for a row equal
+// what launch_linear_f32_ws(M = M_max) gives that row.
+int launch_linear_f32_ws_dev(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M_max,
+                             const int64_t* m_dev, int N, int K, int epilogue, const float* bias, const float* residual,
+                             int64_t ldr, float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream);
 int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M_max,
                           const int64_t* m_dev, int N, int K, int epilogue, const float* bias, const float* residual,
                           int64_t ldr, int64_t prof_rows, hipStream_t stream);
@@ -76,7 +82,7 @@ int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, f
                        int K, int epilogue, const float* bias, const float* residual, int64_t ldr, hipStream_t stream);
 int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
-                            int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream);
+                            int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev = nullptr);
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, int out_bf16, hipStream_t stream);

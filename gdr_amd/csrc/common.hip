@@ -116,4 +116,4 @@ extern "C" int gdr_prof_collect(int64_t* launches, double* total_ms, double* tot
 }
 
 extern "C" const char* gdr_last_error(void) { return gdr::g_err; }
-extern "C" int gdr_abi_version(void) { return 1; }
+extern "C" int gdr_abi_version(void) { return 2; }  // 2: gdr_t5_generate takes a GdrPrefixTable; GdrTrie carries V

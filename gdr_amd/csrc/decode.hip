@@ -15,6 +15,11 @@
 //     slice [V+1][d][d] and a fused dot kernel; masked columns are exactly -1e9 either way.
 //   * beam bookkeeping (top-2R, EOS handling, BeamHypotheses.add/is_done, finalisation) runs in three small
 //     kernels per step with no host round trip; the reference syncs per candidate through .item().
+//   * the adaptor chain and the head matrix W = adaptor_linear(adaptor(prefix)) + lm_head depend on the TOKEN PREFIX
+//     only, never on the query (modeling_t5.py:1618-1639): with a GdrPrefixTable — built once from the weights and the
+//     corpus' docid trie (gdr_t5_prefix_table_build) — a row whose prefix is a trie node reads its head matrix (and,
+//     for its descendants, its adaptor K/V) from the table; only rows whose prefix left the trie are compacted and run
+//     through the adaptor + head GEMM (device-side row count, no host round trip).
 #include <math.h>
 
 #include <mutex>
@@ -36,6 +41,10 @@ struct BeamBufs {
   int32_t* anc[2];      // [rows][maxlen] row whose cache slot holds position p of this row's prefix
   int32_t* kv_rows;     // [rows][s+1] absolute cache row = p*rows + anc
   int32_t* node[2];     // [rows] trie node reached by the row's prefix (-1: left the tree), double buffered
+  int32_t* miss_rows;   // [rows] prefix-table mode: rows whose prefix has no table entry, compacted (ascending)
+  int32_t* miss_index;  // [rows] inverse: position of a row in miss_rows, or -1 when its prefix hit the table
+  int32_t* kv_rows_c;   // [rows][maxlen] kv_rows of the compacted rows
+  int64_t* n_miss;      // [1] number of compacted rows (read by the kernels of the adaptor chain)
   float* logits;        // [rows][V+1] unmasked-column logits of the step
   float* cand_score;    // [B][2R]
   int32_t* cand_idx;    // [B][2R]  beam*Vd + token
@@ -52,8 +61,9 @@ struct BeamBufs {
 struct BeamDims {
   int B, R, V, Vd, maxlen, nret;
   double lp;
-  // optional trie constraint (generation_utils_previous.py:714-729): child[node*V + c] = next node or -1 for the digit
-  // c of the node's depth, eos_ok[node] = 1 if EOS is a child.  null = the shipped behaviour (positional mask only).
+  // docid trie: child[node*V + c] = next node or -1 for the digit c of the node's depth.  trie_child alone = rows only
+  // TRACK the node their prefix reaches (prefix-table mode); with trie_eos (eos_ok[node] = 1 if EOS is a child) the
+  // trie also CONSTRAINS the beams (generation_utils_previous.py:714-729).  Both null = the shipped behaviour.
   const int32_t* trie_child;
   const int32_t* trie_eos;
   int trie_nodes;
@@ -83,6 +93,10 @@ static size_t beam_layout(const BeamDims& bd, char* base, BeamBufs* bb) {
   CARVE(kv_rows, int32_t, rows * ml);
   CARVE(node[0], int32_t, rows);
   CARVE(node[1], int32_t, rows);
+  CARVE(miss_rows, int32_t, rows);
+  CARVE(miss_index, int32_t, rows);
+  CARVE(kv_rows_c, int32_t, rows * ml);
+  CARVE(n_miss, int64_t, 1);
   CARVE(logits, float, rows * V1);
   CARVE(cand_score, float, (size_t)bd.B * 2 * bd.R);
   CARVE(cand_idx, int32_t, (size_t)bd.B * 2 * bd.R);
@@ -149,6 +163,128 @@ __global__ __launch_bounds__(256) void head_logits_kernel(const float* __restric
   if (lane == 0) logits[item] = acc;
 }
 
+// Prefix-table form of the same dot: a row whose prefix is a table node reads its finished head matrix
+// W[node][c][i] = A + E (built at load); any other row reads the A computed this step for its compacted slot.
+__global__ __launch_bounds__(256) void head_logits_table_kernel(const float* __restrict__ h, const float* __restrict__ A_c,
+                                                                const float* __restrict__ E, const float* __restrict__ tabW,
+                                                                const int32_t* __restrict__ node,
+                                                                const int32_t* __restrict__ miss_index, int n_table,
+                                                                int rows, int V1, int d, float scale,
+                                                                float* __restrict__ logits) {
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (int64_t)rows * V1) return;
+  const int r = (int)(item / V1), c = (int)(item % V1), lane = threadIdx.x & 63;
+  const float4* h4 = reinterpret_cast<const float4*>(h + (size_t)r * d);
+  const int mi = miss_index[r];
+  float acc = 0.f;
+  if (mi < 0) {
+    const float4* w4 = reinterpret_cast<const float4*>(tabW + ((size_t)node[r] * V1 + c) * d);
+    for (int i = lane; i < d / 4; i += 64) {
+      const float4 hv = h4[i], wv = w4[i];
+      acc = fmaf(hv.x * scale, wv.x, acc);
+      acc = fmaf(hv.y * scale, wv.y, acc);
+      acc = fmaf(hv.z * scale, wv.z, acc);
+      acc = fmaf(hv.w * scale, wv.w, acc);
+    }
+  } else {
+    const float4* a4 = reinterpret_cast<const float4*>(A_c + ((size_t)mi * V1 + c) * d);
+    const float4* e4 = reinterpret_cast<const float4*>(E + (size_t)c * d);
+    for (int i = lane; i < d / 4; i += 64) {
+      const float4 hv = h4[i], av = a4[i], ev = e4[i];
+      acc = fmaf(hv.x * scale, av.x + ev.x, acc);
+      acc = fmaf(hv.y * scale, av.y + ev.y, acc);
+      acc = fmaf(hv.z * scale, av.z + ev.z, acc);
+      acc = fmaf(hv.w * scale, av.w + ev.w, acc);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) logits[item] = acc;
+  (void)n_table;
+}
+
+// Prefix-table mode, once per step (one workgroup): which rows have a table entry for their prefix?  The others are
+// compacted in ascending row order (deterministic) together with their ancestor rows; *n_miss is what every kernel of
+// the adaptor chain reads as its row count.
+__global__ __launch_bounds__(1024) void prefix_plan_kernel(BeamBufs bb, int rows, int stride, int cur, int n_table) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < rows; base += 1024) {
+    const int r = base + tid;
+    int nd = -1;
+    if (r < rows) nd = bb.node[cur][r];
+    const int miss = (r < rows && !(nd >= 0 && nd < n_table)) ? 1 : 0;
+    int inc = miss;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    const int pos = before + inc - miss;
+    if (r < rows) {
+      bb.miss_index[r] = miss ? pos : -1;
+      if (miss) bb.miss_rows[pos] = r;
+    }
+    __syncthreads();
+    if (tid == 1023) carry = before + inc;
+    __syncthreads();
+  }
+  if (tid == 0) *bb.n_miss = carry;
+  (void)stride;
+}
+
+// kv_rows_c[i][p] = kv_rows[miss_rows[i]][p]; hit rows: the table's (q,k,v) of the node -> this step's slot of every
+// adaptor layer's cache, so that a descendant that later leaves the trie finds its ancestors' K/V where it looks.
+__global__ __launch_bounds__(256) void prefix_fill_kernel(BeamBufs bb, int rows, int stride, int cur,
+                                                          const float* __restrict__ tab_kv, int64_t tab_layer_stride,
+                                                          float* __restrict__ acache_slot, int64_t cache_layer_stride,
+                                                          int n_layers, int d3) {
+  const int r = blockIdx.x;
+  const int mi = bb.miss_index[r];
+  if (mi >= 0) {
+    for (int p = threadIdx.x; p < stride; p += 256) bb.kv_rows_c[(size_t)mi * stride + p] = bb.kv_rows[(size_t)r * stride + p];
+    return;
+  }
+  const int nd = bb.node[cur][r];
+  const int n4 = d3 >> 2;
+  for (int l = 0; l < n_layers; ++l) {
+    const float4* src = reinterpret_cast<const float4*>(tab_kv + l * tab_layer_stride + (size_t)nd * d3);
+    float4* dst = reinterpret_cast<float4*>(acache_slot + l * cache_layer_stride + (size_t)r * d3);
+    for (int c = threadIdx.x; c < n4; c += 256) dst[c] = src[c];
+  }
+}
+
+// out[i] = table[tok[rows_map[i]]] for i < *n_dev
+__global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ tok,
+                                                         const int32_t* __restrict__ rows_map,
+                                                         const int64_t* __restrict__ n_dev, int d4, int vocab,
+                                                         float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= *n_dev) return;
+  int64_t id = tok[rows_map[i]];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float4* src = reinterpret_cast<const float4*>(table) + id * d4;
+  float4* dst = reinterpret_cast<float4*>(out) + i * d4;
+  for (int c = threadIdx.x & 63; c < d4; c += 64) dst[c] = src[c];
+}
+
+// slot[rows_map[i]] = src[i] (rows of d3 floats), i < *n_dev: the compacted (q,k,v) of this step into the cache slot
+__global__ __launch_bounds__(256) void scatter_slot_kernel(const float* __restrict__ src, const int32_t* __restrict__ rows_map,
+                                                           const int64_t* __restrict__ n_dev, int n4,
+                                                           float* __restrict__ slot) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= *n_dev) return;
+  const float4* s4 = reinterpret_cast<const float4*>(src) + i * n4;
+  float4* d4 = reinterpret_cast<float4*>(slot) + (int64_t)rows_map[i] * n4;
+  for (int c = threadIdx.x & 63; c < n4; c += 64) d4[c] = s4[c];
+}
+
 // Teacher forcing: logits[r][c] = table[b][pos][last_token][token(pos,c)]
 __global__ void table_logits_kernel(const float* __restrict__ table, const int64_t* __restrict__ cur_tok, int rows,
                                     int R, int V, int Vd, int maxlen, int pos, float* __restrict__ logits) {
@@ -191,7 +327,7 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims b
       const int j = e / V1, c = e - j * V1;
       const float logp = (bb.logits[((size_t)b * R + j) * V1 + c] - lse_max[j]) - lse_log[j];
       float s = logp + bb.beam_scores[(size_t)b * R + j];
-      if (bd.trie_child) {  // scores += mask(-inf on tokens that are not children of the prefix' node)
+      if (bd.trie_eos) {  // scores += mask(-inf on tokens that are not children of the prefix' node)
         const int nd = bb.node[cur][(size_t)b * R + j];
         const bool ok = c < bd.V ? (nd >= 0 && bd.trie_child[(size_t)nd * bd.V + c] >= 0) : (nd < 0 || bd.trie_eos[nd] != 0);
         if (!ok) s = -INFINITY;
@@ -554,7 +690,7 @@ struct SideLease {
 
 // ------------------------------------------------------------------------------------------ model workspace
 struct GenWs {
-  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, total;
+  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, total;
 };
 
 static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
@@ -581,6 +717,7 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
   g.ctx2 = carve(o, 4 * rows * d);                       // adaptor chain runs on a side stream: own scratch
   g.ff2 = carve(o, 4 * rows * (size_t)w.adaptor_ff);
   g.splitk2 = carve(o, SPLITK_WS_BYTES);
+  g.qkv_c = carve(o, 4 * rows * 3 * d);                 // prefix-table mode: (q,k,v) of the compacted rows
   g.total = o;
   return g;
 }
@@ -596,18 +733,25 @@ extern "C" size_t gdr_t5_generate_workspace_bytes(const GdrT5DecoderWeights* w, 
 
 extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B,
                                int L, int num_beams, int max_length, double length_penalty,
-                               int num_return_sequences, const GdrTrie* trie, int64_t* out_ids, int32_t* out_len,
-                               double* out_scores, float* step_scores, int32_t* step_tokens, void* workspace,
-                               size_t workspace_bytes, void* stream_) {
+                               int num_return_sequences, const GdrTrie* trie, const GdrPrefixTable* ptab,
+                               int64_t* out_ids, int32_t* out_len, double* out_scores, float* step_scores,
+                               int32_t* step_tokens, void* workspace, size_t workspace_bytes, void* stream_) {
   using namespace gdr;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   GDR_CHECK_ARG(w && enc_hidden && enc_mask && out_ids && out_len && out_scores && workspace, "generate: null pointer");
   const GdrT5Dims& dm = w->dims;
-  BeamDims bd{B, num_beams, w->out_vocab, dm.vocab_size, max_length, num_return_sequences, length_penalty,
-              trie ? trie->child : nullptr, trie ? trie->eos_ok : nullptr, trie ? trie->n_nodes : 0};
   GDR_CHECK_ARG(!trie || (trie->child && trie->eos_ok && trie->n_nodes > 0), "generate: bad trie");
   GDR_CHECK_ARG(!trie || trie->V == w->out_vocab, "generate: trie built for V=%d but the head has output_vocab_size=%d",
                 trie ? trie->V : 0, w->out_vocab);
+  GDR_CHECK_ARG(!ptab || (ptab->child && ptab->kv && ptab->W && ptab->n_nodes > 0 && ptab->n_table > 0 &&
+                          ptab->n_table <= ptab->n_nodes && ptab->V == w->out_vocab),
+                "generate: bad prefix table (V=%d, head output_vocab_size=%d)", ptab ? ptab->V : 0, w->out_vocab);
+  GDR_CHECK_ARG(!ptab || !trie || (trie->child == ptab->child && trie->n_nodes == ptab->n_nodes),
+                "generate: the trie constraint and the prefix table must be built over the same trie arrays");
+  GDR_CHECK_ARG(!ptab || (dm.d_model % 32 == 0 && w->adaptor_ff % 32 == 0), "generate: prefix-table mode needs d %% 32 == 0");
+  BeamDims bd{B, num_beams, w->out_vocab, dm.vocab_size, max_length, num_return_sequences, length_penalty,
+              trie ? trie->child : (ptab ? ptab->child : nullptr), trie ? trie->eos_ok : nullptr,
+              trie ? trie->n_nodes : (ptab ? ptab->n_nodes : 0)};
   int rc = check_beam_dims(bd, max_length);
   if (rc) return rc;
   GDR_CHECK_ARG(L >= 1 && L <= 128, "generate: L=%d must be in [1,128]", L);
@@ -631,7 +775,7 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
   float *dcache = F(g.dcache), *acache = F(g.acache), *crosskv = F(g.crosskv), *xd = F(g.xd), *xa = F(g.xa),
         *nx = F(g.nx), *ctx = F(g.ctx), *qc = F(g.qc), *ff = F(g.ff), *tmp = F(g.tmp), *A = F(g.A), *hl = F(g.hl),
-        *skw = F(g.splitk), *ctx2 = F(g.ctx2), *ff2 = F(g.ff2), *skw2 = F(g.splitk2);
+        *skw = F(g.splitk), *ctx2 = F(g.ctx2), *ff2 = F(g.ff2), *skw2 = F(g.splitk2), *qkv_c = F(g.qkv_c);
   const int d = dm.d_model, H = dm.num_heads, dk = dm.d_kv, inner = H * dk;
   const int rows = B * num_beams, V1 = bd.V + 1;
   const int aH = w->adaptor_nhead, ahd = d / aH, aff = w->adaptor_ff;
@@ -668,29 +812,73 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
         return GDR_EHIP;
       }
     }
-    GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows, d, dm.vocab_size, xa, as));
-    // ---------------- adaptor: post-LN nn.TransformerDecoder over decode_embeddings(ids) (modeling_t5.py:1615-1633)
-    for (int l = 0; l < w->adaptor_layers; ++l) {
-      const GdrAdaptorLayer& al = w->alayers[l];
-      float* cache = acache + l * alayer;
-      float* slot = cache + s * aslab;
-      GDR_TRY(LIN2(xa, d, al.in_w, d, slot, 3 * d, rows, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0));
-      AttnArgs at{};
-      at.q = slot, at.k = cache + d, at.v = cache + 2 * d, at.out = ctx2;
-      at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
-      at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
-      at.B = rows, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
-      at.scale = 1.0f / sqrtf((float)ahd);
-      at.rel_bias = nullptr, at.bidirectional = 0, at.num_buckets = 0, at.lut = lut_uni;
-      at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
-      at.kv_rows = bb.kv_rows, at.kv_group = 1;
-      GDR_TRY(launch_attention(at, as));
-      GDR_TRY(LIN2(ctx2, d, al.out_w, d, tmp, d, rows, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d));
-      GDR_TRY(launch_layernorm(tmp, al.ln1_w, al.ln1_b, xa, rows, d, w->adaptor_eps, nullptr, as));
-      GDR_TRY(launch_layernorm(xa, al.ln2_w, al.ln2_b, tmp, rows, d, w->adaptor_eps, al.cross_const, as));
-      GDR_TRY(LIN2(tmp, d, al.lin1_w, d, ff2, aff, rows, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
-      GDR_TRY(LIN2(ff2, aff, al.lin2_w, aff, xa, d, rows, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d));
-      GDR_TRY(launch_layernorm(xa, al.ln3_w, al.ln3_b, xa, rows, d, w->adaptor_eps, nullptr, as));
+    if (!ptab) {
+      GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows, d, dm.vocab_size, xa, as));
+      // ---------------- adaptor: post-LN nn.TransformerDecoder over decode_embeddings(ids) (modeling_t5.py:1615-1633)
+      for (int l = 0; l < w->adaptor_layers; ++l) {
+        const GdrAdaptorLayer& al = w->alayers[l];
+        float* cache = acache + l * alayer;
+        float* slot = cache + s * aslab;
+        GDR_TRY(LIN2(xa, d, al.in_w, d, slot, 3 * d, rows, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0));
+        AttnArgs at{};
+        at.q = slot, at.k = cache + d, at.v = cache + 2 * d, at.out = ctx2;
+        at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
+        at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
+        at.B = rows, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
+        at.scale = 1.0f / sqrtf((float)ahd);
+        at.rel_bias = nullptr, at.bidirectional = 0, at.num_buckets = 0, at.lut = lut_uni;
+        at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
+        at.kv_rows = bb.kv_rows, at.kv_group = 1;
+        GDR_TRY(launch_attention(at, as));
+        GDR_TRY(LIN2(ctx2, d, al.out_w, d, tmp, d, rows, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d));
+        GDR_TRY(launch_layernorm(tmp, al.ln1_w, al.ln1_b, xa, rows, d, w->adaptor_eps, nullptr, as));
+        GDR_TRY(launch_layernorm(xa, al.ln2_w, al.ln2_b, tmp, rows, d, w->adaptor_eps, al.cross_const, as));
+        GDR_TRY(LIN2(tmp, d, al.lin1_w, d, ff2, aff, rows, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
+        GDR_TRY(LIN2(ff2, aff, al.lin2_w, aff, xa, d, rows, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d));
+        GDR_TRY(launch_layernorm(xa, al.ln3_w, al.ln3_b, xa, rows, d, w->adaptor_eps, nullptr, as));
+      }
+    } else {
+      // ---------------- prefix-table mode: rows whose prefix is a table node take everything from the table; the rest
+      // are compacted (row count *bb.n_miss lives on the device) and run the same chain + the head GEMM on `as`
+      const int64_t* nm = bb.n_miss;
+      hipLaunchKernelGGL(prefix_plan_kernel, dim3(1), dim3(1024), 0, as, bb, rows, s + 1, cur, ptab->n_table);
+      GDR_CHECK_LAUNCH("prefix_plan_kernel");
+      hipLaunchKernelGGL(prefix_fill_kernel, dim3(rows), dim3(256), 0, as, bb, rows, s + 1, cur, ptab->kv,
+                         (int64_t)ptab->n_table * 3 * d, acache + s * aslab, (int64_t)alayer, w->adaptor_layers, 3 * d);
+      GDR_CHECK_LAUNCH("prefix_fill_kernel");
+      hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as, w->dec_embed, bb.cur_tok,
+                         bb.miss_rows, nm, d / 4, dm.vocab_size, xa);
+      GDR_CHECK_LAUNCH("embed_rows_kernel");
+#define LIN2D(A_, lda_, W_, ldw_, C_, ldc_, N_, K_, epi_, bias_, res_, ldr_) \
+  launch_linear_f32_ws_dev(A_, lda_, W_, ldw_, C_, ldc_, rows, nm, N_, K_, epi_, bias_, res_, ldr_, skw2, SPLITK_WS_BYTES, as)
+      for (int l = 0; l < w->adaptor_layers; ++l) {
+        const GdrAdaptorLayer& al = w->alayers[l];
+        float* cache = acache + l * alayer;
+        float* slot = cache + s * aslab;
+        GDR_TRY(LIN2D(xa, d, al.in_w, d, qkv_c, 3 * d, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0));
+        hipLaunchKernelGGL(scatter_slot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as, qkv_c, bb.miss_rows, nm,
+                           3 * d / 4, slot);
+        GDR_CHECK_LAUNCH("scatter_slot_kernel");
+        AttnArgs at{};
+        at.q = qkv_c, at.k = cache + d, at.v = cache + 2 * d, at.out = ctx2;
+        at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
+        at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
+        at.B = rows, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
+        at.scale = 1.0f / sqrtf((float)ahd);
+        at.rel_bias = nullptr, at.bidirectional = 0, at.num_buckets = 0, at.lut = lut_uni;
+        at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
+        at.kv_rows = bb.kv_rows_c, at.kv_group = 1, at.b_count_dev = nm;
+        GDR_TRY(launch_attention(at, as));
+        GDR_TRY(LIN2D(ctx2, d, al.out_w, d, tmp, d, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d));
+        GDR_TRY(launch_layernorm_dev(tmp, al.ln1_w, al.ln1_b, xa, nm, rows, d, w->adaptor_eps, nullptr, as));
+        GDR_TRY(launch_layernorm_dev(xa, al.ln2_w, al.ln2_b, tmp, nm, rows, d, w->adaptor_eps, al.cross_const, as));
+        GDR_TRY(LIN2D(tmp, d, al.lin1_w, d, ff2, aff, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
+        GDR_TRY(LIN2D(ff2, aff, al.lin2_w, aff, xa, d, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d));
+        GDR_TRY(launch_layernorm_dev(xa, al.ln3_w, al.ln3_b, xa, nm, rows, d, w->adaptor_eps, nullptr, as));
+      }
+      // the head GEMM of the compacted rows belongs to the same chain (it needs nothing from the decoder stack)
+      GDR_TRY(LIN2D(xa, d, w->head_w + (size_t)s * V1 * d * d, d, A, (int64_t)V1 * d, V1 * d, d, GDR_EPI_NONE, nullptr, nullptr, 0));
+#undef LIN2D
     }
     if (ss.ok) {
       if (hipEventRecord(ss.join, ss.s) != hipSuccess) {
@@ -743,12 +931,17 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
     // ---------------- head: last position, unmasked columns only (modeling_t5.py:1634-1646)
     const float* hw = w->head_w + (size_t)s * V1 * d * d;
     const float* he = w->head_e + (size_t)s * V1 * d;
-    GDR_TRY(LIN(xa, d, hw, d, A, (int64_t)V1 * d, rows, V1 * d, d, GDR_EPI_NONE, nullptr, nullptr, 0));
-    {
+    if (!ptab) {
+      GDR_TRY(LIN(xa, d, hw, d, A, (int64_t)V1 * d, rows, V1 * d, d, GDR_EPI_NONE, nullptr, nullptr, 0));
       const int64_t items = (int64_t)rows * V1;
       hipLaunchKernelGGL(head_logits_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, hl, A, he, rows, V1, d,
                          1.0f / sqrtf((float)d), bb.logits);
       GDR_CHECK_LAUNCH("head_logits_kernel");
+    } else {
+      const int64_t items = (int64_t)rows * V1;
+      hipLaunchKernelGGL(head_logits_table_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, hl, A, he, ptab->W,
+                         bb.node[cur], bb.miss_index, ptab->n_table, rows, V1, d, 1.0f / sqrtf((float)d), bb.logits);
+      GDR_CHECK_LAUNCH("head_logits_table_kernel");
     }
     GDR_TRY(beam_step(bb, bd, s, cur, step_scores, step_tokens, stream));
     cur ^= 1;
@@ -757,6 +950,105 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
 #undef GDR_TRY
 #undef LIN
 #undef LIN2
+}
+
+// ------------------------------------------------------------------------------------------------ prefix table build
+// Level by level over the trie (nodes in breadth-first order, so a level is a contiguous row range and the GEMMs write
+// straight into the table): the adaptor chain of every node of depth s attends over the node's ancestors, whose (q,k,v)
+// rows of every layer are already in the table; the head GEMM with the level's slice of adaptor_linear and lm_head as
+// bias gives W[node] = A + E.  Same arithmetic as the in-call chain of gdr_t5_generate, at corpus scale.
+namespace gdr {
+struct TabWs {
+  size_t xa, tmp, ctx, ff, splitk, total;
+};
+static TabWs tab_ws(const GdrT5DecoderWeights& w, int max_level_nodes) {
+  TabWs t{};
+  const size_t n = (size_t)max_level_nodes, d = w.dims.d_model;
+  size_t o = 0;
+  t.xa = carve(o, 4 * n * d);
+  t.tmp = carve(o, 4 * n * d);
+  t.ctx = carve(o, 4 * n * d);
+  t.ff = carve(o, 4 * n * (size_t)w.adaptor_ff);
+  t.splitk = carve(o, SPLITK_WS_BYTES);
+  t.total = o;
+  return t;
+}
+}  // namespace gdr
+
+extern "C" size_t gdr_t5_prefix_table_workspace_bytes(const GdrT5DecoderWeights* w, int max_level_nodes) {
+  if (!w || max_level_nodes <= 0) return 0;
+  return gdr::tab_ws(*w, max_level_nodes).total;
+}
+
+extern "C" int gdr_t5_prefix_table_build(const GdrT5DecoderWeights* w, int n_levels, const int32_t* level_off,
+                                         const int64_t* node_tok, const int32_t* node_anc, float* kv, float* W,
+                                         void* workspace, size_t workspace_bytes, void* stream_) {
+  using namespace gdr;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GDR_CHECK_ARG(w && level_off && node_tok && node_anc && kv && W && workspace, "prefix_table_build: null pointer");
+  const GdrT5Dims& dm = w->dims;
+  GDR_CHECK_ARG(n_levels >= 1 && n_levels <= w->max_out_len - 1 && n_levels <= MAXLEN_CAP,
+                "prefix_table_build: n_levels=%d must be in [1, max_output_length - 1 = %d]", n_levels, w->max_out_len - 1);
+  GDR_CHECK_ARG(level_off[0] == 0 && level_off[1] == 1, "prefix_table_build: level 0 must be the root alone");
+  const int d = dm.d_model, V1 = w->out_vocab + 1, aH = w->adaptor_nhead, ahd = d / aH, aff = w->adaptor_ff;
+  GDR_CHECK_ARG(d % 4 == 0 && d % aH == 0 && ahd % 4 == 0, "prefix_table_build: unsupported dims");
+  int max_n = 0;
+  for (int s = 0; s < n_levels; ++s) {
+    GDR_CHECK_ARG(level_off[s + 1] > level_off[s], "prefix_table_build: empty level %d", s);
+    max_n = level_off[s + 1] - level_off[s] > max_n ? level_off[s + 1] - level_off[s] : max_n;
+  }
+  const TabWs t = tab_ws(*w, max_n);
+  if (workspace_bytes < t.total) {
+    set_error("prefix_table_build: workspace %zu < required %zu", workspace_bytes, t.total);
+    return GDR_ENOSPC;
+  }
+  GDR_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "prefix_table_build: workspace must be 256-byte aligned");
+  char* base = static_cast<char*>(workspace);
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+  float *xa = F(t.xa), *tmp = F(t.tmp), *ctx = F(t.ctx), *ff = F(t.ff), *skw = F(t.splitk);
+  const int64_t n_table = level_off[n_levels];
+  const size_t layer_stride = (size_t)n_table * 3 * d;
+  const BucketLut lut = make_bucket_lut(dm.rel_buckets, dm.rel_max_distance);
+  int rc;
+#define TLIN(...) launch_linear_f32_ws(__VA_ARGS__, skw, SPLITK_WS_BYTES, stream)
+#define T_TRY(x)              \
+  do {                        \
+    if ((rc = (x))) return rc; \
+  } while (0)
+  size_t anc_off = 0;  // level s block of node_anc: [n_s][s + 1]
+  for (int s = 0; s < n_levels; ++s) {
+    const int lo = level_off[s], n = level_off[s + 1] - lo;
+    T_TRY(launch_embed(w->dec_embed, node_tok + lo, n, d, dm.vocab_size, xa, stream));
+    for (int l = 0; l < w->adaptor_layers; ++l) {
+      const GdrAdaptorLayer& al = w->alayers[l];
+      float* tab = kv + l * layer_stride;       // [n_table][3d] of this layer
+      float* slot = tab + (size_t)lo * 3 * d;   // this level's rows
+      T_TRY(TLIN(xa, d, al.in_w, d, slot, 3 * d, n, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0));
+      AttnArgs at{};
+      at.q = slot, at.k = tab + d, at.v = tab + 2 * d, at.out = ctx;
+      at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
+      at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
+      at.B = n, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
+      at.scale = 1.0f / sqrtf((float)ahd);
+      at.rel_bias = nullptr, at.bidirectional = 0, at.num_buckets = 0, at.lut = lut;
+      at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
+      at.kv_rows = node_anc + anc_off, at.kv_group = 1;
+      T_TRY(launch_attention(at, stream));
+      T_TRY(TLIN(ctx, d, al.out_w, d, tmp, d, n, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d));
+      T_TRY(launch_layernorm(tmp, al.ln1_w, al.ln1_b, xa, n, d, w->adaptor_eps, nullptr, stream));
+      T_TRY(launch_layernorm(xa, al.ln2_w, al.ln2_b, tmp, n, d, w->adaptor_eps, al.cross_const, stream));
+      T_TRY(TLIN(tmp, d, al.lin1_w, d, ff, aff, n, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
+      T_TRY(TLIN(ff, aff, al.lin2_w, aff, xa, d, n, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d));
+      T_TRY(launch_layernorm(xa, al.ln3_w, al.ln3_b, xa, n, d, w->adaptor_eps, nullptr, stream));
+    }
+    // W[node][c][i] = sum_k xa[node][k] * head_w[s][c][i][k] + head_e[s][c][i]      (modeling_t5.py:1634-1639)
+    T_TRY(TLIN(xa, d, w->head_w + (size_t)s * V1 * d * d, d, W + (size_t)lo * V1 * d, (int64_t)V1 * d, n, V1 * d, d, GDR_EPI_BIAS,
+               w->head_e + (size_t)s * V1 * d, nullptr, 0));
+    anc_off += (size_t)n * (s + 1);
+  }
+#undef TLIN
+#undef T_TRY
+  return GDR_OK;
 }
 
 extern "C" size_t gdr_beam_search_table_workspace_bytes(int B, int num_beams, int max_length, int out_vocab) {

@@ -677,6 +677,31 @@ int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, 
 
 // With a scratch buffer, linears whose tile grid cannot fill the chip (decode: M = batch*beams rows) are split
 // along K into partial slabs + a fixed-order reduction that applies the epilogue.
+int launch_linear_f32_ws_dev(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M_max,
+                             const int64_t* m_dev, int N, int K, int epilogue, const float* bias, const float* residual,
+                             int64_t ldr, float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream) {
+  if (M_max == 0) return GDR_OK;
+  GDR_CHECK_ARG(m_dev, "linear(dev rows): null row count");
+  const int64_t tiles = ((M_max + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if (tiles < 192 && M_max <= 1536 && K / BK >= 4 && K % BK == 0) {  // the small-tile form, as launch_linear_f32_ws picks it
+    GDR_CHECK_ARG(A && W && C, "linear(dev rows): null pointer");
+    GDR_CHECK_ARG(epilogue >= GDR_EPI_NONE && epilogue <= GDR_EPI_BIAS_GELU, "linear(dev rows): unknown epilogue %d", epilogue);
+    GDR_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= K && ldc >= N && aligned16(A) && aligned16(W),
+                  "linear(dev rows): bad leading dimension / alignment");
+    const bool nb = epilogue == GDR_EPI_BIAS || epilogue == GDR_EPI_BIAS_RELU || epilogue == GDR_EPI_BIAS_RESIDUAL ||
+                    epilogue == GDR_EPI_BIAS_GELU;
+    const bool nr = epilogue == GDR_EPI_RESIDUAL || epilogue == GDR_EPI_BIAS_RESIDUAL;
+    GDR_CHECK_ARG((!nb || bias) && (!nr || (residual && ldr >= N)), "linear(dev rows): epilogue %d lacks an operand", epilogue);
+    const int act = (epilogue == GDR_EPI_RELU || epilogue == GDR_EPI_BIAS_RELU) ? ACT_RELU
+                    : epilogue == GDR_EPI_BIAS_GELU                             ? ACT_GELU
+                                                                                : ACT_NONE;
+    const int rc = launch_linear_f32_small(A, lda, W, ldw, C, ldc, M_max, N, K, nb, nr, act, bias, residual, ldr, splitk_ws,
+                                           splitk_ws_bytes, stream, m_dev);
+    if (rc <= 0) return rc;
+  }
+  return launch_linear_f32_dev(A, lda, W, ldw, C, ldc, M_max, m_dev, N, K, epilogue, bias, residual, ldr, -1, stream);
+}
+
 int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                          int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
                          float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream) {

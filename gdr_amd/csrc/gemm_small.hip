@@ -29,6 +29,7 @@ struct SmallGemmArgs {
   int N, K, tiles_n;
   int has_bias, has_residual, act;  // 0 none, 1 relu, 2 gelu
   int ksplit, kchunk;               // kchunk in elements, multiple of 32
+  const int64_t* m_dev;             // may be null: live row count on the device (<= M); tiles past it exit at once
 };
 
 __device__ __forceinline__ float gelu_erf_s(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -46,6 +47,8 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_f32_small_kernel(const SmallGe
   const unsigned tile = bid / (unsigned)g.ksplit;
   const int64_t m0 = (int64_t)(tile / (unsigned)g.tiles_n) * SB;
   const int n0 = (int)(tile % (unsigned)g.tiles_n) * SB;
+  const int64_t Mrows = g.m_dev ? *g.m_dev : g.M;
+  if (m0 >= Mrows) return;  // uniform
   const int tid = threadIdx.x;
   // staging: 8 lanes cover one 128-B row segment, 32 rows per pass, 2 passes per operand
   const int lrow = tid >> 3, lcol = (tid & 7) * 4;
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_f32_small_kernel(const SmallGe
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     int64_t ra = m0 + lrow + 32 * p;
-    ra = ra < g.M ? ra : g.M - 1;
+    ra = ra < Mrows ? ra : Mrows - 1;
     int rw = n0 + lrow + 32 * p;
     rw = rw < g.N ? rw : g.N - 1;
     a_src[p] = g.A + ra * g.lda + lcol + (int64_t)split * g.kchunk;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_f32_small_kernel(const SmallGe
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (m >= g.M) continue;
+    if (m >= Mrows) continue;
     float v = acc[r] + bia;
     if (g.has_residual) v += g.residual[m * g.ldr + n];
     if (g.act == 1) v = fmaxf(v, 0.f);
@@ -148,7 +151,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const float* _
                                                                   int64_t M, int N, float* __restrict__ C, int64_t ldc,
                                                                   const float* __restrict__ bias,
                                                                   const float* __restrict__ residual, int64_t ldr,
-                                                                  int act) {
+                                                                  int act, const int64_t* __restrict__ m_dev) {
+  if (m_dev) M = *m_dev;
   const int tile = blockIdx.x >> 2;
   const int e = ((blockIdx.x & 3) << 8) + threadIdx.x;  // float4 index inside the tile: 64 rows x 16 float4
   const int r = e >> 4, c = (e & 15) << 2;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const float* _
 // Returns 1 when the shape is left to the 128x128 core, 0 after launching, < 0 on error.
 int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
-                            int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream) {
+                            int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev) {
   static const int target = [] {
     const char* e = getenv("GDR_SMALL_TARGET");  // tuning knob: workgroups wanted per launch; 0 disables this kernel
     return e ? atoi(e) : 512;
@@ -200,6 +204,7 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
   g.A = A, g.W = W, g.bias = bias, g.residual = residual;
   g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr, g.M = M, g.N = N, g.K = K, g.tiles_n = tiles_n;
   g.ksplit = S, g.kchunk = chunk_steps * SBK;
+  g.m_dev = m_dev;
   const double flops = 2.0 * (double)M * (double)N * (double)K;
   if (S == 1) {
     g.C = C, g.has_bias = has_bias, g.has_residual = has_residual, g.act = act;
@@ -216,7 +221,7 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
   GDR_CHECK_LAUNCH("gemm_nt_f32_small_kernel(split)");
   ProfScope prof_r(PROF_REDUCE, 0.0, stream);
   hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((unsigned)(tiles * 4)), dim3(256), 0, stream, ws, S, tiles_n, M, N, C, ldc,
-                     has_bias ? bias : nullptr, has_residual ? residual : nullptr, ldr, act);
+                     has_bias ? bias : nullptr, has_residual ? residual : nullptr, ldr, act, m_dev);
   GDR_CHECK_LAUNCH("splitk_reduce_small_kernel");
   return 0;
 }

@@ -40,6 +40,7 @@ struct AttnArgs {
   // dk = 64 full self-attention form (attention_mfma16_kernel) reads these.
   const int32_t* seq_off;
   const int32_t* seq_len;
+  const int64_t* b_count_dev;  // Lq = 1 decode form only, may be null: only batch entries b < *b_count_dev are computed
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 
@@ -75,5 +76,7 @@ int launch_rmsnorm_bf16(const float* x, const float* w, void* y_bf16, int64_t ro
 // optional addv [d]: y = LN(x + addv)  (the adaptor's constant single-key cross-attention output)
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int d, float eps,
                      const float* addv, hipStream_t stream);
+int launch_layernorm_dev(const float* x, const float* w, const float* b, float* y, const int64_t* rows_dev, int64_t max_rows,
+                         int d, float eps, const float* addv, hipStream_t stream);
 
 }  // namespace gdr

@@ -277,8 +277,10 @@ int launch_rmsnorm_bf16(const float* x, const float* w, void* y_bf16, int64_t ro
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y,
                                                         int64_t rows, int d4, float eps,
-                                                        const float* __restrict__ addv) {
+                                                        const float* __restrict__ addv,
+                                                        const int64_t* __restrict__ rows_dev) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rows_dev) rows = *rows_dev;
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   const float4* xr = reinterpret_cast<const float4*>(x) + row * d4;
@@ -322,8 +324,18 @@ int launch_layernorm(const float* x, const float* w, const float* b, float* y, i
   GDR_CHECK_ARG(d % 4 == 0, "layernorm: d %% 4 != 0");
   if (rows == 0) return GDR_OK;
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, b, y, rows, d / 4,
-                     eps, addv);
+                     eps, addv, (const int64_t*)nullptr);
   GDR_CHECK_LAUNCH("layernorm_kernel");
+  return GDR_OK;
+}
+
+int launch_layernorm_dev(const float* x, const float* w, const float* b, float* y, const int64_t* rows_dev, int64_t max_rows,
+                         int d, float eps, const float* addv, hipStream_t stream) {
+  GDR_CHECK_ARG(d % 4 == 0, "layernorm: d %% 4 != 0");
+  if (max_rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((max_rows + 3) / 4)), dim3(256), 0, stream, x, w, b, y, max_rows, d / 4,
+                     eps, addv, rows_dev);
+  GDR_CHECK_LAUNCH("layernorm_kernel(dev rows)");
   return GDR_OK;
 }
 
@@ -755,6 +767,7 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const AttnArgs a)
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= a.B * a.H) return;
   const int b = item / a.H, h = item % a.H, lane = threadIdx.x & 63;
+  if (a.b_count_dev && b >= (int)*a.b_count_dev) return;  // only the first *b_count_dev batch entries are live
   const int dk = a.dk, c4 = dk >> 2, Lk = a.Lk, kb = b / a.kv_group;
   const float* qr = a.q + (int64_t)b * a.q_bstride * a.ldq + h * dk;
   const int i_abs = a.q_pos0;

@@ -60,13 +60,18 @@ class GDRModel:
     """T5ForConditionalGeneration of the reference (GDR config: decode_embedding=2, adaptor_efficient),
     inference only.  Construct from a reference-style state_dict (SURVEY Appendix C key names)."""
 
-    def __init__(self, cfg: GDRConfig, state_dict, device="cuda:0", with_decoder=True, trie=None, ragged=False):
+    def __init__(self, cfg: GDRConfig, state_dict, device="cuda:0", with_decoder=True, trie=None, ragged=False,
+                 prefix_trie=None):
         """trie: optional codec.Trie — enables the NCI trie constraint of the reference's earlier
         generation_utils_previous.py:714-729 (the shipped generate() ignores `decode_tree`).
         ragged: generate() skips the PAD rows of the encoder (gdr_t5_encoder_forward_ragged).  Decoded ids, scores and the
         CLS rows are unchanged (cross-attention masks PAD keys, kept rows are bit-identical); only the PAD positions of the
         `last_hidden_state` returned with output_encoder_embedding=True are zero instead of the reference's values there,
-        hence opt-in.  get_encoder() always computes every row."""
+        hence opt-in.  get_encoder() always computes every row.
+        prefix_trie: optional codec.Trie over the corpus' docids — builds the device prefix table (ops.PrefixTable) at
+        load: beams whose prefix is a node of that trie read the query-independent adaptor/head results from it instead of
+        recomputing them (modeling_t5.py:1618-1639); other beams are computed as before.  Same logits up to fp32
+        summation order.  When `trie` (the constraint) is given too it must be the same trie."""
         self.config = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -74,7 +79,17 @@ class GDRModel:
         sd = strip_lightning_prefix(state_dict)
         self.enc = ops.T5EncoderHandle(cfg, sd, self.device)
         self.dec = ops.T5DecoderHandle(cfg, sd, self.device) if with_decoder else None
-        self.trie = ops.DeviceTrie(trie, self.device) if trie is not None else None
+        self.prefix_table = None
+        if prefix_trie is not None:
+            if self.dec is None:
+                raise _ffi.GdrError("prefix_trie needs the decoder (with_decoder=True)")
+            if trie is not None and trie is not prefix_trie:
+                raise _ffi.GdrError("trie= and prefix_trie= must be the same codec.Trie object")
+            self.prefix_table = ops.PrefixTable(self.dec, prefix_trie, self.device)
+        if trie is None:
+            self.trie = None
+        else:                                     # the constraint shares the table's breadth-first arrays
+            self.trie = self.prefix_table.device_trie if self.prefix_table is not None else ops.DeviceTrie(trie, self.device)
         self.ragged = bool(ragged)
         self.training = False
 
@@ -125,7 +140,7 @@ class GDRModel:
         input_ids, attention_mask = input_ids.to(self.device), attention_mask.to(self.device)
         enc_h, _ = self.enc.forward(input_ids, attention_mask, want_pooled=False, ragged=self.ragged)
         ids, lens, scores = self.dec.generate(enc_h, attention_mask, num_beams, max_length, length_penalty,
-                                              num_return_sequences, trie=self.trie)
+                                              num_return_sequences, trie=self.trie, prefix_table=self.prefix_table)
         decoded, score_list = ops.finish_generate_output(ids, lens, scores, max_length)
         output = (decoded, score_list) if output_scores else decoded
         if output_encoder_embedding:

@@ -408,7 +408,7 @@ class T5DecoderHandle:
         self.ws = Workspace(device)
 
     def generate(self, enc_hidden, enc_mask, num_beams, max_length, length_penalty, num_return_sequences, trace=False,
-                 trie=None):
+                 trie=None, prefix_table=None):
         """Returns (out_ids int64[B*nret,max_length], out_len int32[B*nret], out_scores float64[B*nret][, trace])."""
         _need_cuda(enc_hidden, enc_mask)
         enc_hidden = _f32c(enc_hidden)
@@ -427,6 +427,7 @@ class T5DecoderHandle:
             tt = torch.empty((max_length - 1, B, 2 * R), dtype=torch.int32, device=dev_)
         check(lib().gdr_t5_generate(C.byref(self.struct), ptr(enc_hidden), ptr(mask), B, L, R, max_length,
                                     float(length_penalty), nret, trie.struct_ref() if trie is not None else None,
+                                    prefix_table.struct_ref() if prefix_table is not None else None,
                                     ptr(ids), ptr(lens), ptr(scores), ptr(ts), ptr(tt),
                                     ptr(ws), ws.numel(), stream_ptr()), "gdr_t5_generate")
         return (ids, lens, scores, ts, tt) if trace else (ids, lens, scores)
@@ -442,6 +443,50 @@ class DeviceTrie:
 
     def struct_ref(self):
         return C.byref(self.struct)
+
+
+class PrefixTable:
+    """Device prefix table (include/gdr_hip.h GdrPrefixTable) over a docid trie, built once from the decoder handle's
+    weights by gdr_t5_prefix_table_build: per trie node the adaptor's per-layer (q,k,v) and the head matrix
+    W = adaptor_linear(adaptor(prefix)) + lm_head of the node's position (modeling_t5.py:1618-1639, query-independent).
+    `trie` is a codec.Trie in any order; `.device_trie` is its breadth-first DeviceTrie — pass THAT one as the constraint
+    trie when both are used (gdr_t5_generate checks that they share their arrays)."""
+
+    def __init__(self, dec, trie, device, max_levels=None):
+        import numpy as np
+        bfs, level_off, parent, tok = trie.breadth_first()
+        cfg = dec.cfg
+        n_levels = min(len(level_off) - 1, cfg.max_output_length - 1, max_levels or (1 << 30))
+        n_table = int(level_off[n_levels])
+        self.device_trie = DeviceTrie(bfs, device)
+        anc_blocks, anc = [], np.zeros((1, 1), np.int32)                 # level 0: the root's ancestor list is itself
+        for s in range(n_levels):
+            lo, hi = int(level_off[s]), int(level_off[s + 1])
+            if s > 0:
+                anc = np.concatenate([anc[parent[lo:hi] - int(level_off[s - 1])], np.arange(lo, hi, dtype=np.int32)[:, None]], 1)
+            anc_blocks.append(anc.reshape(-1))
+        node_anc = torch.from_numpy(np.concatenate(anc_blocks).astype(np.int32)).to(device)
+        node_tok = torch.from_numpy(tok[:n_table].copy()).to(device)
+        d, V1, na = cfg.d_model, cfg.output_vocab_size + 1, cfg.adaptor_layer_num
+        self.kv = torch.empty((na, n_table, 3 * d), dtype=torch.float32, device=device)
+        self.W = torch.empty((n_table, V1, d), dtype=torch.float32, device=device)
+        lo_host = (C.c_int32 * (n_levels + 1))(*[int(x) for x in level_off[:n_levels + 1]])
+        max_n = int(max(level_off[s + 1] - level_off[s] for s in range(n_levels)))
+        need = lib().gdr_t5_prefix_table_workspace_bytes(C.byref(dec.struct), max_n)
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        check(lib().gdr_t5_prefix_table_build(C.byref(dec.struct), n_levels, lo_host, ptr(node_tok), ptr(node_anc),
+                                              ptr(self.kv), ptr(self.W), ptr(ws), ws.numel(), stream_ptr()),
+              "gdr_t5_prefix_table_build")
+        torch.cuda.current_stream().synchronize()                        # the scratch tensors above may go now
+        self.n_levels, self.n_table, self.level_off = n_levels, n_table, level_off
+        self.struct = _ffi.GdrPrefixTable(self.device_trie.child.data_ptr(), self.device_trie.child.shape[0], int(bfs.V),
+                                          n_table, self.kv.data_ptr(), self.W.data_ptr())
+
+    def struct_ref(self):
+        return C.byref(self.struct)
+
+    def nbytes(self):
+        return self.kv.numel() * 4 + self.W.numel() * 4
 
 
 def beam_search_table(table, out_vocab, num_beams, max_length, length_penalty, num_return_sequences=None, trie=None):

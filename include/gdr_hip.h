@@ -305,6 +305,33 @@ typedef struct {
   int32_t V;              /* digits per level the table was built for; must equal the head's out_vocab (checked) */
 } GdrTrie;
 
+/* Prefix table (optional, exact): the adaptor chain and the head matrix W = adaptor_linear(adaptor(prefix))[V+1 columns] +
+ * lm_head depend only on the decoded TOKEN PREFIX, never on the query (modeling_t5.py:1618-1639:
+ * decode_embeddings(decoder_input_ids) -> adaptor(memory = adaptor_embeddings) -> adaptor_linear).  For every node of the
+ * corpus' docid trie (nodes in BREADTH-FIRST order, root = 0; the first n_table nodes = all nodes of depth < n_levels) the
+ * table holds, per adaptor layer, the in_proj output (q,k,v) of the node's position and the finished head matrix.  With
+ * it, gdr_t5_generate reads W[node] for a beam row whose prefix is a table node; rows whose prefix left the trie (or is
+ * deeper than the table) are compacted on the device and run the adaptor + head GEMM for themselves, attending over
+ * ancestors' K/V taken from the table or computed earlier in the call.  Built once per (weights, corpus): a pure function
+ * of those two, nothing query-dependent is ever stored.  Size: n_table * (adaptor_layers*3*d + (V+1)*d) floats
+ * (320k-doc corpus, t5-base: 27 598 nodes, 3.6 GB). */
+typedef struct {
+  const int32_t* child;   /* device int32 [n_nodes, V]: the trie, as GdrTrie.child                                   */
+  int32_t n_nodes, V;
+  int32_t n_table;        /* nodes with entries: the first n_table nodes (breadth-first order)                       */
+  const float* kv;        /* device [adaptor_layers][n_table][3*d]                                                   */
+  const float* W;         /* device [n_table][V+1][d]   (adaptor_linear slice + lm_head rows of the node's position) */
+} GdrPrefixTable;
+
+size_t gdr_t5_prefix_table_workspace_bytes(const GdrT5DecoderWeights* w, int max_level_nodes);
+/* level_off: HOST int32 [n_levels+1], node range of each depth (level 0 = the root alone);
+ * node_tok: device int64 [n_table], the token that leads to the node (root: START = 0);
+ * node_anc: device int32, level after level, for each node of depth s its s+1 ancestors root..self (node ids);
+ * kv, W: the table storage (device), filled by this call.  n_levels <= max_output_length - 1. */
+int gdr_t5_prefix_table_build(const GdrT5DecoderWeights* w, int n_levels, const int32_t* level_off, const int64_t* node_tok,
+                              const int32_t* node_anc, float* kv, float* W, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
 size_t gdr_t5_generate_workspace_bytes(const GdrT5DecoderWeights* w, int B, int L, int num_beams, int max_length);
 /* enc_hidden fp32[B,L,d] (NOT beam-expanded), enc_mask int64[B,L].
  * out_ids int64[B*nret, max_length] (hypothesis tokens incl. START, then EOS if it fits, then PAD),
@@ -314,8 +341,9 @@ size_t gdr_t5_generate_workspace_bytes(const GdrT5DecoderWeights* w, int B, int 
  * 2 <= num_beams <= 256, num_return_sequences <= num_beams, max_length <= max_out_len. */
 int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B, int L,
                     int num_beams, int max_length, double length_penalty, int num_return_sequences,
-                    const GdrTrie* trie, int64_t* out_ids, int32_t* out_len, double* out_scores, float* step_scores,
-                    int32_t* step_tokens, void* workspace, size_t workspace_bytes, void* stream);
+                    const GdrTrie* trie, const GdrPrefixTable* prefix_table /* NULL: compute every row */, int64_t* out_ids,
+                    int32_t* out_len, double* out_scores, float* step_scores, int32_t* step_tokens, void* workspace,
+                    size_t workspace_bytes, void* stream);
 
 /* The same device beam search driven by a logit table instead of the model (teacher forcing):
  * logits(prefix) = table[b, pos, last_token, :] (fp32 [B, max_length, Vd, Vd]) with the positional mask.

@@ -1,0 +1,131 @@
+"""The prefix table of gdr_t5_generate (include/gdr_hip.h GdrPrefixTable): the adaptor chain and the head matrix depend on
+the decoded token prefix only (transformers/modeling_t5.py:1618-1639), so they are built once per (weights, corpus trie) and
+read at decode time; rows whose prefix is not a trie node are compacted on the device and computed as before.  Parity:
+table contents vs the oracle's adaptor + head; generate() with the table vs the reference-made goldens / the oracle /
+the table-less path, with beams that stay in the trie, leave it, and mix both in one step."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from gdr_amd.config import GDRConfig
+from gdr_amd import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _tiny_docids(V, depth, keep_every=1):
+    ids = []
+    for c in range(V ** depth):
+        if c % keep_every:
+            continue
+        ids.append("-".join(str(x) for x in synth.cluster_digits(c, depth, V)))
+    return ids
+
+
+def test_table_contents_match_oracle_adaptor_and_head(dev):
+    """Every stored head matrix W[node] = adaptor_linear(adaptor(prefix))[last position, its V+1 live columns] + lm_head rows,
+    and the stored per-layer (k, v) are what a descendant attends to — checked through W of the deeper levels."""
+    from gdr_amd import codec, ops
+    from oracle import t5_ref
+    cfg = GDRConfig.tiny()
+    sd = synth.make_state_dict(cfg, seed=21)
+    V, d, Vd = cfg.output_vocab_size, cfg.d_model, cfg.decode_vocab_size
+    trie = codec.Trie.from_docids(_tiny_docids(V, 3, keep_every=5), V)
+    dec = ops.T5DecoderHandle(cfg, sd, dev)
+    tab = ops.PrefixTable(dec, trie, dev)
+    bfs, level_off, parent, tok = trie.breadth_first()
+    assert tab.n_levels == 4 and tab.n_table == bfs.child.shape[0]       # depth-3 ids: root + 3 digit levels
+    Wg = tab.W.cpu()
+    for s in range(tab.n_levels):
+        nodes = list(range(int(level_off[s]), int(level_off[s + 1])))[:7]
+        prefixes = []
+        for n in nodes:
+            seq, x = [], n
+            while x >= 0:
+                seq.append(int(tok[x]))
+                x = int(parent[x])
+            prefixes.append(seq[::-1])
+        ids = torch.tensor(prefixes, dtype=torch.long)                    # [n, s+1], starts with START = 0
+        a = t5_ref.adaptor_forward(sd, cfg, ids)[:, -1]                   # [n, d]
+        cols = t5_ref.valid_columns(s, V)
+        Wl = sd["adaptor_linear.weight"].view(d, Vd, d)[:, cols, :]       # [i, c, k]
+        ref = torch.einsum("rk,ick->rci", a, Wl) + sd["lm_head.weight"][cols].unsqueeze(0)
+        torch.testing.assert_close(Wg[nodes], ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("keep_every,constrain", [(1, False), (3, False), (3, True), (7, False)])
+def test_generate_tiny_with_prefix_table_vs_oracle(dev, keep_every, constrain):
+    """Tiny model, V = 6, depth-2 docids.  keep_every = 1: the whole 2-digit space is in the trie (every row hits for three
+    steps, then every row misses); 3 / 7: holes, so hit and miss rows share a step.  With the constraint the beams never
+    leave the trie.  Ids must equal the oracle's and the table-less path's; scores to fp32 tolerance."""
+    from gdr_amd import codec
+    from gdr_amd.modeling import GDRModel
+    from oracle import beam_ref, codec_ref
+    cfg = GDRConfig.tiny()
+    sd = synth.make_state_dict(cfg, seed=1234)
+    V = cfg.output_vocab_size
+    docids = _tiny_docids(V, 2, keep_every)
+    trie = codec.Trie.from_docids(docids, V)
+    B, R = 5, 6
+    ids, mask = synth.make_tokens(B, L=9, vocab_hi=cfg.vocab_size, seed=4, min_len=2)
+    it, mt = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    kw = dict(attention_mask=mt, max_length=cfg.max_output_length, num_beams=R, length_penalty=0.8, num_return_sequences=R,
+              output_scores=True)
+    plain = GDRModel(cfg, sd, dev, trie=trie if constrain else None)
+    tabled = GDRModel(cfg, sd, dev, trie=trie if constrain else None, prefix_trie=trie)
+    (d0, s0), _ = plain.generate(it, **kw)
+    (d1, s1), _ = tabled.generate(it, **kw)
+    assert torch.equal(d0, d1)
+    np.testing.assert_allclose(np.array(s1), np.array(s0), rtol=1e-5, atol=1e-5)
+    tree = beam_ref.build_trie([codec_ref.encode_single_newid(s, kary=V) for s in docids]) if constrain else None
+    (rd, rs), _ = beam_ref.generate(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask), R, restricted_head=True,
+                                    decode_tree=tree)
+    fin = np.isfinite(np.array(rs))
+    np.testing.assert_allclose(np.array(s1)[fin], np.array(rs)[fin], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(d1.cpu().numpy()[fin], rd.numpy()[fin])
+    (d2, s2), _ = tabled.generate(it, **kw)                               # the table is read-only: a second call is identical
+    assert torch.equal(d2, d1) and s2 == s1
+
+
+def test_generate_base_golden_still_exact_with_prefix_table(dev):
+    """The reference-made t5-base fixture (g5: beam 10, B = 2) through generate() with a prefix table over a 30 000-doc
+    corpus' trie (2 500 clusters, depth 3): steps 0-3 read the table (prefixes of up to three digits are almost all trie
+    nodes), deeper steps compute; ids exact, scores to 1e-4."""
+    from gdr_amd import codec
+    from gdr_amd.modeling import GDRModel
+    g = golden("g5_generate_base")
+    cfg = GDRConfig.base()
+    sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
+    names, _, _, _ = synth.make_cluster_ids(30000, cluster_size=12, V=30)
+    model = GDRModel(cfg, sd, dev, prefix_trie=codec.Trie.from_docids(names, 30))
+    assert model.prefix_table.n_levels == 4 and model.prefix_table.n_table == 1 + 3 + 84 + 2500
+    R = int(g["num_beams"])
+    ids, mask = torch.from_numpy(g["input_ids"]).to(dev), torch.from_numpy(g["attention_mask"]).to(dev)
+    (dec, scores), _ = model.generate(ids, attention_mask=mask, max_length=cfg.max_output_length, num_beams=R,
+                                      length_penalty=float(g["length_penalty"]), num_return_sequences=R, output_scores=True)
+    np.testing.assert_allclose(np.array(scores), g["scores"], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(dec.cpu().numpy(), g["decoded"])
+
+
+def test_prefix_table_argument_checks(dev):
+    from gdr_amd import _ffi, codec, ops
+    from gdr_amd.modeling import GDRModel
+    cfg = GDRConfig.tiny()
+    sd = synth.make_state_dict(cfg, seed=1)
+    t1 = codec.Trie.from_docids(_tiny_docids(6, 2), 6)
+    t2 = codec.Trie.from_docids(_tiny_docids(6, 2, 2), 6)
+    with pytest.raises(_ffi.GdrError):
+        GDRModel(cfg, sd, dev, trie=t1, prefix_trie=t2)
+    dec = ops.T5DecoderHandle(cfg, sd, dev)
+    with pytest.raises(_ffi.GdrError, match="V="):
+        tab = ops.PrefixTable(dec, codec.Trie.from_docids(["0-1", "1-0"], 2), dev)   # built for V = 2, head has V = 6
+        enc = torch.zeros((1, 3, cfg.d_model), device=dev)
+        dec.generate(enc, torch.ones((1, 3), dtype=torch.int64, device=dev), 2, 3, 0.8, 2, prefix_table=tab)
