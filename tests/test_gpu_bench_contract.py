@@ -36,10 +36,27 @@ def test_bench_line_contract_fp32():
     assert j["value"] > 0 and abs(j["value"] - 64 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
     rec = j["recall"]
     assert rec["gpu"] == rec["cpu_oracle"], "Recall@{1,10,100} parity with the CPU oracle"
+    assert rec["rows_violating_tie_rule"] == 0 and rec["topk_ids_identical_rows"] + 8 >= rec["rows"]
+    assert j["config"]["encoder_rows"] == "ragged" and "ragged encoder" in j["config"]["workload"]
+    assert c["cpu_model"]
+    st = j["stages"]                                   # the other stages of the path, measured after the timed region
+    lat = st["similarity_topk_f32"]["B32"]
+    assert lat["bound"] == "hbm" and 0 < lat["frac_of_hbm_peak"] < 1
+    for key in ("B64_beam10", "B1_beam100"):
+        g = st["generate"][key]
+        assert g["generate_ms"] > g["encoder_ms"] > 0 and 0 < g["frac_of_floor"] < 1
+    assert st["c3_two_stage"]["queries_per_s"] > 0 and st["bf16_mode_c2_step"]["queries_per_s"] > 0
+    assert st["prefix_table"]["nodes"] > 1
+
+
+def test_bench_padded_encoder_form_gives_the_same_recall():
+    a, b = _run("--encoder", "padded", "--no-stages"), _run("--no-stages")
+    assert a["config"]["encoder_rows"] == "padded" and b["config"]["encoder_rows"] == "ragged"
+    assert a["recall"] == b["recall"] and a["stages"] is None
 
 
 def test_bench_line_contract_bf16_mode():
-    j = _run("--dtype", "bf16", "--no-cpu-baseline")
+    j = _run("--dtype", "bf16", "--no-cpu-baseline", "--no-stages")
     assert j["dtype"] == "bf16" and j["cpu_baseline"] is None and j["roofline"]["peak"] == 2500.0
 
 
@@ -55,7 +72,7 @@ def test_bench_under_torchrun_one_rank_rccl():
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                               "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64", "--corpus", "30000",
-                              "--no-cpu-baseline", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                              "--no-cpu-baseline", "--no-stages", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
         assert out.returncode == 0, out.stderr[-2000:]
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1

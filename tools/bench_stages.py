@@ -38,14 +38,19 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--corpus", type=int, default=320000)
     ap.add_argument("--skip-doc-tower", action="store_true")
+    ap.add_argument("--no-prefix-table", action="store_true", help="compute the adaptor / head for every beam row every step")
+    ap.add_argument("--padded", action="store_true", help="padded encoder form (PAD rows computed)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.set_grad_enabled(False)
     cfg = GDRConfig.base()
     sd = synth.make_state_dict(cfg, seed=1234)
-    model = GDRModel(cfg, sd, dev)
     N = a.corpus
     names, depth, offsets, members = synth.make_cluster_ids(N, cluster_size=12, V=30)
+    t0 = time.perf_counter()
+    model = GDRModel(cfg, sd, dev, ragged=not a.padded,
+                     prefix_trie=None if a.no_prefix_table else codec.Trie.from_docids(names, 30))
+    torch.cuda.synchronize()
     # random weights decode full-length rows; name clusters in that decoded form so that rerank has candidates
     D = torch.from_numpy(synth.make_corpus(N, cfg.d_model)).to(dev)
     ids, mask = synth.make_tokens(a.B, L=40, seed=11)
@@ -53,8 +58,11 @@ def main():
     R = a.beams
     args = types.SimpleNamespace(num_return_sequences=R, output_vocab_size=30, max_output_length=10, length_penalty=0.8,
                                  kary=30, position=1, score_rate=[0, 0.5, 1, 1.5, 2, 2.5, 3], loss_func="tanh")
-    out = {"B": a.B, "beams": R, "corpus": N}
-    t = timed(lambda: model.enc.forward(ids, mask), a.reps)
+    out = {"B": a.B, "beams": R, "corpus": N, "prefix_table": not a.no_prefix_table, "ragged_encoder": not a.padded,
+           "model_load_s": time.perf_counter() - t0}
+    if model.prefix_table is not None:
+        out["prefix_table_nodes"], out["prefix_table_gb"] = model.prefix_table.n_table, model.prefix_table.nbytes() / 1e9
+    t = timed(lambda: model.enc.forward(ids, mask, ragged=not a.padded), a.reps)
     out["encoder_qps"] = a.B / t
     gen = lambda: model.generate(ids, attention_mask=mask, max_length=10, num_beams=R, length_penalty=0.8,
                                  num_return_sequences=R, output_scores=True, output_encoder_embedding=True)

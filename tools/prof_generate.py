@@ -2,14 +2,16 @@
 Post-process the kernel trace with tools/trace_busy.py to see GPU-busy vs wall span (launch-bound or not)."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from gdr_amd import synth
+from gdr_amd import codec, synth
 from gdr_amd.config import GDRConfig
 from gdr_amd.modeling import GDRModel
 torch.set_grad_enabled(False)
 dev = torch.device("cuda:0")
 B, R = int(os.environ.get("B", 64)), int(os.environ.get("BEAMS", 10))
 cfg = GDRConfig.base()
-model = GDRModel(cfg, synth.make_state_dict(cfg, seed=1234), dev)
+names = synth.make_cluster_ids(320000, cluster_size=12, V=30)[0]
+model = GDRModel(cfg, synth.make_state_dict(cfg, seed=1234), dev, ragged=True,
+                 prefix_trie=None if os.environ.get("NO_PREFIX_TABLE") else codec.Trie.from_docids(names, 30))
 ids, mask = synth.make_tokens(B, L=40, seed=11)
 ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
 for _ in range(4):
