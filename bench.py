@@ -395,8 +395,10 @@ def main():
                        "encoder_rows": "ragged" if ragged else "padded", "live_token_rows_per_gpu": live_rows},
             "roofline": {"bound": "mfma",
                          "kernel": ("gdr::gemm_nt_bf16_glds_kernel (bf16 operands, LDS-DMA staging; every encoder linear)"
-                                    if bf16 else "gdr::gemm_nt_f32_persistent_kernel (every encoder linear"
-                                    + ("; the last block's three CLS-row linears run on the 64x64-tile kernel and are "
+                                    if bf16 else "gdr::gemm_nt_f32_persistent_kernel / gdr::gemm_nt_f32_streamk_kernel (every "
+                                    "encoder linear: the same 128x128 MFMA K-step stream, dealt as whole tiles or — where "
+                                    "whole tiles quantise badly — as equal K-step ranges with exact accumulator hand-off"
+                                    + ("; the last block's three CLS-row linears run on the 64x64-tile kernel; all are "
                                        "included in launches / flops / time)" if ragged else ")")),
                          "achieved": lin["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": lin["tflops"] / peak,
                          "traffic": None if bf16 else traffic,

@@ -59,12 +59,23 @@ struct SimEpilogue {
   int32_t mode;           // 1: sample tiles, store every score; 2: other tiles, append score >= thr
 };
 
+// Scratch of the stream-K form of the persistent linear kernel (gemm_f32.hip), owned by the caller: one per stream of
+// launches.  `flag` must be zeroed once (hipMemsetAsync on the same stream) before the first launch that uses it; every
+// launch then takes the next epoch, so flags never need clearing between launches.
+struct StreamK {
+  float* part;     // device [512][128*128]: raw accumulators handed from a workgroup to its successor
+  int32_t* flag;   // device [512]
+  int32_t epoch;   // host-side launch counter
+};
+constexpr size_t STREAMK_PART_BYTES = (size_t)512 * 128 * 128 * 4;
+constexpr size_t STREAMK_BYTES = STREAMK_PART_BYTES + 4096;
+
 int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                       int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
                       hipStream_t stream);
 int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                          int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
-                         float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream);
+                         float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream, StreamK* sk = nullptr);
 // Decode-time linear over a device-side row count (*m_dev <= M_max live rows; grids sized for M_max): the same kernel
 // choice as launch_linear_f32_ws makes for M_max — small-tile / split-K forms included, so its results for a row equal
 // what launch_linear_f32_ws(M = M_max) gives that row.
@@ -73,7 +84,7 @@ int launch_linear_f32_ws_dev(const float* A, int64_t lda, const float* W, int64_
                              int64_t ldr, float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream);
 int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M_max,
                           const int64_t* m_dev, int N, int K, int epilogue, const float* bias, const float* residual,
-                          int64_t ldr, int64_t prof_rows, hipStream_t stream);
+                          int64_t ldr, int64_t prof_rows, hipStream_t stream, StreamK* sk = nullptr);
 // docs D[N,d] take the GEMM's row role, queries Q[B,d] the column role: a lane owns one query.
 int launch_sim_gemm(const void* D, int64_t N, const void* Q, int B, int d, const SimEpilogue& ep, bool bf16,
                     hipStream_t stream);

@@ -15,7 +15,21 @@
 
 namespace gdr {
 
-constexpr size_t ENC_SPLITK_BYTES = (size_t)112 << 20;  // <= 384 tail tiles x 4 splits x 64 KiB + slack
+constexpr size_t ENC_SPLITK_BYTES = (size_t)112 << 20;  // <= 384 tail tiles x 4 splits x 64 KiB + slack; the same region
+                                                        // serves as the stream-K hand-off scratch (a launch uses one or the other)
+static_assert(STREAMK_BYTES <= ENC_SPLITK_BYTES, "stream-K scratch must fit the split-K region");
+
+// the stream-K scratch inside the split-K region of an encoder workspace; flags zeroed once per call
+static int enc_streamk(char* splitk_region, StreamK* sk, hipStream_t stream) {
+  sk->part = reinterpret_cast<float*>(splitk_region);
+  sk->flag = reinterpret_cast<int32_t*>(splitk_region + STREAMK_PART_BYTES);
+  sk->epoch = 0;
+  if (hipMemsetAsync(sk->flag, 0, 512 * sizeof(int32_t), stream) != hipSuccess) {
+    set_error("t5_encoder: memset of the stream-K flags failed");
+    return GDR_EHIP;
+  }
+  return GDR_OK;
+}
 
 struct EncWs {
   size_t off_h, off_nx, off_qkv, off_ctx, off_ff, off_splitk, off_bf, total;
@@ -71,12 +85,15 @@ static int t5_encoder_impl(const GdrT5EncoderWeights* w, const int64_t* ids, con
   float* ff = reinterpret_cast<float*>(base + ws.off_ff);
   float* skw = reinterpret_cast<float*>(base + ws.off_splitk);
   void* abf = base + ws.off_bf;
+  StreamK sk{};
+  if (!bf16)
+    if (int rc_ = enc_streamk(base + ws.off_splitk, &sk, stream)) return rc_;
   // one linear: fp32 as is; in bf16 mode the activation operand is rounded to bf16 into `abf` first (the weights were
   // rounded once by the caller) and the GEMM runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulate / epilogue / output
   auto linear = [&](const float* A, int64_t lda, const float* W, float* C, int64_t ldc, int N, int K, int epi,
                     const float* residual) -> int {
     if (!bf16)
-      return launch_linear_f32_ws(A, lda, W, K, C, ldc, M, N, K, epi, nullptr, residual, ldc, skw, ENC_SPLITK_BYTES, stream);
+      return launch_linear_f32_ws(A, lda, W, K, C, ldc, M, N, K, epi, nullptr, residual, ldc, skw, ENC_SPLITK_BYTES, stream, &sk);
     GDR_CHECK_ARG(lda == K, "t5_encoder_bf16: operand must be dense");
     int rc_ = launch_cast_f32_bf16(A, abf, M * (int64_t)K, stream);
     if (rc_) return rc_;
@@ -232,9 +249,12 @@ extern "C" int gdr_t5_encoder_forward_ragged(const GdrT5EncoderWeights* w, const
   float* h_cls = reinterpret_cast<float*>(base + rw.h_cls);
   float* nx_cls = reinterpret_cast<float*>(base + rw.nx_cls);
   float* ff_cls = reinterpret_cast<float*>(base + rw.ff_cls);
+  StreamK sk{};
+  if ((rc = enc_streamk(base + ws.off_splitk, &sk, stream))) return rc;
   auto linear = [&](const float* A, int64_t lda, const float* W, float* C, int64_t ldc, int N, int K, int epi,
                     const float* residual) -> int {
-    return launch_linear_f32_dev(A, lda, W, K, C, ldc, M, rows_dev, N, K, epi, nullptr, residual, ldc, live_rows_hint, stream);
+    return launch_linear_f32_dev(A, lda, W, K, C, ldc, M, rows_dev, N, K, epi, nullptr, residual, ldc, live_rows_hint, stream,
+                                 &sk);
   };
   if ((rc = launch_embed_packed(w->embed, ids, row_src, rows_dev, M, d, dm.vocab_size, h, stream))) return rc;
 

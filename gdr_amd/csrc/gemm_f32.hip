@@ -623,6 +623,358 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
 #undef P_MFMA16
 }
 
+// ---- stream-K form of the persistent kernel -----------------------------------------------------------------------
+// The persistent kernel above deals whole tiles: with T tiles on G = 512 resident workgroups a CU ends up with
+// ceil(T/256) tiles against T/256 on average — 582 tiles (ragged C2 batch, N = 768) cost three tile times where 2.27 would
+// do, and the whole encoder ran at 98 TFLOP/s instead of 129.  Here the unit of work is the K-STEP: the T*nk steps of a
+// launch are cut into G equal contiguous ranges, so a range covers the end of one tile (begun by the previous workgroup),
+// some whole tiles, and the beginning of another (finished by the next workgroup).  A tile that spans two workgroups is
+// NOT reduced from two partial sums (that would change the summation order): the first workgroup stores its raw
+// accumulators and raises a flag, the second one loads them and simply continues the k loop — the result is bit-identical
+// to the one-workgroup tile.  Every workgroup runs its BEGINNING fragment first (it depends on nobody), then its whole
+// tiles, and the CONTINUED fragment last, by which time the predecessor published long ago; the wait is a bounded spin.
+// Same flattened K-step stream, same K-step body and schedule as above.
+// Memory model: the XCDs' L2s are not coherent with each other inside a kernel.  The producer's accumulator stores are
+// followed by an agent-scope release fence (L2 write-back — cheap, because the begun fragment is the first thing a
+// workgroup does and its L2 holds nothing dirty yet) and the flag store; the consumer spins on the flag with relaxed
+// agent-scope loads, then an agent-scope acquire fence drops whatever stale lines of the buffer (from an earlier launch)
+// its own caches hold before it reads the accumulators.
+struct StreamKArgs {
+  float* part;
+  int32_t* flag;
+  int32_t epoch;
+};
+// Stream-K pays for its balance with L2 locality: workgroups sit at different k of different tiles, so operand slices
+// are no longer shared in time the way the lockstep rounds of the whole-tile form share them (measured on the padded C2
+// batch: 31.0 ms against 28.2).  It is therefore used only where whole tiles quantise badly: with T tiles on 256 CUs x 2
+// workgroups the whole-tile form takes 2*floor(T/512) + {0, 1 (<= 256 left: they run alone on their CUs), 2} single-tile
+// times against T/256 ideally; stream-K runs when that loss exceeds GDR_GEMM_STREAMK percent (default 12; 0 = never,
+// 1 = always).  The tile count comes from the caller's row hint when the real count lives on the device — a tuning
+// input only: both kernels are correct for any row count.
+static bool streamk_wanted(int64_t tiles) {
+  static const int pct = [] {
+    const char* e = getenv("GDR_GEMM_STREAMK");
+    return e ? atoi(e) : 12;
+  }();
+  if (pct <= 0) return false;
+  if (pct == 1) return true;
+  if (tiles < 512) return false;
+  const int64_t rem = tiles % 512;
+  const double whole = 2.0 * (double)(tiles / 512) + (rem == 0 ? 0.0 : rem <= 256 ? 1.0 : 2.0);
+  return whole / ((double)tiles / 256.0) - 1.0 > 0.01 * pct;
+}
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(const GemmArgs g, const int total_tiles_host,
+                                                                              const StreamKArgs sk) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDS_STRIDE + 2 * BN * LDS_STRIDE];
+  float* const As = smem;
+  float* const Bs = smem + 2 * BM * LDS_STRIDE;
+  unsigned bid = blockIdx.x;
+  {
+    const unsigned nblk = gridDim.x, q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int G = (int)gridDim.x;
+  const int tid = threadIdx.x;
+  const int lrow = tid >> 3;
+  const int lcol = (tid & 7) * 4;
+  const int st_off = lrow * LDS_STRIDE + lcol;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int a_rd = (wm * 64 + l31) * LDS_STRIDE + 4 * h;
+  const int b_rd = (wn * 64 + l31) * LDS_STRIDE + 4 * h;
+  const int nk = g.K / BK;
+  const int64_t Mrows = g.m_dev ? *g.m_dev : g.M;  // ragged batches: the row count is a device-side value <= g.M
+  const int tiles_m = (int)((Mrows + BM - 1) / BM);
+  const int total_tiles = g.m_dev ? tiles_m * g.tiles_n : total_tiles_host;
+
+  int64_t a_ld[4];  // element offsets from g.A / g.W — kept as integers: pointers that pass through the tile-crossing
+  int64_t w_ld[4];  // select lose their address space and the loads degrade to flat_load (vmcnt AND lgkmcnt)
+// tile index -> (row panel, column tile): supertiles of GM row panels x all column tiles, row-panel-fastest inside, so
+// that the 64 tiles an XCD works on at a time are ~8 row panels x 8 column tiles (16 operand panels through its L2)
+// instead of a few row panels x every column tile (N=3072: 27 panels).  GM travels in g.ksplit (unused by this kernel).
+#define P_TILE_MN(tile_, mt_, nt_)                                           \
+  {                                                                          \
+    const int per_ = g.ksplit * g.tiles_n;                                   \
+    const int grp_ = (tile_) / per_, loc_ = (tile_) - grp_ * per_;           \
+    const int gm_ = min(g.ksplit, tiles_m - grp_ * g.ksplit);                \
+    nt_ = loc_ / gm_;                                                        \
+    mt_ = grp_ * g.ksplit + (loc_ - nt_ * gm_);                              \
+  }
+#define P_SETPTRS(tile_)                                                     \
+  {                                                                          \
+    int mt_, nt_;                                                            \
+    P_TILE_MN(tile_, mt_, nt_)                                               \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                          \
+      int64_t ra_ = (int64_t)mt_ * BM + lrow + 32 * p;                       \
+      ra_ = ra_ < Mrows ? ra_ : Mrows - 1;                                   \
+      int rw_ = nt_ * BN + lrow + 32 * p;                                    \
+      rw_ = rw_ < g.N ? rw_ : g.N - 1;                                       \
+      a_ld[p] = ra_ * g.lda + lcol;                                          \
+      w_ld[p] = (int64_t)rw_ * g.ldw + lcol;                                 \
+    }                                                                        \
+  }
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define P_GLOAD                                          \
+  ra0 = *reinterpret_cast<const float4*>(g.A + a_ld[0]); \
+  ra1 = *reinterpret_cast<const float4*>(g.A + a_ld[1]); \
+  ra2 = *reinterpret_cast<const float4*>(g.A + a_ld[2]); \
+  ra3 = *reinterpret_cast<const float4*>(g.A + a_ld[3]); \
+  rb0 = *reinterpret_cast<const float4*>(g.W + w_ld[0]); \
+  rb1 = *reinterpret_cast<const float4*>(g.W + w_ld[1]); \
+  rb2 = *reinterpret_cast<const float4*>(g.W + w_ld[2]); \
+  rb3 = *reinterpret_cast<const float4*>(g.W + w_ld[3]);
+#define P_ADVANCE                                                            \
+  if (++ld_kt == ld_kend) { /* the load stream crosses into the next segment (or parks on the last one's start) */ \
+    ld_seg = ld_seg + 1 < nseg ? ld_seg + 1 : nseg - 1;                      \
+    SK_SEG(ld_seg, ld_tile, ld_kt, ld_kend)                                  \
+    P_SETPTRS(ld_tile)                                                       \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) a_ld[p] += (int64_t)ld_kt * BK, w_ld[p] += (int64_t)ld_kt * BK; \
+  } else {                                                                   \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) a_ld[p] += BK, w_ld[p] += BK; \
+  }
+#define P_LSTORE(buf_)                                                       \
+  {                                                                          \
+    float* a_ = As + (buf_)*BM * LDS_STRIDE + st_off;                        \
+    float* b_ = Bs + (buf_)*BN * LDS_STRIDE + st_off;                        \
+    *reinterpret_cast<float4*>(a_) = ra0;                                    \
+    *reinterpret_cast<float4*>(a_ + 32 * LDS_STRIDE) = ra1;                  \
+    *reinterpret_cast<float4*>(a_ + 64 * LDS_STRIDE) = ra2;                  \
+    *reinterpret_cast<float4*>(a_ + 96 * LDS_STRIDE) = ra3;                  \
+    *reinterpret_cast<float4*>(b_) = rb0;                                    \
+    *reinterpret_cast<float4*>(b_ + 32 * LDS_STRIDE) = rb1;                  \
+    *reinterpret_cast<float4*>(b_ + 64 * LDS_STRIDE) = rb2;                  \
+    *reinterpret_cast<float4*>(b_ + 96 * LDS_STRIDE) = rb3;                  \
+  }
+#define P_READ(A0, A1, B0, B1, ap, bp, jj)                                   \
+  A0 = *reinterpret_cast<const float4*>((ap) + 8 * (jj));                    \
+  A1 = *reinterpret_cast<const float4*>((ap) + 32 * LDS_STRIDE + 8 * (jj));  \
+  B0 = *reinterpret_cast<const float4*>((bp) + 8 * (jj));                    \
+  B1 = *reinterpret_cast<const float4*>((bp) + 32 * LDS_STRIDE + 8 * (jj));
+#define P_MFMA4(A0, A1, B0, B1, x_)                                                   \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x_, B0.x_, acc[0][0], 0, 0, 0); \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x_, B1.x_, acc[0][1], 0, 0, 0); \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x_, B0.x_, acc[1][0], 0, 0, 0); \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x_, B1.x_, acc[1][1], 0, 0, 0);
+#define P_MFMA16(A0, A1, B0, B1) \
+  P_MFMA4(A0, A1, B0, B1, x) P_MFMA4(A0, A1, B0, B1, y) P_MFMA4(A0, A1, B0, B1, z) P_MFMA4(A0, A1, B0, B1, w)
+
+  // ---- this workgroup's range of K-steps and its segments, in processing order:
+  //      [begun fragment: tile t_last, k 0..k_last) -> stored]  [whole tiles t_full0 .. t_full0+n_full)]
+  //      [continued fragment: tile t_first, k k_first..nk) <- loaded]
+  int t_first, k_first, t_last, k_last;
+  if (total_tiles >= G) {
+    const int64_t iters = (int64_t)total_tiles * nk;
+    const int64_t lo = (int64_t)bid * iters / G, hi = (int64_t)(bid + 1) * iters / G;
+    t_first = (int)(lo / nk), k_first = (int)(lo - (int64_t)t_first * nk);
+    t_last = (int)(hi / nk), k_last = (int)(hi - (int64_t)t_last * nk);
+  } else {  // fewer tiles than workgroups (device-side row count): whole tiles, one each
+    t_first = min((int)bid, total_tiles), k_first = 0;
+    t_last = min((int)bid + 1, total_tiles), k_last = 0;
+  }
+  const bool has_head = k_first != 0, has_tail = k_last != 0;
+  const int t_full0 = has_head ? t_first + 1 : t_first;
+  const int n_full = t_last - t_full0;
+  const int nseg = (has_tail ? 1 : 0) + n_full + (has_head ? 1 : 0);
+  // segment s -> tile, first K-step, end K-step
+#define SK_SEG(s_, tile_, k0_, k1_)                                   \
+  {                                                                   \
+    int q_ = (s_);                                                    \
+    if (has_tail && q_ == 0) {                                        \
+      tile_ = t_last, k0_ = 0, k1_ = k_last;                          \
+    } else {                                                          \
+      q_ -= has_tail ? 1 : 0;                                         \
+      if (q_ < n_full) {                                              \
+        tile_ = t_full0 + q_, k0_ = 0, k1_ = nk;                      \
+      } else {                                                        \
+        tile_ = t_first, k0_ = k_first, k1_ = nk;                     \
+      }                                                               \
+    }                                                                 \
+  }
+  if (nseg == 0) return;
+  // take over the predecessor's accumulators of the tile both share (the CONTINUED fragment)
+#define SK_TAKEOVER                                                                                               \
+  {                                                                                                               \
+    if (tid == 0) {                                                                                               \
+      int spins_ = 0;                                                                                             \
+      while (__hip_atomic_load(sk.flag + (bid - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {    \
+        __builtin_amdgcn_s_sleep(8);                                                                              \
+        if (++spins_ > (1 << 24)) __builtin_trap(); /* seconds: the predecessor never ran — fail, do not hang */  \
+      }                                                                                                           \
+    }                                                                                                             \
+    __syncthreads();                                                                                              \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* drop stale lines of the hand-off buffer from this XCD's caches */ \
+    const float4* src_ = reinterpret_cast<const float4*>(sk.part + (size_t)(bid - 1) * (BM * BN)) + tid;          \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)             \
+        _Pragma("unroll") for (int r4 = 0; r4 < 4; ++r4) {                                                        \
+      const float4 v_ = src_[((mi * 2 + ni) * 4 + r4) * GEMM_THREADS];                                            \
+      acc[mi][ni][4 * r4] = v_.x, acc[mi][ni][4 * r4 + 1] = v_.y, acc[mi][ni][4 * r4 + 2] = v_.z, acc[mi][ni][4 * r4 + 3] = v_.w; \
+    }                                                                                                             \
+  }
+  int ld_seg = 0, ld_kt, ld_kend, ld_tile;
+  SK_SEG(0, ld_tile, ld_kt, ld_kend)
+  P_SETPTRS(ld_tile)
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) a_ld[p] += (int64_t)ld_kt * BK, w_ld[p] += (int64_t)ld_kt * BK;
+  P_GLOAD
+  P_ADVANCE
+  P_LSTORE(0)
+  __syncthreads();
+  P_GLOAD
+  P_ADVANCE
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int seg = 0, tile, kt, kend, buf = 0;
+  SK_SEG(0, tile, kt, kend)  // never the continued fragment: with total_tiles >= G a range is at least nk steps long, so
+                             // something (a begun fragment or a whole tile) always precedes it
+  while (seg < nseg) {
+    {
+      const float* a = As + buf * BM * LDS_STRIDE + a_rd;
+      const float* b = Bs + buf * BN * LDS_STRIDE + b_rd;
+      float4 c0a0, c0a1, c0b0, c0b1, c1a0, c1a1, c1b0, c1b1, c2a0, c2a1, c2b0, c2b1, c3a0, c3a1, c3b0, c3b1;
+      P_READ(c0a0, c0a1, c0b0, c0b1, a, b, 0)
+      P_READ(c1a0, c1a1, c1b0, c1b1, a, b, 1)
+      P_LSTORE(buf ^ 1)
+      P_MFMA16(c0a0, c0a1, c0b0, c0b1)
+      P_READ(c2a0, c2a1, c2b0, c2b1, a, b, 2)
+      P_READ(c3a0, c3a1, c3b0, c3b1, a, b, 3)
+      P_GLOAD
+      P_MFMA16(c1a0, c1a1, c1b0, c1b1)
+      P_MFMA16(c2a0, c2a1, c2b0, c2b1)
+      P_MFMA16(c3a0, c3a1, c3b0, c3b1)
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // ds_read: chunks 0,1
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // ds_write
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ds_read: chunks 2,3
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // global_load
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 40, 0);
+    }
+    __syncthreads();  // stays in the MFMA block: the compiler hoists it above the trailing 40 MFMAs, which then cover the wait
+    P_ADVANCE
+    buf ^= 1;
+    if (++kt == kend) {
+     if (kend != nk) {
+      // a BEGUN fragment (always this workgroup's first segment): hand the raw accumulators to the successor
+      float4* dst = reinterpret_cast<float4*>(sk.part + (size_t)bid * (BM * BN)) + tid;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            dst[((mi * 2 + ni) * 4 + r4) * GEMM_THREADS] = make_float4(acc[mi][ni][4 * r4], acc[mi][ni][4 * r4 + 1],
+                                                                       acc[mi][ni][4 * r4 + 2], acc[mi][ni][4 * r4 + 3]);
+            acc[mi][ni][4 * r4] = acc[mi][ni][4 * r4 + 1] = acc[mi][ni][4 * r4 + 2] = acc[mi][ni][4 * r4 + 3] = 0.f;
+          }
+      __threadfence();  // release: the stores above are visible device-wide before the flag
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(sk.flag + bid, sk.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+     } else {
+      // epilogue of this tile: stores only (plus the residual / bias loads), no LDS — the other waves are already
+      // in the next tile's first K-step.  Accumulator map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+      int mt, nt;
+      P_TILE_MN(tile, mt, nt)
+      const int64_t m0 = (int64_t)mt * BM;
+      const int n0 = nt * BN;
+      if (m0 + BM <= Mrows && n0 + BN <= g.N) {
+        // interior tile: uniform branches only, so that the 64 residual loads go out as one batch and the 64 stores
+        // as another (per-element flag tests serialise them behind a vmcnt(0) each)
+        const int64_t mrow = m0 + wm * 64 + 4 * h;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {  // one column tile (32 accumulators) at a time: bounds the registers in flight
+          const int ncol = n0 + wn * 64 + ni * 32 + l31;
+          if (g.has_bias) {
+            const float bia = g.bias[ncol];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] += bia;
+          }
+          if (g.has_residual) {
+            const float* rp = g.residual + mrow * g.ldr + ncol;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] += rp[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * g.ldr];
+          }
+          if (g.act == ACT_RELU) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaxf(acc[mi][ni][r], 0.f);
+          } else if (g.act == ACT_GELU) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] = gelu_erf(acc[mi][ni][r]);
+          }
+          float* cp = g.C + mrow * g.ldc + ncol;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              cp[(int64_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc] = acc[mi][ni][r];
+              acc[mi][ni][r] = 0.f;
+            }
+        }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int n = n0 + wn * 64 + ni * 32 + l31;
+          const bool n_ok = n < g.N;
+          const float bia = (g.has_bias && n_ok) ? g.bias[n] : 0.f;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+              float v = acc[mi][ni][r] + bia;
+              acc[mi][ni][r] = 0.f;
+              if (!n_ok || m >= Mrows) continue;
+              if (g.has_residual) v += g.residual[m * g.ldr + n];
+              if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
+              if (g.act == ACT_GELU) v = gelu_erf(v);
+              g.C[m * g.ldc + n] = v;
+            }
+          }
+        }
+      }
+     }
+      if (++seg < nseg) {
+        SK_SEG(seg, tile, kt, kend)
+        if (kt != 0) SK_TAKEOVER  // the CONTINUED fragment (always last)
+      }
+    }
+  }
+#undef SK_SEG
+#undef SK_TAKEOVER
+#undef P_TILE_MN
+#undef P_SETPTRS
+#undef P_GLOAD
+#undef P_ADVANCE
+#undef P_LSTORE
+#undef P_READ
+#undef P_MFMA4
+#undef P_MFMA16
+}
+
 template <int EPI, bool BF16 = false>
 static int launch(const GemmArgs& g, int64_t tiles_m, hipStream_t stream) {
   const int64_t blocks = tiles_m * g.tiles_n;
@@ -672,7 +1024,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                       int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
                       hipStream_t stream) {
-  return launch_linear_f32_ws(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, residual, ldr, nullptr, 0, stream);
+  return launch_linear_f32_ws(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, residual, ldr, nullptr, 0, stream, nullptr);
 }
 
 // With a scratch buffer, linears whose tile grid cannot fill the chip (decode: M = batch*beams rows) are split
@@ -704,7 +1056,7 @@ int launch_linear_f32_ws_dev(const float* A, int64_t lda, const float* W, int64_
 
 int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                          int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
-                         float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream) {
+                         float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream, StreamK* sk) {
   if (M == 0) return GDR_OK;  // empty batch: nothing to do (pointers of empty tensors may be null)
   GDR_CHECK_ARG(A && W && C, "linear: null pointer");
   GDR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
@@ -816,6 +1168,12 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
       // outputs only.  Time is unchanged either way (the kernel is MFMA-bound); this is traffic and energy.
       g.ksplit = gm_env > 0 ? gm_env : (g.tiles_n >= 12 ? 8 : 1);
     }
+    if (sk && streamk_wanted(tiles)) {
+      const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch};
+      hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3((unsigned)SLOTS), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
+      GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel");
+      return GDR_OK;
+    }
     hipLaunchKernelGGL(gemm_nt_f32_persistent_kernel, dim3((unsigned)SLOTS), dim3(GEMM_THREADS), 0, stream, g, (int)tiles);
     GDR_CHECK_LAUNCH("gemm_nt_f32_persistent_kernel");
     return GDR_OK;
@@ -830,7 +1188,7 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
 // know it (< 0: unknown, M_max is used) — only the opt-in profiler's flop accounting reads it.
 int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M_max,
                           const int64_t* m_dev, int N, int K, int epilogue, const float* bias, const float* residual,
-                          int64_t ldr, int64_t prof_rows, hipStream_t stream) {
+                          int64_t ldr, int64_t prof_rows, hipStream_t stream, StreamK* sk) {
   if (M_max == 0) return GDR_OK;
   GDR_CHECK_ARG(A && W && C && m_dev, "linear(dev rows): null pointer");
   GDR_CHECK_ARG(M_max > 0 && N > 0 && K > 0 && K % BK == 0, "linear(dev rows): bad shape M<=%lld N=%d K=%d (K %% 32 == 0)",
@@ -857,6 +1215,13 @@ int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t l
   ProfScope prof(PROF_LINEAR, 2.0 * (double)(prof_rows >= 0 ? prof_rows : M_max) * (double)N * (double)K, stream);
   if (tiles > 512) {
     g.ksplit = g.tiles_n >= 12 ? 8 : 1;  // supertile height, as in launch_linear_f32_ws
+    const int64_t tiles_live = prof_rows >= 0 ? ((prof_rows + BM - 1) / BM) * g.tiles_n : tiles;
+    if (sk && streamk_wanted(tiles_live)) {
+      const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch};
+      hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3(512), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
+      GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel(dev rows)");
+      return GDR_OK;
+    }
     hipLaunchKernelGGL(gemm_nt_f32_persistent_kernel, dim3(512), dim3(GEMM_THREADS), 0, stream, g, (int)tiles);
     GDR_CHECK_LAUNCH("gemm_nt_f32_persistent_kernel(dev rows)");
     return GDR_OK;
