@@ -90,13 +90,14 @@ int launch_sim_gemm(const void* D, int64_t N, const void* Q, int B, int d, const
                     hipStream_t stream);
 
 int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
-                       int K, int epilogue, const float* bias, const float* residual, int64_t ldr, hipStream_t stream);
+                       int K, int epilogue, const float* bias, const float* residual, int64_t ldr, hipStream_t stream,
+                       const int64_t* m_dev = nullptr);
 int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev = nullptr);
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
-                            int64_t ldr, int out_bf16, hipStream_t stream);
+                            int64_t ldr, int out_bf16, hipStream_t stream, const int64_t* m_dev = nullptr);
 int launch_sim_bf16_glds(const void* D, int64_t N, const void* Q, int B, int d, const SimEpilogue& ep, int64_t n_doc_tiles,
                          hipStream_t stream);
 int launch_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, hipStream_t stream);

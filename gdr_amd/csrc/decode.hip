@@ -688,9 +688,28 @@ struct SideLease {
   }
 };
 
+// One linear of the decode path.  fp32: the split-K / small-tile launcher (device-side row count when m_dev is given).
+// bf16 precision mode (BASELINE config C5): W points to bf16 data, the activation operand is rounded to bf16 into `abf`
+// (RNE) and the GEMM accumulates in fp32; bias / residual / output stay fp32.
+static int dec_linear(bool bf16, void* abf, const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
+                      int64_t M, const int64_t* m_dev, int N, int K, int epi, const float* bias, const float* res, int64_t ldr,
+                      float* skw, hipStream_t st) {
+  if (!bf16)
+    return m_dev ? launch_linear_f32_ws_dev(A, lda, W, ldw, C, ldc, M, m_dev, N, K, epi, bias, res, ldr, skw, SPLITK_WS_BYTES, st)
+                 : launch_linear_f32_ws(A, lda, W, ldw, C, ldc, M, N, K, epi, bias, res, ldr, skw, SPLITK_WS_BYTES, st);
+  if (M == 0) return GDR_OK;
+  GDR_CHECK_ARG(lda == K && K % 8 == 0, "decode(bf16): the activation operand must be dense with K %% 8 == 0");
+  if (int rc = launch_cast_f32_bf16(A, abf, M * (int64_t)K, st)) return rc;
+  return launch_linear_bf16(abf, K, W, ldw, C, ldc, M, N, K, epi, bias, res, ldr, st, m_dev);
+}
+// element offset into a linear weight (fp32 or bf16 storage)
+static const float* w_at(const float* W, size_t elems, bool bf16) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(W) + elems * (bf16 ? 2 : 4));
+}
+
 // ------------------------------------------------------------------------------------------ model workspace
 struct GenWs {
-  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, total;
+  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, abf, abf2, total;
 };
 
 static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
@@ -718,6 +737,9 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
   g.ff2 = carve(o, 4 * rows * (size_t)w.adaptor_ff);
   g.splitk2 = carve(o, SPLITK_WS_BYTES);
   g.qkv_c = carve(o, 4 * rows * 3 * d);                 // prefix-table mode: (q,k,v) of the compacted rows
+  const size_t abf_main = rows * ffw > (size_t)bd.B * L * d ? rows * ffw : (size_t)bd.B * L * d;
+  g.abf = carve(o, 2 * abf_main);                       // bf16 mode: the rounded activation operand of a linear (main stream)
+  g.abf2 = carve(o, 2 * rows * ffw);                    //            ... of the adaptor chain (side stream)
   g.total = o;
   return g;
 }
@@ -731,13 +753,12 @@ extern "C" size_t gdr_t5_generate_workspace_bytes(const GdrT5DecoderWeights* w, 
   return gdr::gen_ws(*w, bd, L).total;
 }
 
-extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B,
-                               int L, int num_beams, int max_length, double length_penalty,
-                               int num_return_sequences, const GdrTrie* trie, const GdrPrefixTable* ptab,
-                               int64_t* out_ids, int32_t* out_len, double* out_scores, float* step_scores,
-                               int32_t* step_tokens, void* workspace, size_t workspace_bytes, void* stream_) {
-  using namespace gdr;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+namespace gdr {
+static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B, int L,
+                         int num_beams, int max_length, double length_penalty, int num_return_sequences,
+                         const GdrTrie* trie, const GdrPrefixTable* ptab, int64_t* out_ids, int32_t* out_len,
+                         double* out_scores, float* step_scores, int32_t* step_tokens, void* workspace,
+                         size_t workspace_bytes, bool bf16, hipStream_t stream) {
   GDR_CHECK_ARG(w && enc_hidden && enc_mask && out_ids && out_len && out_scores && workspace, "generate: null pointer");
   const GdrT5Dims& dm = w->dims;
   GDR_CHECK_ARG(!trie || (trie->child && trie->eos_ok && trie->n_nodes > 0), "generate: bad trie");
@@ -776,6 +797,9 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   float *dcache = F(g.dcache), *acache = F(g.acache), *crosskv = F(g.crosskv), *xd = F(g.xd), *xa = F(g.xa),
         *nx = F(g.nx), *ctx = F(g.ctx), *qc = F(g.qc), *ff = F(g.ff), *tmp = F(g.tmp), *A = F(g.A), *hl = F(g.hl),
         *skw = F(g.splitk), *ctx2 = F(g.ctx2), *ff2 = F(g.ff2), *skw2 = F(g.splitk2), *qkv_c = F(g.qkv_c);
+  void *abf = base + g.abf, *abf2 = base + g.abf2;
+  GDR_CHECK_ARG(!bf16 || (dm.d_model % 8 == 0 && dm.d_ff % 8 == 0 && (dm.num_heads * dm.d_kv) % 8 == 0 && w->adaptor_ff % 8 == 0),
+                "generate(bf16): dims must be multiples of 8");
   const int d = dm.d_model, H = dm.num_heads, dk = dm.d_kv, inner = H * dk;
   const int rows = B * num_beams, V1 = bd.V + 1;
   const int aH = w->adaptor_nhead, ahd = d / aH, aff = w->adaptor_ff;
@@ -784,8 +808,10 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
   const size_t dlayer = (size_t)max_length * dslab, alayer = (size_t)max_length * aslab;
   const size_t ckv_layer = (size_t)B * L * 2 * inner;
 
-#define LIN(...) launch_linear_f32_ws(__VA_ARGS__, skw, SPLITK_WS_BYTES, stream)
-#define LIN2(...) launch_linear_f32_ws(__VA_ARGS__, skw2, SPLITK_WS_BYTES, as)
+#define LIN(A_, lda_, W_, ldw_, C_, ldc_, M_, N_, K_, epi_, bias_, res_, ldr_) \
+  dec_linear(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream)
+#define LIN2(A_, lda_, W_, ldw_, C_, ldc_, M_, N_, K_, epi_, bias_, res_, ldr_) \
+  dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw2, as)
 #define GDR_TRY(x)        \
   do {                    \
     if ((rc = (x))) return rc; \
@@ -850,7 +876,7 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
                          bb.miss_rows, nm, d / 4, dm.vocab_size, xa);
       GDR_CHECK_LAUNCH("embed_rows_kernel");
 #define LIN2D(A_, lda_, W_, ldw_, C_, ldc_, N_, K_, epi_, bias_, res_, ldr_) \
-  launch_linear_f32_ws_dev(A_, lda_, W_, ldw_, C_, ldc_, rows, nm, N_, K_, epi_, bias_, res_, ldr_, skw2, SPLITK_WS_BYTES, as)
+  dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, rows, nm, N_, K_, epi_, bias_, res_, ldr_, skw2, as)
       for (int l = 0; l < w->adaptor_layers; ++l) {
         const GdrAdaptorLayer& al = w->alayers[l];
         float* cache = acache + l * alayer;
@@ -877,7 +903,8 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
         GDR_TRY(launch_layernorm_dev(xa, al.ln3_w, al.ln3_b, xa, nm, rows, d, w->adaptor_eps, nullptr, as));
       }
       // the head GEMM of the compacted rows belongs to the same chain (it needs nothing from the decoder stack)
-      GDR_TRY(LIN2D(xa, d, w->head_w + (size_t)s * V1 * d * d, d, A, (int64_t)V1 * d, V1 * d, d, GDR_EPI_NONE, nullptr, nullptr, 0));
+      GDR_TRY(LIN2D(xa, d, w_at(w->head_w, (size_t)s * V1 * d * d, bf16), d, A, (int64_t)V1 * d, V1 * d, d, GDR_EPI_NONE, nullptr,
+                    nullptr, 0));
 #undef LIN2D
     }
     if (ss.ok) {
@@ -929,7 +956,7 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
       return GDR_EHIP;
     }
     // ---------------- head: last position, unmasked columns only (modeling_t5.py:1634-1646)
-    const float* hw = w->head_w + (size_t)s * V1 * d * d;
+    const float* hw = w_at(w->head_w, (size_t)s * V1 * d * d, bf16);
     const float* he = w->head_e + (size_t)s * V1 * d;
     if (!ptab) {
       GDR_TRY(LIN(xa, d, hw, d, A, (int64_t)V1 * d, rows, V1 * d, d, GDR_EPI_NONE, nullptr, nullptr, 0));
@@ -951,6 +978,27 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
 #undef LIN
 #undef LIN2
 }
+}  // namespace gdr
+
+extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B,
+                               int L, int num_beams, int max_length, double length_penalty,
+                               int num_return_sequences, const GdrTrie* trie, const GdrPrefixTable* ptab,
+                               int64_t* out_ids, int32_t* out_len, double* out_scores, float* step_scores,
+                               int32_t* step_tokens, void* workspace, size_t workspace_bytes, void* stream_) {
+  return gdr::generate_impl(w, enc_hidden, enc_mask, B, L, num_beams, max_length, length_penalty, num_return_sequences, trie,
+                            ptab, out_ids, out_len, out_scores, step_scores, step_tokens, workspace, workspace_bytes, false,
+                            static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int gdr_t5_generate_bf16(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B,
+                                    int L, int num_beams, int max_length, double length_penalty,
+                                    int num_return_sequences, const GdrTrie* trie, const GdrPrefixTable* ptab,
+                                    int64_t* out_ids, int32_t* out_len, double* out_scores, float* step_scores,
+                                    int32_t* step_tokens, void* workspace, size_t workspace_bytes, void* stream_) {
+  return gdr::generate_impl(w, enc_hidden, enc_mask, B, L, num_beams, max_length, length_penalty, num_return_sequences, trie,
+                            ptab, out_ids, out_len, out_scores, step_scores, step_tokens, workspace, workspace_bytes, true,
+                            static_cast<hipStream_t>(stream_));
+}
 
 // ------------------------------------------------------------------------------------------------ prefix table build
 // Level by level over the trie (nodes in breadth-first order, so a level is a contiguous row range and the GEMMs write
@@ -959,7 +1007,7 @@ extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hi
 // bias gives W[node] = A + E.  Same arithmetic as the in-call chain of gdr_t5_generate, at corpus scale.
 namespace gdr {
 struct TabWs {
-  size_t xa, tmp, ctx, ff, splitk, total;
+  size_t xa, tmp, ctx, ff, splitk, abf, total;
 };
 static TabWs tab_ws(const GdrT5DecoderWeights& w, int max_level_nodes) {
   TabWs t{};
@@ -970,6 +1018,7 @@ static TabWs tab_ws(const GdrT5DecoderWeights& w, int max_level_nodes) {
   t.ctx = carve(o, 4 * n * d);
   t.ff = carve(o, 4 * n * (size_t)w.adaptor_ff);
   t.splitk = carve(o, SPLITK_WS_BYTES);
+  t.abf = carve(o, 2 * n * (size_t)(w.adaptor_ff > (int)d ? w.adaptor_ff : (int)d));
   t.total = o;
   return t;
 }
@@ -980,11 +1029,10 @@ extern "C" size_t gdr_t5_prefix_table_workspace_bytes(const GdrT5DecoderWeights*
   return gdr::tab_ws(*w, max_level_nodes).total;
 }
 
-extern "C" int gdr_t5_prefix_table_build(const GdrT5DecoderWeights* w, int n_levels, const int32_t* level_off,
-                                         const int64_t* node_tok, const int32_t* node_anc, float* kv, float* W,
-                                         void* workspace, size_t workspace_bytes, void* stream_) {
-  using namespace gdr;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+namespace gdr {
+static int table_build_impl(const GdrT5DecoderWeights* w, int n_levels, const int32_t* level_off, const int64_t* node_tok,
+                            const int32_t* node_anc, float* kv, float* W, void* workspace, size_t workspace_bytes, bool bf16,
+                            hipStream_t stream) {
   GDR_CHECK_ARG(w && level_off && node_tok && node_anc && kv && W && workspace, "prefix_table_build: null pointer");
   const GdrT5Dims& dm = w->dims;
   GDR_CHECK_ARG(n_levels >= 1 && n_levels <= w->max_out_len - 1 && n_levels <= MAXLEN_CAP,
@@ -1006,11 +1054,13 @@ extern "C" int gdr_t5_prefix_table_build(const GdrT5DecoderWeights* w, int n_lev
   char* base = static_cast<char*>(workspace);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
   float *xa = F(t.xa), *tmp = F(t.tmp), *ctx = F(t.ctx), *ff = F(t.ff), *skw = F(t.splitk);
+  void* abf = base + t.abf;
   const int64_t n_table = level_off[n_levels];
   const size_t layer_stride = (size_t)n_table * 3 * d;
   const BucketLut lut = make_bucket_lut(dm.rel_buckets, dm.rel_max_distance);
   int rc;
-#define TLIN(...) launch_linear_f32_ws(__VA_ARGS__, skw, SPLITK_WS_BYTES, stream)
+#define TLIN(A_, lda_, W_, ldw_, C_, ldc_, M_, N_, K_, epi_, bias_, res_, ldr_) \
+  dec_linear(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream)
 #define T_TRY(x)              \
   do {                        \
     if ((rc = (x))) return rc; \
@@ -1042,13 +1092,28 @@ extern "C" int gdr_t5_prefix_table_build(const GdrT5DecoderWeights* w, int n_lev
       T_TRY(launch_layernorm(xa, al.ln3_w, al.ln3_b, xa, n, d, w->adaptor_eps, nullptr, stream));
     }
     // W[node][c][i] = sum_k xa[node][k] * head_w[s][c][i][k] + head_e[s][c][i]      (modeling_t5.py:1634-1639)
-    T_TRY(TLIN(xa, d, w->head_w + (size_t)s * V1 * d * d, d, W + (size_t)lo * V1 * d, (int64_t)V1 * d, n, V1 * d, d, GDR_EPI_BIAS,
-               w->head_e + (size_t)s * V1 * d, nullptr, 0));
+    T_TRY(TLIN(xa, d, w_at(w->head_w, (size_t)s * V1 * d * d, bf16), d, W + (size_t)lo * V1 * d, (int64_t)V1 * d, n, V1 * d, d,
+               GDR_EPI_BIAS, w->head_e + (size_t)s * V1 * d, nullptr, 0));
     anc_off += (size_t)n * (s + 1);
   }
 #undef TLIN
 #undef T_TRY
   return GDR_OK;
+}
+}  // namespace gdr
+
+extern "C" int gdr_t5_prefix_table_build(const GdrT5DecoderWeights* w, int n_levels, const int32_t* level_off,
+                                         const int64_t* node_tok, const int32_t* node_anc, float* kv, float* W,
+                                         void* workspace, size_t workspace_bytes, void* stream_) {
+  return gdr::table_build_impl(w, n_levels, level_off, node_tok, node_anc, kv, W, workspace, workspace_bytes, false,
+                               static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int gdr_t5_prefix_table_build_bf16(const GdrT5DecoderWeights* w, int n_levels, const int32_t* level_off,
+                                              const int64_t* node_tok, const int32_t* node_anc, float* kv, float* W,
+                                              void* workspace, size_t workspace_bytes, void* stream_) {
+  return gdr::table_build_impl(w, n_levels, level_off, node_tok, node_anc, kv, W, workspace, workspace_bytes, true,
+                               static_cast<hipStream_t>(stream_));
 }
 
 extern "C" size_t gdr_beam_search_table_workspace_bytes(int B, int num_beams, int max_length, int out_vocab) {

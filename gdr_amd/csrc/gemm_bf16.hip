@@ -28,6 +28,7 @@ struct Bf16GemmArgs {
   int N, K, tiles_n;
   int has_bias, has_residual, act;  // act: 0 none, 1 relu, 2 gelu
   int out_bf16;
+  const int64_t* m_dev;  // linear only, may be null: live row count on the device (<= M); tiles past it exit at once
   // similarity epilogues (EPI 1 sample / 2 filter): A = queries [B,d] (lane role), W = docs [N,d] (register role);
   // tiles_n then counts QUERY tiles (fastest in the grid: the workgroups that share a doc tile are neighbours)
   SimEpilogue sim;
@@ -62,6 +63,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     }
     n0 = dt * 128;
   }
+  const int64_t Mv = (EPI == 0 && g.m_dev) ? *g.m_dev : g.M;
+  if (EPI == 0 && m0 >= Mv) return;  // uniform
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int r16 = lane & 15, q4 = lane >> 4;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     const int row = (wave * 4 + i) * 8 + srow;
     const int chunk = schunk ^ ((row >> 1) & 7);
     int64_t ra = m0 + row;
-    ra = ra < g.M ? ra : g.M - 1;  // rows past the edge are computed and discarded
+    ra = ra < Mv ? ra : Mv - 1;  // rows past the edge are computed and discarded
     int64_t rw = n0 + row;
     rw = rw < g.Nrows ? rw : g.Nrows - 1;
     a_src[i] = g.A + (ra * g.lda) * 2 + chunk * 16;
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       const int64_t q = m0 + wm * 64 + mi * 16 + r16;
-      if (q >= g.M) continue;
+      if (q >= Mv) continue;
       float* cv = g.sim.cand_val + q * g.sim.cap + slot_base;
       int32_t* ci = g.sim.cand_idx + q * g.sim.cap + slot_base;
 #pragma unroll
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       const int64_t q = m0 + wm * 64 + mi * 16 + r16;
-      const bool q_ok = q < g.M;
+      const bool q_ok = q < Mv;
       const float thr = q_ok ? g.sim.thr[q] : INFINITY;
       unsigned keep = 0u;  // bit 4*ni + r
 #pragma unroll
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     return;
   }
   // ---- epilogue: row m = block*16 + lane&15, columns n = block*16 + 4*(lane>>4) + 0..3 ----
-  const bool interior = m0 + 128 <= g.M && n0 + 128 <= g.N && (g.ldc & 3) == 0 &&
+  const bool interior = m0 + 128 <= Mv && n0 + 128 <= g.N && (g.ldc & 3) == 0 &&
                         (!g.has_residual || (g.ldr & 3) == 0);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (m >= g.M || n + j >= g.N) continue;
+          if (m >= Mv || n + j >= g.N) continue;
           float x = v[j];
           if (g.has_bias) x += g.bias[n + j];
           if (g.has_residual) x += g.residual[m * g.ldr + n + j];
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
 // Returns 1 if the shape is not served here (caller falls back to the generic core), 0 on launch, < 0 on error.
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
-                            int64_t ldr, int out_bf16, hipStream_t stream) {
+                            int64_t ldr, int out_bf16, hipStream_t stream, const int64_t* m_dev) {
   if (K % 64 != 0 || lda % 8 != 0 || ldw % 8 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return 1;  // 16-byte DMA pieces
   if (((uintptr_t)C & 15) || (has_bias && ((uintptr_t)bias & 15)) || (has_residual && ((uintptr_t)residual & 15))) return 1;
   Bf16GemmArgs g{};
@@ -253,6 +256,7 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
   g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr, g.M = M, g.N = N, g.Nrows = N, g.K = K;
   g.tiles_n = (N + 127) / 128;
   g.has_bias = has_bias, g.has_residual = has_residual, g.act = act, g.out_bf16 = out_bf16;
+  g.m_dev = m_dev;
   const int64_t blocks = ((M + 127) / 128) * g.tiles_n;
   if (blocks <= 0) return 0;
   if (blocks > 0x7fffffffLL) {

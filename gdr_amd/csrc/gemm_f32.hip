@@ -1232,7 +1232,8 @@ int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t l
 // bf16 operands (fp32 accumulate, fp32 output): the precision mode of config C5.  Same tiling as the fp32 linears on
 // v_mfma_f32_32x32x16_bf16; no split-K form.
 int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
-                       int K, int epilogue, const float* bias, const float* residual, int64_t ldr, hipStream_t stream) {
+                       int K, int epilogue, const float* bias, const float* residual, int64_t ldr, hipStream_t stream,
+                       const int64_t* m_dev) {
   if (M == 0) return GDR_OK;
   GDR_CHECK_ARG(A && W && C, "linear_bf16: null pointer");
   GDR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear_bf16: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
@@ -1266,9 +1267,10 @@ int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, f
   }();
   if (glds_on) {
     const int rc = launch_linear_bf16_glds(A, lda, W, ldw, C, ldc, M, N, K, needs_bias, needs_res, g.act, bias, residual, ldr, 0,
-                                           stream);
+                                           stream, m_dev);
     if (rc <= 0) return rc;
   }
+  g.m_dev = m_dev;
   return launch<EPI_LINEAR, true>(g, (M + BM - 1) / BM, stream);
 }
 

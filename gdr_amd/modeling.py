@@ -61,7 +61,7 @@ class GDRModel:
     inference only.  Construct from a reference-style state_dict (SURVEY Appendix C key names)."""
 
     def __init__(self, cfg: GDRConfig, state_dict, device="cuda:0", with_decoder=True, trie=None, ragged=False,
-                 prefix_trie=None):
+                 prefix_trie=None, dtype=torch.float32):
         """trie: optional codec.Trie — enables the NCI trie constraint of the reference's earlier
         generation_utils_previous.py:714-729 (the shipped generate() ignores `decode_tree`).
         ragged: generate() skips the PAD rows of the encoder (gdr_t5_encoder_forward_ragged).  Decoded ids, scores and the
@@ -71,14 +71,17 @@ class GDRModel:
         prefix_trie: optional codec.Trie over the corpus' docids — builds the device prefix table (ops.PrefixTable) at
         load: beams whose prefix is a node of that trie read the query-independent adaptor/head results from it instead of
         recomputing them (modeling_t5.py:1618-1639); other beams are computed as before.  Same logits up to fp32
-        summation order.  When `trie` (the constraint) is given too it must be the same trie."""
+        summation order.  When `trie` (the constraint) is given too it must be the same trie.
+        dtype=torch.bfloat16: BASELINE config C5's precision mode (the reference has none: precision=32) — every linear of
+        encoder, decoder, adaptor and head takes bf16 operands with fp32 accumulate; all other arithmetic stays fp32."""
         self.config = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _ffi.GdrError("GDRModel needs a CUDA (ROCm) device; there is no CPU path")
         sd = strip_lightning_prefix(state_dict)
-        self.enc = ops.T5EncoderHandle(cfg, sd, self.device)
-        self.dec = ops.T5DecoderHandle(cfg, sd, self.device) if with_decoder else None
+        self.dtype = dtype
+        self.enc = ops.T5EncoderHandle(cfg, sd, self.device, dtype=dtype)
+        self.dec = ops.T5DecoderHandle(cfg, sd, self.device, dtype=dtype) if with_decoder else None
         self.prefix_table = None
         if prefix_trie is not None:
             if self.dec is None:
@@ -90,7 +93,7 @@ class GDRModel:
             self.trie = None
         else:                                     # the constraint shares the table's breadth-first arrays
             self.trie = self.prefix_table.device_trie if self.prefix_table is not None else ops.DeviceTrie(trie, self.device)
-        self.ragged = bool(ragged)
+        self.ragged = bool(ragged) and dtype == torch.float32      # the ragged encoder form is fp32 only
         self.training = False
 
     def eval(self):

@@ -334,13 +334,25 @@ class T5DecoderHandle:
         head_w[p][c'][i][k] for the V+1 columns that survive the positional mask (modeling_t5.py:1553-1557);
       * the adaptor's cross-attention over its single learned key folded into cross_const (softmax of one key = 1)."""
 
-    def __init__(self, cfg, sd, device):
-        self.cfg, self.device = cfg, device
+    def __init__(self, cfg, sd, device, dtype=torch.float32):
+        """dtype=torch.bfloat16: the C5 precision mode — every linear weight (decoder, adaptor, head slices) is rounded to
+        bf16 on the device and generate() calls gdr_t5_generate_bf16; everything else stays fp32."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("T5DecoderHandle: dtype must be float32 or bfloat16")
+        self.cfg, self.device, self.dtype = cfg, device, dtype
         keep = []
 
         def dev(t):
             t = t.detach().to(device=device, dtype=torch.float32).contiguous()
             keep.append(t)
+            return t
+
+        def lin(t):                                      # a linear's weight: bf16 copy in the C5 mode
+            t = dev(t)
+            if dtype == torch.bfloat16:
+                keep.pop()
+                t = to_bf16(t)
+                keep.append(t)
             return t
 
         d, V, Vd, ml = cfg.d_model, cfg.output_vocab_size, cfg.decode_vocab_size, cfg.max_output_length
@@ -354,48 +366,50 @@ class T5DecoderHandle:
             p = f"decoder.block.{i}.layer."
             L = self._layers[i]
             L.ln_self = dev(sd[p + "0.layer_norm.weight"]).data_ptr()
-            L.wqkv = dev(torch.cat([sd[p + "0.SelfAttention.q.weight"], sd[p + "0.SelfAttention.k.weight"],
+            L.wqkv = lin(torch.cat([sd[p + "0.SelfAttention.q.weight"], sd[p + "0.SelfAttention.k.weight"],
                                     sd[p + "0.SelfAttention.v.weight"]], dim=0)).data_ptr()
-            L.wo = dev(sd[p + "0.SelfAttention.o.weight"]).data_ptr()
+            L.wo = lin(sd[p + "0.SelfAttention.o.weight"]).data_ptr()
             L.ln_cross = dev(sd[p + "1.layer_norm.weight"]).data_ptr()
-            L.wq_c = dev(sd[p + "1.EncDecAttention.q.weight"]).data_ptr()
-            L.wkv_c = dev(torch.cat([sd[p + "1.EncDecAttention.k.weight"], sd[p + "1.EncDecAttention.v.weight"]],
+            L.wq_c = lin(sd[p + "1.EncDecAttention.q.weight"]).data_ptr()
+            L.wkv_c = lin(torch.cat([sd[p + "1.EncDecAttention.k.weight"], sd[p + "1.EncDecAttention.v.weight"]],
                                     dim=0)).data_ptr()
-            L.wo_c = dev(sd[p + "1.EncDecAttention.o.weight"]).data_ptr()
+            L.wo_c = lin(sd[p + "1.EncDecAttention.o.weight"]).data_ptr()
             L.ln_ff = dev(sd[p + "2.layer_norm.weight"]).data_ptr()
-            L.wi = dev(sd[p + "2.DenseReluDense.wi.weight"]).data_ptr()
-            L.wo_ff = dev(sd[p + "2.DenseReluDense.wo.weight"]).data_ptr()
+            L.wi = lin(sd[p + "2.DenseReluDense.wi.weight"]).data_ptr()
+            L.wo_ff = lin(sd[p + "2.DenseReluDense.wo.weight"]).data_ptr()
         mem = dev(sd["adaptor_embeddings"]).view(1, d)
         self._alayers = (_ffi.GdrAdaptorLayer * na)()
         aff = None
         for i in range(na):
             p = f"adaptor.layers.{i}."
             A = self._alayers[i]
-            A.in_w = dev(sd[p + "self_attn.in_proj_weight"]).data_ptr()
+            A.in_w = lin(sd[p + "self_attn.in_proj_weight"]).data_ptr()
             A.in_b = dev(sd[p + "self_attn.in_proj_bias"]).data_ptr()
-            A.out_w = dev(sd[p + "self_attn.out_proj.weight"]).data_ptr()
+            A.out_w = lin(sd[p + "self_attn.out_proj.weight"]).data_ptr()
             A.out_b = dev(sd[p + "self_attn.out_proj.bias"]).data_ptr()
             cw, cb = dev(sd[p + "multihead_attn.in_proj_weight"]), dev(sd[p + "multihead_attn.in_proj_bias"])
-            vmem = linear(mem, cw[2 * d:], epilogue=_ffi.EPI_BIAS, bias=cb[2 * d:].contiguous())
-            cc = linear(vmem, dev(sd[p + "multihead_attn.out_proj.weight"]), epilogue=_ffi.EPI_BIAS,
-                        bias=dev(sd[p + "multihead_attn.out_proj.bias"]))
+            flin = linear_bf16 if dtype == torch.bfloat16 else linear        # the two folded linears round like all others
+            vmem = flin(mem, cw[2 * d:].contiguous(), epilogue=_ffi.EPI_BIAS, bias=cb[2 * d:].contiguous())
+            cc = flin(vmem, dev(sd[p + "multihead_attn.out_proj.weight"]), epilogue=_ffi.EPI_BIAS,
+                      bias=dev(sd[p + "multihead_attn.out_proj.bias"]))
             keep.append(cc)
             A.cross_const = cc.data_ptr()
             for n in ("1", "2", "3"):
                 setattr(A, f"ln{n}_w", dev(sd[p + f"norm{n}.weight"]).data_ptr())
                 setattr(A, f"ln{n}_b", dev(sd[p + f"norm{n}.bias"]).data_ptr())
-            l1 = dev(sd[p + "linear1.weight"])
+            l1 = lin(sd[p + "linear1.weight"])
             aff = l1.shape[0]
             A.lin1_w, A.lin1_b = l1.data_ptr(), dev(sd[p + "linear1.bias"]).data_ptr()
-            A.lin2_w, A.lin2_b = dev(sd[p + "linear2.weight"]).data_ptr(), dev(sd[p + "linear2.bias"]).data_ptr()
+            A.lin2_w, A.lin2_b = lin(sd[p + "linear2.weight"]).data_ptr(), dev(sd[p + "linear2.bias"]).data_ptr()
         # head slices
         P = ml - 1
         cols = torch.tensor([[p * V + 2 + c for c in range(V)] + [1] for p in range(P)], dtype=torch.long, device=device)
         Wfull = sd["adaptor_linear.weight"].detach().to(device=device, dtype=torch.float32)
         W = Wfull.view(d, Vd, d)
-        self.head_w = torch.empty((P, V + 1, d, d), dtype=torch.float32, device=device)
+        self.head_w = torch.empty((P, V + 1, d, d), dtype=dtype, device=device)
         for p in range(P):                                   # per position: bounded temporaries
-            self.head_w[p] = W[:, cols[p], :].permute(1, 0, 2)
+            sl = W[:, cols[p], :].permute(1, 0, 2).contiguous()
+            self.head_w[p] = to_bf16(sl) if dtype == torch.bfloat16 else sl
         del W, Wfull                                         # only the slices stay resident
         self.head_e = dev(sd["lm_head.weight"])[cols].contiguous()            # [P, V+1, d]
         self._keep = keep
@@ -425,7 +439,8 @@ class T5DecoderHandle:
         if trace:
             ts = torch.empty((max_length - 1, B, 2 * R), dtype=torch.float32, device=dev_)
             tt = torch.empty((max_length - 1, B, 2 * R), dtype=torch.int32, device=dev_)
-        check(lib().gdr_t5_generate(C.byref(self.struct), ptr(enc_hidden), ptr(mask), B, L, R, max_length,
+        fn = lib().gdr_t5_generate_bf16 if self.dtype == torch.bfloat16 else lib().gdr_t5_generate
+        check(fn(C.byref(self.struct), ptr(enc_hidden), ptr(mask), B, L, R, max_length,
                                     float(length_penalty), nret, trie.struct_ref() if trie is not None else None,
                                     prefix_table.struct_ref() if prefix_table is not None else None,
                                     ptr(ids), ptr(lens), ptr(scores), ptr(ts), ptr(tt),
@@ -474,9 +489,9 @@ class PrefixTable:
         max_n = int(max(level_off[s + 1] - level_off[s] for s in range(n_levels)))
         need = lib().gdr_t5_prefix_table_workspace_bytes(C.byref(dec.struct), max_n)
         ws = torch.empty(need, dtype=torch.uint8, device=device)
-        check(lib().gdr_t5_prefix_table_build(C.byref(dec.struct), n_levels, lo_host, ptr(node_tok), ptr(node_anc),
-                                              ptr(self.kv), ptr(self.W), ptr(ws), ws.numel(), stream_ptr()),
-              "gdr_t5_prefix_table_build")
+        build = lib().gdr_t5_prefix_table_build_bf16 if dec.dtype == torch.bfloat16 else lib().gdr_t5_prefix_table_build
+        check(build(C.byref(dec.struct), n_levels, lo_host, ptr(node_tok), ptr(node_anc), ptr(self.kv), ptr(self.W), ptr(ws),
+                    ws.numel(), stream_ptr()), "gdr_t5_prefix_table_build")
         torch.cuda.current_stream().synchronize()                        # the scratch tensors above may go now
         self.n_levels, self.n_table, self.level_off = n_levels, n_table, level_off
         self.struct = _ffi.GdrPrefixTable(self.device_trie.child.data_ptr(), self.device_trie.child.shape[0], int(bfs.V),

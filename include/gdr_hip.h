@@ -345,6 +345,24 @@ int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const
                     int32_t* out_len, double* out_scores, float* step_scores, int32_t* step_tokens, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* bf16 precision mode of the decode path (BASELINE config C5; the reference itself runs precision=32, main.py:61,91): the
+ * SAME structs, but every linear weight — GdrT5DecLayer.{wqkv, wo, wq_c, wkv_c, wo_c, wi, wo_ff},
+ * GdrAdaptorLayer.{in_w, out_w, lin1_w, lin2_w} and head_w — points to bf16 data (round-to-nearest-even of the fp32
+ * checkpoint); the `const float*` field type is nominal for them.  Each linear rounds its activation operand to bf16 and
+ * accumulates in fp32; embeddings, norms, attention, biases, the residual stream, the head dot product (h · W), log-softmax
+ * and all beam arithmetic stay fp32, hypothesis scores fp64.  A prefix table for this mode is built by the _bf16 builder
+ * (same rounding points as the in-call computation); its storage stays fp32.  Parity: against the oracle's emulation of
+ * exactly these rounding points (oracle/t5_ref.py bf16_linears) and within bf16 tolerance of the fp32 path.
+ * Workspace: gdr_t5_generate_workspace_bytes / gdr_t5_prefix_table_workspace_bytes serve both modes. */
+int gdr_t5_generate_bf16(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B, int L,
+                         int num_beams, int max_length, double length_penalty, int num_return_sequences,
+                         const GdrTrie* trie, const GdrPrefixTable* prefix_table, int64_t* out_ids, int32_t* out_len,
+                         double* out_scores, float* step_scores, int32_t* step_tokens, void* workspace,
+                         size_t workspace_bytes, void* stream);
+int gdr_t5_prefix_table_build_bf16(const GdrT5DecoderWeights* w, int n_levels, const int32_t* level_off,
+                                   const int64_t* node_tok, const int32_t* node_anc, float* kv, float* W, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
 /* The same device beam search driven by a logit table instead of the model (teacher forcing):
  * logits(prefix) = table[b, pos, last_token, :] (fp32 [B, max_length, Vd, Vd]) with the positional mask.
  * Exercises EOS / early-done / eviction paths that random weights never reach. */

@@ -146,9 +146,9 @@ def _mha(x_q, x_kv, sd, prefix, nhead, attn_mask=None):
     S = x_kv.shape[0]
     hd = d // nhead
     Wi, bi = sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"]
-    q = x_q @ Wi[:d].T + bi[:d]
-    k = x_kv @ Wi[d:2 * d].T + bi[d:2 * d]
-    v = x_kv @ Wi[2 * d:].T + bi[2 * d:]
+    q = _lin(x_q, Wi[:d]) + bi[:d]
+    k = _lin(x_kv, Wi[d:2 * d]) + bi[d:2 * d]
+    v = _lin(x_kv, Wi[2 * d:]) + bi[2 * d:]
     q = q.contiguous().view(T, R * nhead, hd).transpose(0, 1) * (hd ** -0.5)
     k = k.contiguous().view(S, R * nhead, hd).transpose(0, 1)
     v = v.contiguous().view(S, R * nhead, hd).transpose(0, 1)
@@ -157,7 +157,7 @@ def _mha(x_q, x_kv, sd, prefix, nhead, attn_mask=None):
         s = s + attn_mask
     w = F.softmax(s, dim=-1)
     o = torch.bmm(w, v).transpose(0, 1).contiguous().view(T, R, d)
-    return o @ sd[prefix + ".out_proj.weight"].T + sd[prefix + ".out_proj.bias"]
+    return _lin(o, sd[prefix + ".out_proj.weight"]) + sd[prefix + ".out_proj.bias"]
 
 
 def adaptor_forward(sd, cfg, dec_ids):
@@ -176,7 +176,7 @@ def adaptor_forward(sd, cfg, dec_ids):
                          sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps)
         x = F.layer_norm(x + _mha(x, mem, sd, p + ".multihead_attn", cfg.adaptor_nhead), (d,),
                          sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps)
-        ff = F.relu(x @ sd[p + ".linear1.weight"].T + sd[p + ".linear1.bias"]) @ sd[p + ".linear2.weight"].T \
+        ff = _lin(F.relu(_lin(x, sd[p + ".linear1.weight"]) + sd[p + ".linear1.bias"]), sd[p + ".linear2.weight"]) \
             + sd[p + ".linear2.bias"]
         x = F.layer_norm(x + ff, (d,), sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], eps)
     return x.transpose(0, 1)
@@ -214,6 +214,8 @@ def head_last_restricted(sd, cfg, dec_hidden_last, adapt_last, p):
     R = dec_hidden_last.shape[0]
     cols = valid_columns(p, cfg.output_vocab_size)
     Wl = sd["adaptor_linear.weight"].view(d, Vd, d)[:, cols, :]           # [i, c', k]
+    if GEMM_BF16:                                                         # the head GEMM is a linear of the C5 mode too
+        adapt_last, Wl = adapt_last.to(torch.bfloat16).float(), Wl.to(torch.bfloat16).float()
     A = torch.einsum("rk,ick->ric", adapt_last, Wl)                       # [R, d(i), 31]
     W = A + sd["lm_head.weight"][cols].T.unsqueeze(0)
     h = dec_hidden_last * (d ** -0.5)
