@@ -256,6 +256,17 @@ def stages(dev, cfg, D, D_dev, a):
     t = timed(step16, reps=5, warm=2)
     out["bf16_mode_c2_step"] = {"ms": t * 1e3, "queries_per_s": a.batch / t,
                                 "note": "padded encoder with bf16 linear operands + bf16 corpus similarity, fp32 accumulate"}
+    del enc16
+    torch.cuda.empty_cache()
+    # ---- config C5's decode leg: beam 30, bf16 linears in encoder / decoder / adaptor / head (prefix table built in bf16)
+    model16 = GDRModel(cfg, sd, dev, prefix_trie=codec.Trie.from_docids(names, 30), dtype=torch.bfloat16)
+    ids, mask = synth.make_tokens(64, L=40, seed=11)
+    ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    g16 = lambda: model16.generate(ids, attention_mask=mask, max_length=10, num_beams=30, length_penalty=0.8,   # noqa: E731
+                                   num_return_sequences=30, output_scores=True)
+    t = timed(g16, reps=3, warm=1)
+    out["bf16_mode_generate_B64_beam30"] = {"generate_ms": t * 1e3, "queries_per_s": 64 / t,
+                                            "note": "C5's decode leg: 1920 beam rows, bf16 linear operands, fp32 accumulate"}
     return out
 
 

@@ -1,58 +1,141 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs of a bench run (gpurun_out/...) into the committed summaries under profiles/.
-usage: summarize_profiles.py TAG STATS_CSV FETCH_COUNTER_CSV WRITE_COUNTER_CSV BENCH_JSON"""
+"""Turn the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/TAG/...) into the committed summaries under profiles/.
+usage: summarize_profiles.py TAG [gpurun_out/TAG]
+
+Writes  profiles/TAG_bench_n1.json, TAG_bench_n1_padded.json, TAG_bench_bf16.json      the bench lines
+        profiles/TAG_bench_kernel_stats.csv, TAG_bench_padded_kernel_stats.csv,
+        profiles/TAG_generate_kernel_stats.csv                                           rocprofv3 --stats summaries
+        profiles/TAG_bench_pmc_hbm.md       HBM-side bytes per launch (FETCH_SIZE x2 / WRITE_SIZE, separate passes)
+        profiles/TAG_mfma_busy.md           SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE of the GEMM kernels
+        profiles/traffic.json               what bench.py reports as roofline.traffic
+"""
 import collections
 import csv
+import glob
 import json
+import os
 import shutil
 import sys
 
-tag, stats, fetch, write, bench = sys.argv[1:6]
-shutil.copy(stats, f"profiles/{tag}_bench_kernel_stats.csv")
-shutil.copy(bench, f"profiles/{tag}_bench_n1.json")
+tag = sys.argv[1]
+src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/{tag}"
 
 
-def agg(path):
-    d = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        d[(r["Kernel_Name"], r["Grid_Size"])].append(float(r["Counter_Value"]))
+def one(pattern):
+    m = sorted(glob.glob(os.path.join(src, pattern)))
+    return m[0] if m else None
+
+
+def copy(pattern, dst):
+    f = one(pattern)
+    if f:
+        shutil.copy(f, f"profiles/{dst}")
+    return f
+
+
+copy("bench_n1.json", f"{tag}_bench_n1.json")
+copy("bench_n1_padded.json", f"{tag}_bench_n1_padded.json")
+copy("bench_bf16.json", f"{tag}_bench_bf16.json")
+copy("stats/*/*kernel_stats.csv", f"{tag}_bench_kernel_stats.csv")
+copy("stats_padded/*/*kernel_stats.csv", f"{tag}_bench_padded_kernel_stats.csv")
+copy("stats_generate/*/*kernel_stats.csv", f"{tag}_generate_kernel_stats.csv")
+
+
+def counters(pattern):
+    """{(kernel, grid): {counter: [values]}, 'dur': [ns]} per dispatch of a counter-collection CSV."""
+    f = one(pattern)
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not f:
+        return d
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        k = (r["Kernel_Name"], r["Grid_Size"])
+        d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if (r["Dispatch_Id"], "dur") not in seen:
+            seen.add((r["Dispatch_Id"], "dur"))
+            d[k]["dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     return d
 
 
-f, w = agg(fetch), agg(write)
-rows, tot = [], collections.defaultdict(lambda: [0, 0.0, 0.0])
-for k in f:
-    fv = sum(f[k]) / len(f[k])
-    wv = sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
-    fb, wb = fv * 1024 * 2, wv * 1024
-    rows.append((k[0], k[1], len(f[k]), fv, fb, wb))
-    t = tot[k[0]]
-    t[0] += len(f[k]); t[1] += fb * len(f[k]); t[2] += wb * len(f[k])
+def avg(x):
+    return sum(x) / len(x) if x else 0.0
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+CMD = ("    cd /tmp && export TMPDIR=/tmp\n"
+       "    B=\"python3 bench.py --no-cpu-baseline --no-recall --no-stages\"\n"
+       "    rocprofv3 --kernel-trace --stats --output-format csv -d OUT/stats -- $B --steps 5 --warmup 2\n"
+       "    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d OUT/pmc_fetch -- $B --steps 2 --warmup 1\n"
+       "    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d OUT/pmc_write -- $B --steps 2 --warmup 1\n"
+       "    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d OUT/pmc_mfma -- $B --steps 2 --warmup 1\n"
+       "    rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d OUT/pmc_clk -- $B --steps 2 --warmup 1\n"
+       "    (the *_padded passes add `--encoder padded`; tools/collect_profiles.sh is the script)\n")
+
+# ---------------------------------------------------------------------------------------------- HBM-side traffic
+traffic = {}
 with open(f"profiles/{tag}_bench_pmc_hbm.md", "w") as o:
     o.write(f"# {tag} — HBM-side traffic per launch (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes)\n\n"
-            "Commands (each counter in its own run, kernel-trace only, as gpurun requires):\n\n"
-            "    cd /tmp && export TMPDIR=/tmp\n"
-            "    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-recall\n"
-            "    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-recall\n"
-            "    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-recall\n\n"
-            "Correction per MI355X_MICROARCH.md §HBM: FETCH_SIZE is in KiB and reads exactly half of a wide coalesced stream on gfx950 "
-            "-> bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 is exact for 16-B/lane stores.  FETCH counts L2 misses "
-            "(Infinity-Cache hits included), so it bounds HBM reads from above.\n\n"
-            "| kernel | grid (threads) | launches | FETCH_SIZE avg (KiB) | read MB/launch (x2) | write MB/launch |\n|---|---|---|---|---|---|\n")
-    for r in rows:
-        o.write(f"| `{r[0][:70]}` | {r[1]} | {r[2]} | {r[3]:.0f} | {r[4] / 1e6:.1f} | {r[5] / 1e6:.1f} |\n")
-    o.write("\nPer kernel name (all shapes averaged, as `roofline.traffic` in bench.py reports it):\n\n"
-            "| kernel | launches | bytes/launch (read+write) |\n|---|---|---|\n")
-    out = {}
-    for k, t in tot.items():
-        o.write(f"| `{k[:70]}` | {t[0]} | {(t[1] + t[2]) / t[0] / 1e6:.1f} MB |\n")
-        out[k] = (t[1] + t[2]) / t[0]
+            "Commands (each counter group in its own run, kernel-trace only, the program directly after `--`):\n\n" + CMD +
+            "\nCorrection per MI355X_MICROARCH.md §HBM: FETCH_SIZE is in KiB and reads exactly half of a wide coalesced stream on "
+            "gfx950 -> bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 is exact for 16-B/lane stores.  FETCH counts L2 misses "
+            "(Infinity-Cache hits included), so it bounds HBM reads from above.\n")
+    for mode, fp, wp in (("ragged encoder (the default bench)", "pmc_fetch/*/*counter_collection.csv", "pmc_write/*/*counter_collection.csv"),
+                         ("padded encoder (`--encoder padded`)", "pmc_fetch_padded/*/*counter_collection.csv",
+                          "pmc_write_padded/*/*counter_collection.csv")):
+        f, w = counters(fp), counters(wp)
+        o.write(f"\n## {mode}\n\n| kernel | grid (threads) | launches | read MB/launch (FETCH x2) | write MB/launch |\n|---|---|---|---|---|\n")
+        tot = collections.defaultdict(lambda: [0, 0.0])
+        for k in sorted(f, key=lambda k: -sum(f[k]["FETCH_SIZE"])):
+            n = len(f[k]["FETCH_SIZE"])
+            rb = avg(f[k]["FETCH_SIZE"]) * 1024 * 2
+            wb = avg(w[k]["WRITE_SIZE"]) * 1024 if k in w else 0.0
+            if rb + wb < 1e5:
+                continue
+            o.write(f"| `{short(k[0])[:60]}` | {k[1]} | {n} | {rb / 1e6:.1f} | {wb / 1e6:.1f} |\n")
+            tot[short(k[0])][0] += n
+            tot[short(k[0])][1] += (rb + wb) * n
+        lin = [(k, v) for k, v in tot.items() if "persistent" in k or "streamk" in k]
+        if lin:
+            n = sum(v[0] for _, v in lin)
+            b = sum(v[1] for _, v in lin) / n
+            key = "linear_gemm_bytes_per_launch_ragged" if "ragged" in mode else "linear_gemm_bytes_per_launch"
+            traffic[key] = b
+            o.write(f"\nThe linear GEMM (whole-tile + stream-K forms together, {n} launches): **{b / 1e6:.1f} MB per launch** "
+                    "(read + write) — `roofline.traffic` of this mode.\n")
     o.write("\nAlgorithmic bytes of the linear GEMM, averaged over its four call shapes per layer (A + W + C (+ residual)): "
-            "290 MB/launch.  The excess is operand panels re-read through the Infinity Cache when an XCD's 4 MiB L2 cannot "
-            "hold the panels of the 64 tiles it works on: wide outputs (N = 2304, 3072) run in 8-row-panel supertiles "
-            "(1112 -> 557 MB and 653 -> 443 MB fetched per launch), N = 768 keeps the column-fastest order (552 MB; supertiles "
-            "made it 684).  The kernel is MFMA-bound, so this is energy rather than time (bench identical to 0.1 %).\n")
-key = [k for k in out if "gemm_nt_f32_persistent_kernel" in k or "gemm_nt_f32_kernel<0, false>" in k][0]   # the linear GEMM (persistent form in the bench)
-json.dump({"linear_gemm_bytes_per_launch": out[key], "kernel": key, "source": f"profiles/{tag}_bench_pmc_hbm.md"},
-          open("profiles/traffic.json", "w"), indent=1)
-print(open(f"profiles/{tag}_bench_kernel_stats.csv").read()[:1500])
+            "290 MB/launch padded (20 480 rows), 176 MB ragged (12 308 rows).  The excess is operand panels re-read through the "
+            "Infinity Cache when an XCD's 4 MiB L2 cannot hold the panels its tiles touch; the stream-K form re-reads more than "
+            "the whole-tile form (its workgroups sit at different k of different tiles, so operand slices are not shared in "
+            "time) — the reason it only runs where whole tiles quantise badly.\n")
+traffic["source"] = f"profiles/{tag}_bench_pmc_hbm.md"
+json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
+
+# ---------------------------------------------------------------------------------------------- MFMA utilisation
+m, c = counters("pmc_mfma/*/*counter_collection.csv"), counters("pmc_clk/*/*counter_collection.csv")
+with open(f"profiles/{tag}_mfma_busy.md", "w") as o:
+    o.write(f"# {tag} — MFMA utilisation of the GEMM kernels in the bench (rocprofv3 --pmc)\n\n"
+            "Two counter passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-recall --no-stages` (ragged encoder):\n\n" + CMD +
+            "\nPer launch averages.  `clock` = GRBM_GUI_ACTIVE / 8 XCDs / duration (MI355X_MICROARCH.md, DVFS give-back);\n"
+            "`MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock): the share of SIMD-cycles in which the matrix "
+            "pipe is executing.  Durations are those of the profiled pass (profiled runs clock 2-3 % lower than un-profiled).\n\n"
+            "| kernel | grid | launches | avg us | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES | GRBM_GUI_ACTIVE | clock GHz | MFMA busy |\n"
+            "|---|---|---|---|---|---|---|---|---|\n")
+    for k in sorted(m, key=lambda k: -sum(m[k]["dur_ns"])):
+        if not any(s in k[0] for s in ("gemm_nt", "attention_mfma")):
+            continue
+        dur = avg(m[k]["dur_ns"])
+        gui = avg(c[k]["GRBM_GUI_ACTIVE"]) if k in c else 0.0
+        dur_c = avg(c[k]["dur_ns"]) if k in c else 0.0
+        clk = gui / 8 / dur_c if dur_c else 0.0                      # cycles per ns = GHz
+        busy = avg(m[k]["SQ_VALU_MFMA_BUSY_CYCLES"])
+        frac = busy / (1024 * dur * clk) if clk else 0.0
+        o.write(f"| `{short(k[0])[:48]}` | {k[1]} | {len(m[k]['dur_ns'])} | {dur / 1e3:.1f} | {busy:.3e} | "
+                f"{avg(m[k]['SQ_BUSY_CYCLES']):.3e} | {gui:.3e} | {clk:.2f} | {frac:.3f} |\n")
+    o.write("\nReading: for the fp32 GEMMs MFMA busy x clock / 2.4 GHz is the fraction of the 157.3 TFLOP/s peak that the issue "
+            "stream could deliver; what bench.py reports as `roofline.frac` is lower by the tile-edge waste (rows past the live "
+            "count are computed and discarded) and by the epilogue / prologue phases in which no MFMA is issued.\n")
+print(open(f"profiles/{tag}_mfma_busy.md").read())
+print(open(f"profiles/{tag}_bench_pmc_hbm.md").read()[-3000:])
