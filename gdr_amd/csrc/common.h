@@ -92,9 +92,18 @@ int launch_sim_gemm(const void* D, int64_t N, const void* Q, int B, int d, const
 int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                        int K, int epilogue, const float* bias, const float* residual, int64_t ldr, hipStream_t stream,
                        const int64_t* m_dev = nullptr);
+// A norm fused behind a split-K linear whose output rows are whole model rows (gemm_small.hip splitk_reduce_norm_kernel).
+struct NormEpilogue {
+  int kind;                 // 1 RMS (w1), 2 LayerNorm (w1,b1), 3 LayerNorm(w1,b1) -> + addv -> LayerNorm(w2,b2)
+  const float *w1, *b1, *w2, *b2, *addv;
+  float eps;
+  float* Y;                 // normed rows [M, ldy]
+  int64_t ldy;
+};
 int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
-                            int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev = nullptr);
+                            int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev = nullptr,
+                            const NormEpilogue* ne = nullptr);  // with ne: returns 2 if the fused form does not apply
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, int out_bf16, hipStream_t stream, const int64_t* m_dev = nullptr);

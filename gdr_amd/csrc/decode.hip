@@ -21,6 +21,7 @@
 //     for its descendants, its adaptor K/V) from the table; only rows whose prefix left the trie are compacted and run
 //     through the adaptor + head GEMM (device-side row count, no host round trip).
 #include <math.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <vector>
@@ -306,8 +307,12 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims b
   const int R = bd.R, V1 = bd.V + 1, nthr = blockDim.x, nwaves = blockDim.x >> 6;
   float* lse_max = reinterpret_cast<float*>(keys + npad);  // [R]
   float* lse_log = lse_max + R;                            // [R]
+  float* lg_s = lse_log + R;                               // [R*V1] this query's logits, staged once (coalesced)
+  const int ncand = R * V1;
+  for (int e = tid; e < ncand; e += nthr) lg_s[e] = bb.logits[(size_t)b * ncand + e];
+  __syncthreads();
   for (int j = wave; j < R; j += nwaves) {
-    const float* lg = bb.logits + ((size_t)b * R + j) * V1;
+    const float* lg = lg_s + j * V1;
     float mx = -INFINITY;
     for (int c = lane; c < V1; c += 64) mx = fmaxf(mx, lg[c]);
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -320,12 +325,11 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims b
     }
   }
   __syncthreads();
-  const int ncand = R * V1;
   for (int e = tid; e < npad; e += nthr) {
     unsigned long long key = 0ull;
     if (e < ncand) {
       const int j = e / V1, c = e - j * V1;
-      const float logp = (bb.logits[((size_t)b * R + j) * V1 + c] - lse_max[j]) - lse_log[j];
+      const float logp = (lg_s[e] - lse_max[j]) - lse_log[j];
       float s = logp + bb.beam_scores[(size_t)b * R + j];
       if (bd.trie_eos) {  // scores += mask(-inf on tokens that are not children of the prefix' node)
         const int nd = bb.node[cur][(size_t)b * R + j];
@@ -339,20 +343,42 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims b
     keys[e] = key;
   }
   __syncthreads();
+  // Bitonic sort, descending.  A wave owns a block of epw consecutive keys: every stage whose compare-exchange pairs stay
+  // inside a block (2*stride <= epw) needs no workgroup barrier — LDS operations of one wave execute in order — so of the
+  // 78 stages of a 4096-key sort (100 beams) only the 10 with stride >= 256 cost a barrier pair (52 -> 14 us per step).
+  const int epw = npad / nwaves;
   for (int size = 2; size <= npad; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < (npad >> 1); t += nthr) {
-        const int lo = (t / stride) * (stride << 1) + (t % stride), hi = lo + stride;
-        const bool desc = ((lo & size) == 0);
-        const unsigned long long x = keys[lo], y = keys[hi];
-        if ((x < y) == desc) {
-          keys[lo] = y;
-          keys[hi] = x;
+      if (2 * stride <= epw) {
+        for (int q = lane; q < (epw >> 1); q += 64) {
+          const int t = (epw >> 1) * wave + q;
+          const int lo = (t / stride) * (stride << 1) + (t % stride), hi = lo + stride;
+          const bool desc = ((lo & size) == 0);
+          const unsigned long long x = keys[lo], y = keys[hi];
+          if ((x < y) == desc) {
+            keys[lo] = y;
+            keys[hi] = x;
+          }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      } else {
+        __syncthreads();
+        for (int t = tid; t < (npad >> 1); t += nthr) {
+          const int lo = (t / stride) * (stride << 1) + (t % stride), hi = lo + stride;
+          const bool desc = ((lo & size) == 0);
+          const unsigned long long x = keys[lo], y = keys[hi];
+          if ((x < y) == desc) {
+            keys[lo] = y;
+            keys[hi] = x;
+          }
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
+  __syncthreads();
   for (int i = tid; i < 2 * R; i += nthr) {
     const unsigned long long key = keys[i];
     const float s = dfkey_inv((uint32_t)(key >> 32));
@@ -371,6 +397,13 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims b
 // drops its worst entry with `del` (order of the rest kept), the final pick is a stable sort by score popped from the
 // end.  Only the RELATIVE list order of surviving entries is ever observed (tie-breaks), so each entry carries its
 // insertion number and the storage order is free: a delete moves the last entry into the hole.
+// The hypothesis-heap helpers below are executed by ONE wave (the first wave of the block): LDS operations of a wave
+// execute in order, so a wave-level barrier (plus fences for the compiler) is all the synchronisation they need.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 struct HypLds {
   double* sc;   // [R+1]
   int32_t* ln;  // [R+1]
@@ -394,12 +427,12 @@ __device__ __forceinline__ void hyp_load(HypLds& H, char* smem, const BeamBufs& 
     H.sq[i] = bb.hyp_seq[(size_t)b * cap + i];
   }
   for (int e = lane; e < H.n * ml; e += 64) H.tk[e] = bb.hyp_tok[(size_t)b * cap * ml + e];
-  __syncthreads();
+  wave_sync();
 }
 
 __device__ __forceinline__ void hyp_store(const HypLds& H, const BeamBufs& bb, const BeamDims& bd, int b, int lane) {
   const int cap = bd.R + 1, ml = bd.maxlen;
-  __syncthreads();
+  wave_sync();
   for (int i = lane; i < H.n; i += 64) {
     bb.hyp_score[(size_t)b * cap + i] = H.sc[i];
     bb.hyp_len[(size_t)b * cap + i] = H.ln[i];
@@ -418,7 +451,7 @@ __device__ void hyp_add(HypLds& H, const BeamDims& bd, const int32_t* toks, int 
   if (lane == 0) H.sc[H.n] = score, H.ln[H.n] = len, H.sq[H.n] = H.next;
   for (int t = lane; t < len; t += 64) H.tk[(size_t)H.n * ml + t] = toks[t];
   ++H.n, ++H.next;
-  __syncthreads();
+  wave_sync();
   if (H.n > bd.R) {
     // sorted([(s, idx)])[0] is removed (lowest score, then lowest list index = lowest insertion number);
     // [1] gives the new worst score
@@ -448,57 +481,90 @@ __device__ void hyp_add(HypLds& H, const BeamDims& bd, const int32_t* toks, int 
     }
     --H.n;
     H.worst = second;
-    __syncthreads();
+    wave_sync();
   } else {
     H.worst = score < H.worst ? score : H.worst;
   }
 }
 
-// The host loop of generation_utils.py:783-850: one wave per query.  The walk over the 2R ranked candidates stays
-// sequential (hypothesis state carries from one EOS candidate to the next) but only decides; rows are filled afterwards
-// by all lanes.  cur = index of the current seq buffer.
-__global__ __launch_bounds__(64) void beam_update_kernel(BeamBufs bb, BeamDims bd, int cur_len, int cur) {
+// The host loop of generation_utils.py:783-850, one workgroup of four waves per query.  What that loop decides is fixed
+// by the ranked candidate list alone: the next beams are the first R non-EOS candidates, and the EOS candidates that are
+// offered to the hypothesis heap are those of rank < R that come before the R-th non-EOS one — so the non-EOS ranks are
+// found with ballots / popcounts, and only the (few) EOS candidates walk the heap one after another, in rank order, on the
+// first wave.  All four waves then fill the rows.  cur = index of the current seq buffer.
+__global__ __launch_bounds__(256) void beam_update_kernel(BeamBufs bb, BeamDims bd, int cur_len, int cur) {
   extern __shared__ __attribute__((aligned(16))) char bsm[];
-  const int b = blockIdx.x, lane = threadIdx.x;
+  __shared__ int n_sh;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int R = bd.R, ml = bd.maxlen;
   const int32_t* seq_c = bb.seq[cur];
   int32_t* seq_n = bb.seq[cur ^ 1];
   if (bb.done[b]) {  // :786-794 padded batch entry
-    for (int j = lane; j < R; j += 64) {
+    for (int j = tid; j < R; j += 256) {
       const int row = b * R + j;
       bb.beam_scores[row] = 0.f;
       bb.cur_tok[row] = PAD_ID;
       bb.parent[row] = b * R;
       bb.node[cur ^ 1][row] = -1;
     }
-    for (int e = lane; e < R * (cur_len + 1); e += 64) {
+    for (int e = tid; e < R * (cur_len + 1); e += 256) {
       const int j = e / (cur_len + 1), t = e - j * (cur_len + 1);
       seq_n[(size_t)(b * R + j) * ml + t] = t < cur_len ? seq_c[(size_t)(b * R) * ml + t] : PAD_ID;
     }
     return;
   }
-  HypLds H;
-  hyp_load(H, bsm, bb, bd, b, lane);
   int32_t* sel = reinterpret_cast<int32_t*>(bsm + ((hyp_lds_bytes(R, ml) + 15) & ~(size_t)15));  // [R] chosen candidate ranks
-  const float* cs = bb.cand_score + (size_t)b * 2 * R;
-  const int32_t* ci = bb.cand_idx + (size_t)b * 2 * R;
-  int n = 0;
-  bool touched = false;
-  for (int rank = 0; rank < 2 * R; ++rank) {
-    const int flat = ci[rank];
-    const int beam = flat / bd.Vd, tok = flat % bd.Vd;
-    if (tok == EOS_ID) {
-      if (rank >= R) continue;  // :811-813
-      hyp_add(H, bd, seq_c + (size_t)(b * R + beam) * ml, cur_len, (double)cs[rank], lane);
-      touched = true;
-    } else {
-      if (lane == 0) sel[n] = rank;
-      ++n;
-    }
-    if (n == R) break;
+  int32_t* ci = sel + R;                               // [2R] ranked candidates, staged once
+  float* cs = reinterpret_cast<float*>(ci + 2 * R);    // [2R]
+  for (int e = tid; e < 2 * R; e += 256) {
+    ci[e] = bb.cand_idx[(size_t)b * 2 * R + e];
+    cs[e] = bb.cand_score[(size_t)b * 2 * R + e];
   }
   __syncthreads();
-  for (int j = lane; j < n; j += 64) {
+  if (wave == 0) {
+    HypLds H;
+    hyp_load(H, bsm, bb, bd, b, lane);
+    // pass 1: rank of the j-th non-EOS candidate -> sel[j]; `end` = one past the rank at which the R-th one is taken
+    int n = 0, end = 2 * R;
+    for (int base = 0; base < 2 * R && n < R; base += 64) {
+      const int rank = base + lane;
+      const bool live = rank < 2 * R && (ci[rank] % bd.Vd) != EOS_ID;
+      const unsigned long long m = __ballot(live);
+      const int before = n + __popcll(m & ((1ull << lane) - 1ull));
+      if (live && before < R) sel[before] = rank;
+      const int tot = n + __popcll(m);
+      if (tot >= R) {  // the R-th non-EOS candidate sits in this chunk: find its rank
+        const unsigned long long hit = __ballot(live && before == R - 1);
+        end = base + (int)__ffsll((long long)hit);
+      }
+      n = tot < R ? tot : R;
+    }
+    // pass 2: EOS candidates of rank < min(R, end) enter the heap, in rank order (:811-817)
+    bool touched = false;
+    const int lim = end < R ? end : R;
+    for (int base = 0; base < lim; base += 64) {
+      const int rank = base + lane;
+      unsigned long long m = __ballot(rank < lim && (ci[rank] % bd.Vd) == EOS_ID);
+      while (m) {
+        const int rk = base + (int)__ffsll((long long)m) - 1;
+        m &= m - 1;
+        hyp_add(H, bd, seq_c + (size_t)(b * R + ci[rk] / bd.Vd) * ml, cur_len, (double)cs[rk], lane);
+        touched = true;
+      }
+    }
+    if (touched) hyp_store(H, bb, bd, b, lane);
+    // :827-829  is_done(best_sum_logprobs = next_scores[b].max(), cur_len)
+    if (lane == 0) {
+      n_sh = n;
+      if (H.n >= R) {
+        const double cur_score = (double)cs[0] / pow((double)cur_len, bd.lp);
+        if (H.worst >= cur_score) bb.done[b] = 1;
+      }
+    }
+  }
+  __syncthreads();
+  const int n = n_sh;
+  for (int j = tid; j < n; j += 256) {
     const int rank = sel[j];
     const int flat = ci[rank];
     const int beam = flat / bd.Vd, tok = flat % bd.Vd;
@@ -513,17 +579,11 @@ __global__ __launch_bounds__(64) void beam_update_kernel(BeamBufs bb, BeamDims b
       bb.node[cur ^ 1][row] = nx;
     }
   }
-  for (int e = lane; e < n * (cur_len + 1); e += 64) {
+  for (int e = tid; e < n * (cur_len + 1); e += 256) {
     const int j = e / (cur_len + 1), t = e - j * (cur_len + 1);
     const int flat = ci[sel[j]];
     const int beam = flat / bd.Vd, tok = flat % bd.Vd;
     seq_n[(size_t)(b * R + j) * ml + t] = t < cur_len ? seq_c[(size_t)(b * R + beam) * ml + t] : tok;
-  }
-  if (touched) hyp_store(H, bb, bd, b, lane);
-  // :827-829  is_done(best_sum_logprobs = next_scores[b].max(), cur_len)
-  if (lane == 0 && H.n >= R) {
-    const double cur_score = (double)cs[0] / pow((double)cur_len, bd.lp);
-    if (H.worst >= cur_score) bb.done[b] = 1;
   }
 }
 
@@ -610,13 +670,13 @@ static int beam_step(const BeamBufs& bb, const BeamDims& bd, int pos, int cur, f
                      int32_t* step_tokens, hipStream_t stream) {
   const int rows = bd.B * bd.R;
   const int npad = next_pow2i(bd.R * (bd.V + 1));
-  const size_t lds = (size_t)npad * 8 + (size_t)bd.R * 8;
+  const size_t lds = (size_t)npad * 8 + (size_t)bd.R * 8 + (size_t)bd.R * (bd.V + 1) * 4;
   const size_t tr = (size_t)pos * bd.B * 2 * bd.R;
   hipLaunchKernelGGL(beam_topk_kernel, dim3(bd.B), dim3(npad >= 2048 ? 1024 : 256), lds, stream, bb, bd, pos, npad, cur,
                      step_scores ? step_scores + tr : nullptr, step_tokens ? step_tokens + tr : nullptr);
   GDR_CHECK_LAUNCH("beam_topk_kernel");
-  const size_t hyp_lds = ((hyp_lds_bytes(bd.R, bd.maxlen) + 15) & ~(size_t)15) + (size_t)bd.R * 4;
-  hipLaunchKernelGGL(beam_update_kernel, dim3(bd.B), dim3(64), hyp_lds, stream, bb, bd, pos + 1, cur);
+  const size_t hyp_lds = ((hyp_lds_bytes(bd.R, bd.maxlen) + 15) & ~(size_t)15) + (size_t)bd.R * 4 + (size_t)bd.R * 16;
+  hipLaunchKernelGGL(beam_update_kernel, dim3(bd.B), dim3(256), hyp_lds, stream, bb, bd, pos + 1, cur);
   GDR_CHECK_LAUNCH("beam_update_kernel");
   const int n = rows * (pos + 2);
   hipLaunchKernelGGL(anc_update_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, bb, rows, bd.maxlen, pos + 1, cur);
@@ -701,6 +761,41 @@ static int dec_linear(bool bf16, void* abf, const float* A, int64_t lda, const f
   GDR_CHECK_ARG(lda == K && K % 8 == 0, "decode(bf16): the activation operand must be dense with K %% 8 == 0");
   if (int rc = launch_cast_f32_bf16(A, abf, M * (int64_t)K, st)) return rc;
   return launch_linear_bf16(abf, K, W, ldw, C, ldc, M, N, K, epi, bias, res, ldr, st, m_dev);
+}
+// A linear whose output rows are whole model rows, followed by the norm that always comes next on the decode path:
+// C = epilogue(A·W^T), ne.Y = norm(C).  fp32 with split-K: the reduction kernel applies the norm while it holds the
+// finished row (one launch instead of two or three); otherwise the linear and the norm kernels run one after another.
+static int dec_linear_norm(bool bf16, void* abf, const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
+                           int64_t M, const int64_t* m_dev, int N, int K, int epi, const float* bias, const float* res,
+                           int64_t ldr, float* skw, hipStream_t st, const NormEpilogue& ne) {
+  if (M == 0) return GDR_OK;
+  static const bool fuse_on = [] {
+    const char* e = getenv("GDR_DECODE_FUSE_NORM");  // A/B knob: 0 = always separate launches
+    return e ? atoi(e) != 0 : true;
+  }();
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  // measured: +2 % per generate() at 640 rows, -3 % at 100 rows (one wave per row leaves the chip empty there)
+  if (fuse_on && !bf16 && M >= 256 && tiles < 192 && M <= 1536 && K % 32 == 0 && K / 32 >= 4 && ldc == N && ne.ldy == N) {
+    const bool nb = epi == GDR_EPI_BIAS || epi == GDR_EPI_BIAS_RELU || epi == GDR_EPI_BIAS_RESIDUAL;
+    const bool nr = epi == GDR_EPI_RESIDUAL || epi == GDR_EPI_BIAS_RESIDUAL;
+    const int act = (epi == GDR_EPI_RELU || epi == GDR_EPI_BIAS_RELU) ? 1 : 0;
+    GDR_CHECK_ARG(epi != GDR_EPI_BIAS_GELU && (!nb || bias) && (!nr || res), "decode: bad epilogue for a fused norm");
+    const int rc = launch_linear_f32_small(A, lda, W, ldw, C, ldc, M, N, K, nb, nr, act, bias, res, ldr, skw, SPLITK_WS_BYTES, st,
+                                           m_dev, &ne);
+    if (rc <= 0) return rc;
+  }
+  if (int rc = dec_linear(bf16, abf, A, lda, W, ldw, C, ldc, M, m_dev, N, K, epi, bias, res, ldr, skw, st)) return rc;
+  if (ne.kind == 1)
+    return m_dev ? launch_rmsnorm_dev(C, ne.w1, ne.Y, m_dev, M, N, ne.eps, st) : launch_rmsnorm(C, ne.w1, ne.Y, M, N, ne.eps, nullptr, 1, st);
+  // LayerNorm(s): the second one reads the first one's output through Y
+  float* y1 = ne.kind == 3 ? C : ne.Y;  // kind 3: norm1 may overwrite C (the pre-norm rows are not needed again)
+  if (int rc = m_dev ? launch_layernorm_dev(C, ne.w1, ne.b1, y1, m_dev, M, N, ne.eps, nullptr, st)
+                     : launch_layernorm(C, ne.w1, ne.b1, y1, M, N, ne.eps, nullptr, st))
+    return rc;
+  if (ne.kind == 3)
+    return m_dev ? launch_layernorm_dev(y1, ne.w2, ne.b2, ne.Y, m_dev, M, N, ne.eps, ne.addv, st)
+                 : launch_layernorm(y1, ne.w2, ne.b2, ne.Y, M, N, ne.eps, ne.addv, st);
+  return GDR_OK;
 }
 // element offset into a linear weight (fp32 or bf16 storage)
 static const float* w_at(const float* W, size_t elems, bool bf16) {
@@ -812,6 +907,17 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   dec_linear(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream)
 #define LIN2(A_, lda_, W_, ldw_, C_, ldc_, M_, N_, K_, epi_, bias_, res_, ldr_) \
   dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw2, as)
+#define LINN(A_, lda_, W_, ldw_, C_, ldc_, M_, N_, K_, epi_, bias_, res_, ldr_, ne_) \
+  dec_linear_norm(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream, ne_)
+#define LIN2N(A_, lda_, W_, ldw_, C_, ldc_, M_, md_, N_, K_, epi_, bias_, res_, ldr_, ne_) \
+  dec_linear_norm(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, M_, md_, N_, K_, epi_, bias_, res_, ldr_, skw2, as, ne_)
+  auto rms = [&](const float* wgt, float* y) { return NormEpilogue{1, wgt, nullptr, nullptr, nullptr, nullptr, dm.eps, y, (int64_t)dm.d_model}; };
+  auto ln = [&](const float* w1, const float* b1, float* y) {
+    return NormEpilogue{2, w1, b1, nullptr, nullptr, nullptr, w->adaptor_eps, y, (int64_t)dm.d_model};
+  };
+  auto ln2 = [&](const GdrAdaptorLayer& al, float* y) {  // norm1 -> + cross_const -> norm2
+    return NormEpilogue{3, al.ln1_w, al.ln1_b, al.ln2_w, al.ln2_b, al.cross_const, w->adaptor_eps, y, (int64_t)dm.d_model};
+  };
 #define GDR_TRY(x)        \
   do {                    \
     if ((rc = (x))) return rc; \
@@ -840,8 +946,9 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
     }
     if (!ptab) {
       GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows, d, dm.vocab_size, xa, as));
-      // ---------------- adaptor: post-LN nn.TransformerDecoder over decode_embeddings(ids) (modeling_t5.py:1615-1633)
-      for (int l = 0; l < w->adaptor_layers; ++l) {
+    }
+    // ---------------- adaptor: post-LN nn.TransformerDecoder over decode_embeddings(ids) (modeling_t5.py:1615-1633)
+    auto ad_layer_plain = [&](int l) -> int {
         const GdrAdaptorLayer& al = w->alayers[l];
         float* cache = acache + l * alayer;
         float* slot = cache + s * aslab;
@@ -856,17 +963,17 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
         at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
         at.kv_rows = bb.kv_rows, at.kv_group = 1;
         GDR_TRY(launch_attention(at, as));
-        GDR_TRY(LIN2(ctx2, d, al.out_w, d, tmp, d, rows, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d));
-        GDR_TRY(launch_layernorm(tmp, al.ln1_w, al.ln1_b, xa, rows, d, w->adaptor_eps, nullptr, as));
-        GDR_TRY(launch_layernorm(xa, al.ln2_w, al.ln2_b, tmp, rows, d, w->adaptor_eps, al.cross_const, as));
+        // tmp = norm2(norm1(out_proj(ctx) + xa) + cross_const); xa = norm3(lin2(relu(lin1(tmp))) + tmp)
+        GDR_TRY(LIN2N(ctx2, d, al.out_w, d, tmp, d, rows, nullptr, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d, ln2(al, tmp)));
         GDR_TRY(LIN2(tmp, d, al.lin1_w, d, ff2, aff, rows, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
-        GDR_TRY(LIN2(ff2, aff, al.lin2_w, aff, xa, d, rows, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d));
-        GDR_TRY(launch_layernorm(xa, al.ln3_w, al.ln3_b, xa, rows, d, w->adaptor_eps, nullptr, as));
-      }
-    } else {
+        GDR_TRY(LIN2N(ff2, aff, al.lin2_w, aff, xa, d, rows, nullptr, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d,
+                      ln(al.ln3_w, al.ln3_b, xa)));
+        return GDR_OK;
+    };
+    const int64_t* nm = bb.n_miss;
+    if (ptab) {
       // ---------------- prefix-table mode: rows whose prefix is a table node take everything from the table; the rest
       // are compacted (row count *bb.n_miss lives on the device) and run the same chain + the head GEMM on `as`
-      const int64_t* nm = bb.n_miss;
       hipLaunchKernelGGL(prefix_plan_kernel, dim3(1), dim3(1024), 0, as, bb, rows, s + 1, cur, ptab->n_table);
       GDR_CHECK_LAUNCH("prefix_plan_kernel");
       hipLaunchKernelGGL(prefix_fill_kernel, dim3(rows), dim3(256), 0, as, bb, rows, s + 1, cur, ptab->kv,
@@ -875,9 +982,10 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as, w->dec_embed, bb.cur_tok,
                          bb.miss_rows, nm, d / 4, dm.vocab_size, xa);
       GDR_CHECK_LAUNCH("embed_rows_kernel");
+    }
 #define LIN2D(A_, lda_, W_, ldw_, C_, ldc_, N_, K_, epi_, bias_, res_, ldr_) \
   dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, rows, nm, N_, K_, epi_, bias_, res_, ldr_, skw2, as)
-      for (int l = 0; l < w->adaptor_layers; ++l) {
+    auto ad_layer_tab = [&](int l) -> int {
         const GdrAdaptorLayer& al = w->alayers[l];
         float* cache = acache + l * alayer;
         float* slot = cache + s * aslab;
@@ -895,30 +1003,19 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
         at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
         at.kv_rows = bb.kv_rows_c, at.kv_group = 1, at.b_count_dev = nm;
         GDR_TRY(launch_attention(at, as));
-        GDR_TRY(LIN2D(ctx2, d, al.out_w, d, tmp, d, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d));
-        GDR_TRY(launch_layernorm_dev(tmp, al.ln1_w, al.ln1_b, xa, nm, rows, d, w->adaptor_eps, nullptr, as));
-        GDR_TRY(launch_layernorm_dev(xa, al.ln2_w, al.ln2_b, tmp, nm, rows, d, w->adaptor_eps, al.cross_const, as));
+        GDR_TRY(LIN2N(ctx2, d, al.out_w, d, tmp, d, rows, nm, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d, ln2(al, tmp)));
         GDR_TRY(LIN2D(tmp, d, al.lin1_w, d, ff2, aff, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
-        GDR_TRY(LIN2D(ff2, aff, al.lin2_w, aff, xa, d, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d));
-        GDR_TRY(launch_layernorm_dev(xa, al.ln3_w, al.ln3_b, xa, nm, rows, d, w->adaptor_eps, nullptr, as));
-      }
-      // the head GEMM of the compacted rows belongs to the same chain (it needs nothing from the decoder stack)
-      GDR_TRY(LIN2D(xa, d, w_at(w->head_w, (size_t)s * V1 * d * d, bf16), d, A, (int64_t)V1 * d, V1 * d, d, GDR_EPI_NONE, nullptr,
-                    nullptr, 0));
-#undef LIN2D
-    }
-    if (ss.ok) {
-      if (hipEventRecord(ss.join, ss.s) != hipSuccess) {
-        set_error("generate: adaptor stream join failed");
-        return GDR_EHIP;
-      }
-    }
+        GDR_TRY(LIN2N(ff2, aff, al.lin2_w, aff, xa, d, rows, nm, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d,
+                      ln(al.ln3_w, al.ln3_b, xa)));
+        return GDR_OK;
+    };
     // ---------------- T5 decoder stack (modeling_t5.py:498-584, 685-821)
-    for (int l = 0; l < dm.num_layers; ++l) {
+    auto dec_layer = [&](int l) -> int {
       const GdrT5DecLayer& ly = w->layers[l];
       float* cache = dcache + l * dlayer;
       float* slot = cache + s * dslab;
-      GDR_TRY(launch_rmsnorm(xd, ly.ln_self, nx, rows, d, dm.eps, nullptr, 1, stream));
+      // every later RMS norm rides on the reduction of the residual linear in front of it (dec_linear_norm)
+      if (l == 0) GDR_TRY(launch_rmsnorm(xd, ly.ln_self, nx, rows, d, dm.eps, nullptr, 1, stream));
       GDR_TRY(LIN(nx, d, ly.wqkv, d, slot, 3 * inner, rows, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
       AttnArgs at{};
       at.q = slot, at.k = cache + inner, at.v = cache + 2 * inner, at.out = ctx;
@@ -929,9 +1026,8 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 0;
       at.kv_rows = bb.kv_rows, at.kv_group = 1;
       GDR_TRY(launch_attention(at, stream));
-      GDR_TRY(LIN(ctx, inner, ly.wo, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d));
+      GDR_TRY(LINN(ctx, inner, ly.wo, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, rms(ly.ln_cross, nx)));
       // cross attention over the encoder states of the row's query
-      GDR_TRY(launch_rmsnorm(xd, ly.ln_cross, nx, rows, d, dm.eps, nullptr, 1, stream));
       GDR_TRY(LIN(nx, d, ly.wq_c, d, qc, inner, rows, inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
       AttnArgs ca{};
       const float* ckv = crosskv + l * ckv_layer;
@@ -945,12 +1041,29 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       ca.key_mask = enc_mask, ca.mask_bstride = L, ca.causal = 0, ca.causal_neg_inf = 0;
       ca.kv_rows = nullptr, ca.kv_group = 1;
       GDR_TRY(launch_attention(ca, stream));
-      GDR_TRY(LIN(ctx, inner, ly.wo_c, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d));
-      GDR_TRY(launch_rmsnorm(xd, ly.ln_ff, nx, rows, d, dm.eps, nullptr, 1, stream));
+      GDR_TRY(LINN(ctx, inner, ly.wo_c, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, rms(ly.ln_ff, nx)));
       GDR_TRY(LIN(nx, d, ly.wi, d, ff, dm.d_ff, rows, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0));
-      GDR_TRY(LIN(ff, dm.d_ff, ly.wo_ff, dm.d_ff, xd, d, rows, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, xd, d));
+      const bool last = l + 1 == dm.num_layers;  // the norm behind the block: the next block's first, or final_layer_norm
+      GDR_TRY(LINN(ff, dm.d_ff, ly.wo_ff, dm.d_ff, xd, d, rows, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, xd, d,
+                   rms(last ? w->final_ln : w->layers[l + 1].ln_self, last ? hl : nx)));
+      return GDR_OK;
+    };
+    // The two chains are enqueued layer by layer in turn: a host thread that first enqueued the whole adaptor chain left
+    // the main stream idle for as long as those ~55 launches take to issue (measured: a fifth of a 100-beam step).
+    for (int l = 0; l < dm.num_layers || l < w->adaptor_layers; ++l) {
+      if (l < dm.num_layers) GDR_TRY(dec_layer(l));
+      if (l < w->adaptor_layers) GDR_TRY(ptab ? ad_layer_tab(l) : ad_layer_plain(l));
     }
-    GDR_TRY(launch_rmsnorm(xd, w->final_ln, hl, rows, d, dm.eps, nullptr, 1, stream));
+    if (ptab)  // the head GEMM of the compacted rows belongs to the adaptor chain (it needs nothing from the decoder stack)
+      GDR_TRY(LIN2D(xa, d, w_at(w->head_w, (size_t)s * V1 * d * d, bf16), d, A, (int64_t)V1 * d, V1 * d, d, GDR_EPI_NONE, nullptr,
+                    nullptr, 0));
+#undef LIN2D
+    if (ss.ok) {
+      if (hipEventRecord(ss.join, ss.s) != hipSuccess) {
+        set_error("generate: adaptor stream join failed");
+        return GDR_EHIP;
+      }
+    }
     if (ss.ok && hipStreamWaitEvent(stream, ss.join, 0) != hipSuccess) {
       set_error("generate: adaptor stream join failed");
       return GDR_EHIP;
@@ -977,6 +1090,8 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
 #undef GDR_TRY
 #undef LIN
 #undef LIN2
+#undef LINN
+#undef LIN2N
 }
 }  // namespace gdr
 

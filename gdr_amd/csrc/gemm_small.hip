@@ -178,10 +178,121 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const float* _
   }
 }
 
+// Split-K reduction of a full-row output (N = the model width) fused with what always follows it on the decode path:
+// epilogue (bias, residual, activation) -> C, then a norm of the finished row -> Y.  One wave per row: the row stays in
+// registers between the two.  Same summation order as splitk_reduce_small_kernel (slabs s = 0..S-1, then bias, then
+// residual) and the same lane -> column map and arithmetic as rmsnorm_kernel / layernorm_kernel (layers.hip), so C and Y
+// are bit-identical to the three-launch form.
+//   kind 1: Y = w1 * x / sqrt(mean(x^2) + eps)                               (T5LayerNorm, modeling_t5.py:164-171)
+//   kind 2: Y = LN(x; w1, b1)                                                (torch.nn.LayerNorm)
+//   kind 3: Y = LN(LN(x; w1, b1) + addv; w2, b2)                             (the adaptor's norm1 -> norm2 with its constant
+//                                                                             single-key cross-attention output in between)
+template <int NV>  // float4 per lane: N = 256 * NV (exact) or less with the tail lanes masked
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ partial, int S, int tiles_n, int64_t M,
+                                                                int N, float* __restrict__ C, int64_t ldc,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ residual, int64_t ldr, int act,
+                                                                const int64_t* __restrict__ m_dev, const NormEpilogue ne) {
+  if (m_dev) M = *m_dev;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int lane = threadIdx.x & 63, n4 = N >> 2;
+  const int tm = (int)(m / SB), r = (int)(m - (int64_t)tm * SB);
+  float4 x[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;  // float4 column index, as in rmsnorm_kernel / layernorm_kernel
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < n4) {
+      const int n = c4 << 2, tn = n / SB, c = n - tn * SB;
+      const float* p = partial + ((int64_t)(tm * tiles_n + tn) * S) * (SB * SB) + r * SB + c;
+      v = *reinterpret_cast<const float4*>(p);
+      for (int s = 1; s < S; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)s * (SB * SB));
+        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+      }
+      if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+      }
+      if (residual) {
+        const float4 q = *reinterpret_cast<const float4*>(residual + m * ldr + n);
+        v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+      }
+      if (act == 1) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+      *reinterpret_cast<float4*>(C + m * ldc + n) = v;
+    }
+    x[i] = v;
+  }
+  auto wsum = [](float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  float* yr = ne.Y + m * ne.ldy;
+  if (ne.kind == 1) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < n4) ss += x[i].x * x[i].x + x[i].y * x[i].y + x[i].z * x[i].z + x[i].w * x[i].w;
+    const float denom = sqrtf(wsum(ss) / (float)N + ne.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 >= n4) continue;
+      const float4 g = reinterpret_cast<const float4*>(ne.w1)[c4], v = x[i];
+      *reinterpret_cast<float4*>(yr + 4 * c4) = make_float4(g.x * (v.x / denom), g.y * (v.y / denom), g.z * (v.z / denom),
+                                                            g.w * (v.w / denom));
+    }
+    return;
+  }
+  const float inv_d = 1.0f / (float)N;
+  auto layer_norm = [&](const float* w, const float* b) {  // x <- LN(x), arithmetic of layernorm_kernel
+    float su = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < n4) su += x[i].x + x[i].y + x[i].z + x[i].w;
+    const float mean = wsum(su) * inv_d;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < n4) {
+        const float a0 = x[i].x - mean, a1 = x[i].y - mean, a2 = x[i].z - mean, a3 = x[i].w - mean;
+        ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+      }
+    const float rstd = 1.0f / sqrtf(wsum(ss) * inv_d + ne.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 >= n4) continue;
+      const float4 g = reinterpret_cast<const float4*>(w)[c4], bb = reinterpret_cast<const float4*>(b)[c4], v = x[i];
+      x[i] = make_float4((v.x - mean) * rstd * g.x + bb.x, (v.y - mean) * rstd * g.y + bb.y, (v.z - mean) * rstd * g.z + bb.z,
+                         (v.w - mean) * rstd * g.w + bb.w);
+    }
+  };
+  layer_norm(ne.w1, ne.b1);
+  if (ne.kind == 3) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 >= n4) continue;
+      const float4 t = reinterpret_cast<const float4*>(ne.addv)[c4];
+      x[i].x += t.x, x[i].y += t.y, x[i].z += t.z, x[i].w += t.w;
+    }
+    layer_norm(ne.w2, ne.b2);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < n4) *reinterpret_cast<float4*>(yr + 4 * c4) = x[i];
+  }
+}
+
 // Returns 1 when the shape is left to the 128x128 core, 0 after launching, < 0 on error.
 int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
-                            int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev) {
+                            int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev,
+                            const NormEpilogue* ne) {
   static const int target = [] {
     const char* e = getenv("GDR_SMALL_TARGET");  // tuning knob: workgroups wanted per launch; 0 disables this kernel
     return e ? atoi(e) : 512;
@@ -206,6 +317,7 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
   g.ksplit = S, g.kchunk = chunk_steps * SBK;
   g.m_dev = m_dev;
   const double flops = 2.0 * (double)M * (double)N * (double)K;
+  if (ne && (S == 1 || N % 4 != 0 || N > 256 * 4 * 4 || act > 1)) return 2;  // the fused norm needs split slabs of a row it can hold
   if (S == 1) {
     g.C = C, g.has_bias = has_bias, g.has_residual = has_residual, g.act = act;
     ProfScope prof(PROF_LINEAR, flops, stream);
@@ -220,6 +332,21 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
   }
   GDR_CHECK_LAUNCH("gemm_nt_f32_small_kernel(split)");
   ProfScope prof_r(PROF_REDUCE, 0.0, stream);
+  if (ne) {
+    const unsigned grid = (unsigned)((M + 3) / 4);
+    const float* bp = has_bias ? bias : nullptr;
+    const float* rp = has_residual ? residual : nullptr;
+    const int nv = (N / 4 + 63) / 64;
+#define GDR_RN(NV_) \
+  hipLaunchKernelGGL(splitk_reduce_norm_kernel<NV_>, dim3(grid), dim3(256), 0, stream, ws, S, tiles_n, M, N, C, ldc, bp, rp, ldr, act, m_dev, *ne)
+    if (nv <= 1) GDR_RN(1);
+    else if (nv == 2) GDR_RN(2);
+    else if (nv == 3) GDR_RN(3);
+    else GDR_RN(4);
+#undef GDR_RN
+    GDR_CHECK_LAUNCH("splitk_reduce_norm_kernel");
+    return 0;
+  }
   hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((unsigned)(tiles * 4)), dim3(256), 0, stream, ws, S, tiles_n, M, N, C, ldc,
                      has_bias ? bias : nullptr, has_residual ? residual : nullptr, ldr, act, m_dev);
   GDR_CHECK_LAUNCH("splitk_reduce_small_kernel");

@@ -61,7 +61,7 @@ class GDRModel:
     inference only.  Construct from a reference-style state_dict (SURVEY Appendix C key names)."""
 
     def __init__(self, cfg: GDRConfig, state_dict, device="cuda:0", with_decoder=True, trie=None, ragged=False,
-                 prefix_trie=None, dtype=torch.float32):
+                 prefix_trie=None, dtype=torch.float32, graph=False):
         """trie: optional codec.Trie — enables the NCI trie constraint of the reference's earlier
         generation_utils_previous.py:714-729 (the shipped generate() ignores `decode_tree`).
         ragged: generate() skips the PAD rows of the encoder (gdr_t5_encoder_forward_ragged).  Decoded ids, scores and the
@@ -73,7 +73,9 @@ class GDRModel:
         recomputing them (modeling_t5.py:1618-1639); other beams are computed as before.  Same logits up to fp32
         summation order.  When `trie` (the constraint) is given too it must be the same trie.
         dtype=torch.bfloat16: BASELINE config C5's precision mode (the reference has none: precision=32) — every linear of
-        encoder, decoder, adaptor and head takes bf16 operands with fp32 accumulate; all other arithmetic stays fp32."""
+        encoder, decoder, adaptor and head takes bf16 operands with fp32 accumulate; all other arithmetic stays fp32.
+        graph: replay the decode (gdr_t5_generate) of a repeated call shape as one captured HIP graph instead of ~1 400
+        host launches per call (ops.T5DecoderHandle.generate); same kernels, same results."""
         self.config = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -93,6 +95,7 @@ class GDRModel:
             self.trie = None
         else:                                     # the constraint shares the table's breadth-first arrays
             self.trie = self.prefix_table.device_trie if self.prefix_table is not None else ops.DeviceTrie(trie, self.device)
+        self.graph = bool(graph)
         self.ragged = bool(ragged) and dtype == torch.float32      # the ragged encoder form is fp32 only
         self.training = False
 
@@ -143,7 +146,8 @@ class GDRModel:
         input_ids, attention_mask = input_ids.to(self.device), attention_mask.to(self.device)
         enc_h, _ = self.enc.forward(input_ids, attention_mask, want_pooled=False, ragged=self.ragged)
         ids, lens, scores = self.dec.generate(enc_h, attention_mask, num_beams, max_length, length_penalty,
-                                              num_return_sequences, trie=self.trie, prefix_table=self.prefix_table)
+                                              num_return_sequences, trie=self.trie, prefix_table=self.prefix_table,
+                                              graph=self.graph)
         decoded, score_list = ops.finish_generate_output(ids, lens, scores, max_length)
         output = (decoded, score_list) if output_scores else decoded
         if output_encoder_embedding:

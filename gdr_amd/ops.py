@@ -422,29 +422,68 @@ class T5DecoderHandle:
         self.ws = Workspace(device)
 
     def generate(self, enc_hidden, enc_mask, num_beams, max_length, length_penalty, num_return_sequences, trace=False,
-                 trie=None, prefix_table=None):
-        """Returns (out_ids int64[B*nret,max_length], out_len int32[B*nret], out_scores float64[B*nret][, trace])."""
+                 trie=None, prefix_table=None, graph=False):
+        """Returns (out_ids int64[B*nret,max_length], out_len int32[B*nret], out_scores float64[B*nret][, trace]).
+        graph=True: the ~1 400 kernel launches of one call are captured once per (B, L, beams, max_length, nret) into a HIP
+        graph (gdr_t5_generate contains no host synchronisation and forks / joins its side stream with events, i.e. it is
+        capturable as is) and replayed on later calls — at small batches (one query x 100 beams, infer.sh's setting) the
+        call is otherwise bound by the host's launch rate, not by the GPU."""
         _need_cuda(enc_hidden, enc_mask)
         enc_hidden = _f32c(enc_hidden)
         mask = enc_mask.to(torch.int64).contiguous()
         B, L, _ = enc_hidden.shape
         R, nret = int(num_beams), int(num_return_sequences)
-        need = lib().gdr_t5_generate_workspace_bytes(C.byref(self.struct), B, L, R, max_length)
-        ws = self.ws.get(need)
         dev_ = enc_hidden.device
-        ids = torch.empty((B * nret, max_length), dtype=torch.int64, device=dev_)
-        lens = torch.empty((B * nret,), dtype=torch.int32, device=dev_)
-        scores = torch.empty((B * nret,), dtype=torch.float64, device=dev_)
+        fn = lib().gdr_t5_generate_bf16 if self.dtype == torch.bfloat16 else lib().gdr_t5_generate
+        need = lib().gdr_t5_generate_workspace_bytes(C.byref(self.struct), B, L, R, max_length)
+
+        def call(enc_t, mask_t, ids, lens, scores, ts, tt, ws):
+            check(fn(C.byref(self.struct), ptr(enc_t), ptr(mask_t), B, L, R, max_length,
+                     float(length_penalty), nret, trie.struct_ref() if trie is not None else None,
+                     prefix_table.struct_ref() if prefix_table is not None else None,
+                     ptr(ids), ptr(lens), ptr(scores), ptr(ts), ptr(tt),
+                     ptr(ws), ws.numel(), stream_ptr()), "gdr_t5_generate")
+
+        def outputs():
+            ids = torch.empty((B * nret, max_length), dtype=torch.int64, device=dev_)
+            lens = torch.empty((B * nret,), dtype=torch.int32, device=dev_)
+            scores = torch.empty((B * nret,), dtype=torch.float64, device=dev_)
+            return ids, lens, scores
+
+        if graph and not trace:
+            key = (B, L, R, max_length, nret, float(length_penalty), id(trie), id(prefix_table))
+            if not hasattr(self, "_graphs"):
+                self._graphs = {}
+            entry = self._graphs.get(key)
+            if entry is None:
+                s_enc, s_mask = torch.empty_like(enc_hidden), torch.empty_like(mask)
+                s_ids, s_lens, s_scores = outputs()
+                s_ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=dev_)
+                s_enc.copy_(enc_hidden)
+                s_mask.copy_(mask)
+                warm = torch.cuda.Stream(device=dev_)                 # capture needs one eager run first (kernel
+                warm.wait_stream(torch.cuda.current_stream())         # attributes, the side-stream lease, lazy module loads)
+                with torch.cuda.stream(warm):
+                    call(s_enc, s_mask, s_ids, s_lens, s_scores, None, None, s_ws)
+                torch.cuda.current_stream().wait_stream(warm)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    call(s_enc, s_mask, s_ids, s_lens, s_scores, None, None, s_ws)
+                entry = self._graphs[key] = (g, s_enc, s_mask, s_ids, s_lens, s_scores, s_ws)
+            g, s_enc, s_mask, s_ids, s_lens, s_scores, _ = entry
+            s_enc.copy_(enc_hidden)
+            s_mask.copy_(mask)
+            g.replay()
+            return s_ids.clone(), s_lens.clone(), s_scores.clone()
+
+        ws = self.ws.get(need)
+        ids, lens, scores = outputs()
         ts = tt = None
         if trace:
             ts = torch.empty((max_length - 1, B, 2 * R), dtype=torch.float32, device=dev_)
             tt = torch.empty((max_length - 1, B, 2 * R), dtype=torch.int32, device=dev_)
-        fn = lib().gdr_t5_generate_bf16 if self.dtype == torch.bfloat16 else lib().gdr_t5_generate
-        check(fn(C.byref(self.struct), ptr(enc_hidden), ptr(mask), B, L, R, max_length,
-                                    float(length_penalty), nret, trie.struct_ref() if trie is not None else None,
-                                    prefix_table.struct_ref() if prefix_table is not None else None,
-                                    ptr(ids), ptr(lens), ptr(scores), ptr(ts), ptr(tt),
-                                    ptr(ws), ws.numel(), stream_ptr()), "gdr_t5_generate")
+        call(enc_hidden, mask, ids, lens, scores, ts, tt, ws)
         return (ids, lens, scores, ts, tt) if trace else (ids, lens, scores)
 
 

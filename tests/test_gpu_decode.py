@@ -326,3 +326,21 @@ def test_generate_bf16_mode_vs_oracle_emulation(dev, kind, B, R, use_table):
         assert len(gset & rset) >= 0.7 * R, (b, len(gset & rset))
         if rs[b, 0] - rs[b, 1] > 3e-2 * (1 + abs(rs[b, 0])):
             assert tuple(got[b * R][:W]) == tuple(ref[b * R][:W])
+
+
+def test_generate_graph_replay_is_identical(dev):
+    """GDRModel(graph=True): gdr_t5_generate captured into a HIP graph (it has no host sync; its side stream forks and
+    joins with events) and replayed — same ids and scores as the eager launches, also after the inputs change."""
+    from gdr_amd.modeling import GDRModel
+    cfg = GDRConfig.tiny()
+    sd = synth.make_state_dict(cfg, seed=1234)
+    eager, graphed = GDRModel(cfg, sd, dev), GDRModel(cfg, sd, dev, graph=True)
+    for seed in (1, 2, 3):
+        ids, mask = synth.make_tokens(4, L=9, vocab_hi=cfg.vocab_size, seed=seed, min_len=2)
+        it, mt = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+        kw = dict(attention_mask=mt, max_length=cfg.max_output_length, num_beams=5, length_penalty=0.8, num_return_sequences=5,
+                  output_scores=True)
+        (d0, s0), _ = eager.generate(it, **kw)
+        (d1, s1), _ = graphed.generate(it, **kw)
+        assert torch.equal(d0, d1) and s0 == s1
+    assert len(graphed.dec._graphs) == 1

@@ -14,7 +14,7 @@ model = GDRModel(cfg, synth.make_state_dict(cfg, seed=1234), dev, ragged=True,
                  prefix_trie=None if os.environ.get("NO_PREFIX_TABLE") else codec.Trie.from_docids(names, 30))
 ids, mask = synth.make_tokens(B, L=40, seed=11)
 ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
-for _ in range(4):
+for _ in range(int(os.environ.get("CALLS", 4))):
     model.generate(ids, attention_mask=mask, max_length=10, num_beams=R, length_penalty=0.8, num_return_sequences=R,
                    output_scores=True, output_encoder_embedding=True)
     torch.cuda.synchronize()
