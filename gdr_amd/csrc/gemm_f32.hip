@@ -651,6 +651,9 @@ struct StreamKArgs {
 // times against T/256 ideally; stream-K runs when that loss exceeds GDR_GEMM_STREAMK percent (default 12; 0 = never,
 // 1 = always).  The tile count comes from the caller's row hint when the real count lives on the device — a tuning
 // input only: both kernels are correct for any row count.
+static bool streamk_fits(int64_t M, int64_t lda, int N, int64_t ldw) {  // 32-bit element offsets inside the kernel
+  return M * lda < 0x7fffffffLL && (int64_t)N * ldw < 0x7fffffffLL;
+}
 static bool streamk_wanted(int64_t tiles) {
   static const int pct = [] {
     const char* e = getenv("GDR_GEMM_STREAMK");
@@ -688,8 +691,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
   const int tiles_m = (int)((Mrows + BM - 1) / BM);
   const int total_tiles = g.m_dev ? tiles_m * g.tiles_n : total_tiles_host;
 
-  int64_t a_ld[4];  // element offsets from g.A / g.W — kept as integers: pointers that pass through the tile-crossing
-  int64_t w_ld[4];  // select lose their address space and the loads degrade to flat_load (vmcnt AND lgkmcnt)
+  int a_ld[4];  // element offsets from g.A / g.W, 32-bit (the launcher sends operands of >= 2^31 elements to the whole-tile
+  int w_ld[4];  // kernel): with 64-bit offsets the segment bookkeeping pushed three spills into the K-step
 // tile index -> (row panel, column tile): supertiles of GM row panels x all column tiles, row-panel-fastest inside, so
 // that the 64 tiles an XCD works on at a time are ~8 row panels x 8 column tiles (16 operand panels through its L2)
 // instead of a few row panels x every column tile (N=3072: 27 panels).  GM travels in g.ksplit (unused by this kernel).
@@ -710,8 +713,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
       ra_ = ra_ < Mrows ? ra_ : Mrows - 1;                                   \
       int rw_ = nt_ * BN + lrow + 32 * p;                                    \
       rw_ = rw_ < g.N ? rw_ : g.N - 1;                                       \
-      a_ld[p] = ra_ * g.lda + lcol;                                          \
-      w_ld[p] = (int64_t)rw_ * g.ldw + lcol;                                 \
+      a_ld[p] = (int)(ra_ * g.lda + lcol);                                   \
+      w_ld[p] = (int)((int64_t)rw_ * g.ldw + lcol);                          \
     }                                                                        \
   }
   float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
     ld_seg = ld_seg + 1 < nseg ? ld_seg + 1 : nseg - 1;                      \
     SK_SEG(ld_seg, ld_tile, ld_kt, ld_kend)                                  \
     P_SETPTRS(ld_tile)                                                       \
-    _Pragma("unroll") for (int p = 0; p < 4; ++p) a_ld[p] += (int64_t)ld_kt * BK, w_ld[p] += (int64_t)ld_kt * BK; \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) a_ld[p] += ld_kt * BK, w_ld[p] += ld_kt * BK; \
   } else {                                                                   \
     _Pragma("unroll") for (int p = 0; p < 4; ++p) a_ld[p] += BK, w_ld[p] += BK; \
   }
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
   int ld_seg = 0, ld_kt, ld_kend, ld_tile;
   SK_SEG(0, ld_tile, ld_kt, ld_kend)
   P_SETPTRS(ld_tile)
-  _Pragma("unroll") for (int p = 0; p < 4; ++p) a_ld[p] += (int64_t)ld_kt * BK, w_ld[p] += (int64_t)ld_kt * BK;
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) a_ld[p] += ld_kt * BK, w_ld[p] += ld_kt * BK;
   P_GLOAD
   P_ADVANCE
   P_LSTORE(0)
@@ -1168,7 +1171,7 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
       // outputs only.  Time is unchanged either way (the kernel is MFMA-bound); this is traffic and energy.
       g.ksplit = gm_env > 0 ? gm_env : (g.tiles_n >= 12 ? 8 : 1);
     }
-    if (sk && streamk_wanted(tiles)) {
+    if (sk && streamk_wanted(tiles) && streamk_fits(M, lda, N, ldw)) {
       const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch};
       hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3((unsigned)SLOTS), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
       GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel");
@@ -1216,7 +1219,7 @@ int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t l
   if (tiles > 512) {
     g.ksplit = g.tiles_n >= 12 ? 8 : 1;  // supertile height, as in launch_linear_f32_ws
     const int64_t tiles_live = prof_rows >= 0 ? ((prof_rows + BM - 1) / BM) * g.tiles_n : tiles;
-    if (sk && streamk_wanted(tiles_live)) {
+    if (sk && streamk_wanted(tiles_live) && streamk_fits(M_max, lda, N, ldw)) {
       const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch};
       hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3(512), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
       GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel(dev rows)");
