@@ -250,12 +250,12 @@ def stages(dev, cfg, D, D_dev, a):
     ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
 
     def step16():
-        _, pooled = enc16.forward(ids, mask)
+        _, pooled = enc16.forward(ids, mask, want_hidden=False, ragged=True, live_rows_hint=int(mask.sum()))
         return ops.sim_topk(pooled, D16, k, workspace=ws, exact_on_overflow=False)
 
     t = timed(step16, reps=5, warm=2)
     out["bf16_mode_c2_step"] = {"ms": t * 1e3, "queries_per_s": a.batch / t,
-                                "note": "padded encoder with bf16 linear operands + bf16 corpus similarity, fp32 accumulate"}
+                                "note": "ragged encoder with bf16 linear operands + bf16 corpus similarity, fp32 accumulate"}
     del enc16
     torch.cuda.empty_cache()
     # ---- config C5's decode leg: beam 30, bf16 linears in encoder / decoder / adaptor / head (prefix table built in bf16)
@@ -308,7 +308,7 @@ def main():
     ids_all, mask_all = synth.make_tokens(a.batch * world, L=40, seed=11)
     ids = torch.from_numpy(ids_all[rank * a.batch:(rank + 1) * a.batch]).to(dev)
     mask = torch.from_numpy(mask_all[rank * a.batch:(rank + 1) * a.batch]).to(dev)
-    ragged = a.encoder == "ragged" and not bf16
+    ragged = a.encoder == "ragged"
     live_rows = int(mask_all[rank * a.batch:(rank + 1) * a.batch].sum())      # token rows that are not PAD (host-side metadata)
 
     pending = [None]
@@ -316,10 +316,7 @@ def main():
     def step():
         """One batch through the path.  N > 1: the exchange + merge of this batch is left in flight on a side stream and
         joined at the start of the next step's search, i.e. it overlaps the next batch's encoder."""
-        if bf16:
-            _, pooled = enc.forward(ids, mask)
-        else:
-            _, pooled = enc.forward(ids, mask, want_hidden=False, ragged=ragged, live_rows_hint=live_rows)
+        _, pooled = enc.forward(ids, mask, want_hidden=False, ragged=ragged, live_rows_hint=live_rows)
         q_all = index.gather_queries(pooled)
         if a.replicated_merge:
             return index.search(q_all, a.k, return_status=True)

@@ -87,6 +87,7 @@ SIGNATURES = {
     "gdr_t5_encoder_forward": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "gdr_t5_encoder_ragged_workspace_bytes": (_sz, [C.POINTER(GdrT5Dims), _i, _i]),
     "gdr_t5_encoder_forward_ragged": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "gdr_t5_encoder_forward_ragged_bf16": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "gdr_t5_encoder_bf16_workspace_bytes": (_sz, [C.POINTER(GdrT5Dims), _i, _i]),
     "gdr_t5_encoder_forward_bf16": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "gdr_sim_topk_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i]),

@@ -203,14 +203,13 @@ static bool ragged_packs(const GdrT5Dims& dm, int B, int L) {
 
 extern "C" size_t gdr_t5_encoder_ragged_workspace_bytes(const GdrT5Dims* dims, int B, int L) {
   if (!dims || B <= 0 || L <= 0) return 0;
-  return gdr::rag_ws(*dims, B, L, gdr::enc_ws(*dims, (int64_t)B * L).total).total;
+  return gdr::rag_ws(*dims, B, L, gdr::enc_ws(*dims, (int64_t)B * L, true).total).total;  // serves both precisions
 }
 
-extern "C" int gdr_t5_encoder_forward_ragged(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B,
-                                             int L, float* out_hidden, float* out_pooled, int64_t live_rows_hint,
-                                             void* workspace, size_t workspace_bytes, void* stream_) {
-  using namespace gdr;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+namespace gdr {
+static int ragged_impl(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L, float* out_hidden,
+                       float* out_pooled, int64_t live_rows_hint, void* workspace, size_t workspace_bytes, bool bf16,
+                       hipStream_t stream) {
   if (B == 0) return GDR_OK;
   GDR_CHECK_ARG(w && ids && mask && workspace && (out_hidden || out_pooled), "t5_encoder_ragged: null pointer");
   const GdrT5Dims& dm = w->dims;
@@ -218,7 +217,7 @@ extern "C" int gdr_t5_encoder_forward_ragged(const GdrT5EncoderWeights* w, const
   GDR_CHECK_ARG(dm.d_model % 4 == 0 && dm.d_kv % 4 == 0 && dm.d_ff % 4 == 0, "t5_encoder_ragged: dims must be multiples of 4");
   GDR_CHECK_ARG(w->embed && w->rel_bias && w->final_ln && w->layers, "t5_encoder_ragged: null weight pointer");
   const int64_t M = (int64_t)B * L;
-  const EncWs ws = enc_ws(dm, M);
+  const EncWs ws = enc_ws(dm, M, true);
   const RagWs rw = rag_ws(dm, B, L, ws.total);
   if (workspace_bytes < rw.total) {
     set_error("t5_encoder_ragged: workspace %zu < required %zu", workspace_bytes, rw.total);
@@ -233,12 +232,83 @@ extern "C" int gdr_t5_encoder_forward_ragged(const GdrT5EncoderWeights* w, const
   int32_t* row_src = reinterpret_cast<int32_t*>(base + rw.row_src);
   int64_t* rows_dev = reinterpret_cast<int64_t*>(base + rw.rows_total);
   if ((rc = launch_pack_plan(mask, B, L, seq_len, seq_off, row_src, rows_dev, stream))) return rc;
-  if (!ragged_packs(dm, B, L)) {
+  // bf16 precision mode: the packed form exists for the fused producer chain only (every contraction a multiple of 64)
+  const bool fused16 = bf16 && d % 64 == 0 && inner % 64 == 0 && dm.d_ff % 64 == 0 && (((uintptr_t)w->layers[0].wqkv) & 15) == 0;
+  if (!ragged_packs(dm, B, L) || (bf16 && !fused16)) {
     // small problem / other head size: the padded forward, then the rows that the packed form would not have computed
     // are zeroed so that the output contract does not depend on which form ran
-    float* full = out_hidden ? out_hidden : reinterpret_cast<float*>(base + ws.off_ff);  // ff is dead when the final norm runs
-    if ((rc = t5_encoder_impl(w, ids, mask, B, L, full, out_pooled, workspace, ws.total, false, stream))) return rc;
+    float* full = out_hidden ? out_hidden : reinterpret_cast<float*>(base + ws.off_qkv);  // qkv is dead when the final norm runs
+    if ((rc = t5_encoder_impl(w, ids, mask, B, L, full, out_pooled, workspace, ws.total, bf16, stream))) return rc;
     return out_hidden ? launch_zero_dead_rows(out_hidden, seq_len, B, L, d, stream) : GDR_OK;
+  }
+  if (bf16) {
+    // ---- packed form of the bf16 precision mode: the producers write the bf16 operand of the next linear (RMSNorm, the
+    //      attention context, the ReLU epilogue of wi); same rounding points as gdr_t5_encoder_forward_bf16, rows independent
+    float* h = reinterpret_cast<float*>(base + ws.off_h);
+    float* nx = reinterpret_cast<float*>(base + ws.off_nx);
+    float* qkv = reinterpret_cast<float*>(base + ws.off_qkv);
+    float* ff = reinterpret_cast<float*>(base + ws.off_ff);
+    void* abf = base + ws.off_bf;
+    float* h_cls = reinterpret_cast<float*>(base + rw.h_cls);
+    void* ctx_cls16 = base + rw.ctx_cls;
+    void* nx_cls16 = base + rw.nx_cls;
+    void* ff_cls16 = base + rw.ff_cls;
+    auto lin16 = [&](const void* A, const float* W, float* C, int64_t ldc, int64_t rows, const int64_t* md, int N, int K, int act,
+                     const float* residual, int out_bf16) -> int {
+      ProfScope prof(PROF_LINEAR, 2.0 * (double)(md && live_rows_hint >= 0 ? live_rows_hint : rows) * (double)N * (double)K, stream);
+      const int rc_ = launch_linear_bf16_glds(A, K, W, K, C, ldc, rows, N, K, 0, residual != nullptr, act, nullptr, residual, ldc,
+                                              out_bf16, stream, md);
+      if (rc_ > 0) {
+        set_error("t5_encoder_ragged_bf16: shape not served by the LDS-DMA linear");
+        return GDR_EINVAL;
+      }
+      return rc_;
+    };
+    if ((rc = launch_embed_packed(w->embed, ids, row_src, rows_dev, M, d, dm.vocab_size, h, stream))) return rc;
+    AttnArgs at{};
+    at.q = qkv, at.k = qkv + inner, at.v = qkv + 2 * inner, at.out = nullptr, at.out_bf16 = abf;
+    at.ldq = at.ldk = at.ldv = 3 * inner, at.ldo = inner;
+    at.q_bstride = at.k_bstride = at.o_bstride = L;
+    at.B = B, at.H = H, at.dk = dk, at.Lq = L, at.Lk = L;
+    at.q_pos0 = 0, at.scale = 1.0f;
+    at.rel_bias = w->rel_bias, at.bidirectional = 1, at.num_buckets = dm.rel_buckets;
+    at.lut = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
+    at.key_mask = mask, at.mask_bstride = L, at.causal = 0, at.causal_neg_inf = 0;
+    at.kv_rows = nullptr, at.kv_group = 1;
+    at.seq_off = seq_off, at.seq_len = seq_len;
+    const bool pooled_only = out_hidden == nullptr;
+    for (int i = 0; i < dm.num_layers; ++i) {
+      const GdrT5EncLayer& ly = w->layers[i];
+      GDR_CHECK_ARG(ly.ln_attn && ly.wqkv && ly.wo && ly.ln_ff && ly.wi && ly.wo_ff, "t5_encoder_ragged: layer %d null weight", i);
+      if ((rc = launch_rmsnorm_bf16_dev(h, ly.ln_attn, abf, rows_dev, M, d, dm.eps, stream))) return rc;
+      if ((rc = lin16(abf, ly.wqkv, qkv, 3 * inner, M, rows_dev, 3 * inner, d, 0, nullptr, 0))) return rc;
+      if ((rc = launch_attention(at, stream))) return rc;  // ctx -> abf as bf16 [rows, inner]
+      if (pooled_only && i == dm.num_layers - 1) {
+        // bf16 rows are inner/2 (d/2, d_ff/2) floats wide for the row mover
+        if ((rc = launch_gather_rows(static_cast<const float*>(abf), seq_off, B, inner / 2, static_cast<float*>(ctx_cls16), stream)))
+          return rc;
+        if ((rc = launch_gather_rows(h, seq_off, B, d, h_cls, stream))) return rc;
+        if ((rc = lin16(ctx_cls16, ly.wo, h_cls, d, B, nullptr, d, inner, 0, h_cls, 0))) return rc;
+        if ((rc = launch_rmsnorm_bf16(h_cls, ly.ln_ff, nx_cls16, B, d, dm.eps, stream))) return rc;
+        if ((rc = lin16(nx_cls16, ly.wi, static_cast<float*>(ff_cls16), dm.d_ff, B, nullptr, dm.d_ff, d, 1, nullptr, 1))) return rc;
+        if ((rc = lin16(ff_cls16, ly.wo_ff, h_cls, d, B, nullptr, d, dm.d_ff, 0, h_cls, 0))) return rc;
+        return launch_rmsnorm(h_cls, w->final_ln, out_pooled, B, d, dm.eps, nullptr, 1, stream);
+      }
+      if ((rc = lin16(abf, ly.wo, h, d, M, rows_dev, d, inner, 0, h, 0))) return rc;
+      if ((rc = launch_rmsnorm_bf16_dev(h, ly.ln_ff, abf, rows_dev, M, d, dm.eps, stream))) return rc;
+      if ((rc = lin16(abf, ly.wi, ff, dm.d_ff, M, rows_dev, dm.d_ff, d, 1, nullptr, 1))) return rc;  // relu, bf16 out (in the ff buffer)
+      if ((rc = lin16(ff, ly.wo_ff, h, d, M, rows_dev, d, dm.d_ff, 0, h, 0))) return rc;
+    }
+    if ((rc = launch_rmsnorm_dev(h, w->final_ln, nx, rows_dev, M, d, dm.eps, stream))) return rc;
+    if (out_pooled && (rc = launch_gather_rows(nx, seq_off, B, d, out_pooled, stream))) return rc;
+    if (out_hidden) {
+      if (hipMemsetAsync(out_hidden, 0, (size_t)M * d * sizeof(float), stream) != hipSuccess) {
+        set_error("t5_encoder_ragged: memset failed");
+        return GDR_EHIP;
+      }
+      if ((rc = launch_scatter_rows(nx, row_src, rows_dev, M, d, out_hidden, stream))) return rc;
+    }
+    return GDR_OK;
   }
   float* h = reinterpret_cast<float*>(base + ws.off_h);
   float* nx = reinterpret_cast<float*>(base + ws.off_nx);
@@ -308,6 +378,21 @@ extern "C" int gdr_t5_encoder_forward_ragged(const GdrT5EncoderWeights* w, const
     if ((rc = launch_scatter_rows(nx, row_src, rows_dev, M, d, out_hidden, stream))) return rc;
   }
   return GDR_OK;
+}
+}  // namespace gdr
+
+extern "C" int gdr_t5_encoder_forward_ragged(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B,
+                                             int L, float* out_hidden, float* out_pooled, int64_t live_rows_hint,
+                                             void* workspace, size_t workspace_bytes, void* stream_) {
+  return gdr::ragged_impl(w, ids, mask, B, L, out_hidden, out_pooled, live_rows_hint, workspace, workspace_bytes, false,
+                          static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int gdr_t5_encoder_forward_ragged_bf16(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B,
+                                                  int L, float* out_hidden, float* out_pooled, int64_t live_rows_hint,
+                                                  void* workspace, size_t workspace_bytes, void* stream_) {
+  return gdr::ragged_impl(w, ids, mask, B, L, out_hidden, out_pooled, live_rows_hint, workspace, workspace_bytes, true,
+                          static_cast<hipStream_t>(stream_));
 }
 
 extern "C" size_t gdr_t5_encoder_bf16_workspace_bytes(const GdrT5Dims* dims, int B, int L) {

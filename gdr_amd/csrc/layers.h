@@ -72,6 +72,8 @@ int launch_rmsnorm_dev(const float* x, const float* w, float* y, const int64_t* 
                        hipStream_t stream);
 // same, output rounded to bf16 (RNE): the activation operand of a bf16-mode linear
 int launch_rmsnorm_bf16(const float* x, const float* w, void* y_bf16, int64_t rows, int d, float eps, hipStream_t stream);
+int launch_rmsnorm_bf16_dev(const float* x, const float* w, void* y_bf16, const int64_t* rows_dev, int64_t max_rows, int d,
+                            float eps, hipStream_t stream);
 // y = (x - mean) / sqrt(var + eps) * w + b   (torch.nn.LayerNorm; BERT / nn.TransformerDecoderLayer)
 // optional addv [d]: y = LN(x + addv)  (the adaptor's constant single-key cross-attention output)
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int d, float eps,

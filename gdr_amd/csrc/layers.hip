@@ -274,6 +274,16 @@ int launch_rmsnorm_bf16(const float* x, const float* w, void* y_bf16, int64_t ro
   return GDR_OK;
 }
 
+int launch_rmsnorm_bf16_dev(const float* x, const float* w, void* y_bf16, const int64_t* rows_dev, int64_t max_rows, int d,
+                            float eps, hipStream_t stream) {
+  GDR_CHECK_ARG(d % 4 == 0, "rmsnorm: d %% 4 != 0");
+  if (max_rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3((unsigned)((max_rows + 3) / 4)), dim3(256), 0, stream, x, w,
+                     static_cast<float*>(y_bf16), max_rows, d / 4, eps, (float*)nullptr, 1, rows_dev);
+  GDR_CHECK_LAUNCH("rmsnorm_kernel<bf16>(dev rows)");
+  return GDR_OK;
+}
+
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y,
                                                         int64_t rows, int d4, float eps,

@@ -96,7 +96,7 @@ class GDRModel:
         else:                                     # the constraint shares the table's breadth-first arrays
             self.trie = self.prefix_table.device_trie if self.prefix_table is not None else ops.DeviceTrie(trie, self.device)
         self.graph = bool(graph)
-        self.ragged = bool(ragged) and dtype == torch.float32      # the ragged encoder form is fp32 only
+        self.ragged = bool(ragged)
         self.training = False
 
     def eval(self):

@@ -255,14 +255,12 @@ class T5EncoderHandle:
         d = self.cfg.d_model
         pooled = torch.empty((B, d), dtype=torch.float32, device=ids.device) if want_pooled else None
         if ragged:
-            if bf:
-                raise _ffi.GdrError("the ragged encoder form is fp32 only")
             need = lib().gdr_t5_encoder_ragged_workspace_bytes(C.byref(self.dims), B, L)
             ws = self.ws.get(need)
             out = torch.empty((B, L, d), dtype=torch.float32, device=ids.device) if want_hidden else None
-            check(lib().gdr_t5_encoder_forward_ragged(C.byref(self.struct), ptr(ids), ptr(mask), B, L, ptr(out), ptr(pooled),
-                                                      int(live_rows_hint), ptr(ws), ws.numel(), stream_ptr()),
-                  "gdr_t5_encoder_forward_ragged")
+            rfn = lib().gdr_t5_encoder_forward_ragged_bf16 if bf else lib().gdr_t5_encoder_forward_ragged
+            check(rfn(C.byref(self.struct), ptr(ids), ptr(mask), B, L, ptr(out), ptr(pooled), int(live_rows_hint), ptr(ws),
+                      ws.numel(), stream_ptr()), "gdr_t5_encoder_forward_ragged")
             return out, pooled
         need = (lib().gdr_t5_encoder_bf16_workspace_bytes if bf else lib().gdr_t5_encoder_workspace_bytes)(
             C.byref(self.dims), B, L)

@@ -135,6 +135,13 @@ int gdr_t5_encoder_forward_ragged(const GdrT5EncoderWeights* w, const int64_t* i
                                   float* out_hidden, float* out_pooled, int64_t live_rows_hint, void* workspace,
                                   size_t workspace_bytes, void* stream);
 
+/* The ragged form in the bf16 precision mode below (weights as for gdr_t5_encoder_forward_bf16): same contract, kept rows
+ * bit-identical to gdr_t5_encoder_forward_bf16.  The packed kernels serve the fused bf16 chain (d_model, inner and d_ff
+ * multiples of 64); other shapes run the padded bf16 form internally.  gdr_t5_encoder_ragged_workspace_bytes serves both. */
+int gdr_t5_encoder_forward_ragged_bf16(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L,
+                                       float* out_hidden, float* out_pooled, int64_t live_rows_hint, void* workspace,
+                                       size_t workspace_bytes, void* stream);
+
 /* bf16 precision mode (BASELINE config C5): the SAME structs, but the four linear weights of every layer (wqkv, wo, wi,
  * wo_ff) point to bf16 [N,K] matrices (round-to-nearest-even of the fp32 checkpoint, e.g. gdr_cast_f32_bf16); the
  * `const float*` field type is nominal for them.  Each linear rounds its activation operand to bf16 and accumulates in

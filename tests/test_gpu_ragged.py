@@ -127,3 +127,21 @@ def test_generate_with_ragged_encoder_is_unchanged(dev):
     (d1, s1), e1 = GDRModel(cfg, sd, dev, ragged=True).generate(it, **kw)
     assert torch.equal(d0, d1) and s0 == s1
     assert torch.equal(e0.last_hidden_state[::R][:, 0], e1.last_hidden_state[::R][:, 0])
+
+
+@pytest.mark.parametrize("B,L", [(512, 40), (128, 40)])
+def test_ragged_bf16_mode_bit_identical_to_padded_bf16(dev, B, L):
+    """gdr_t5_encoder_forward_ragged_bf16: the packed form of the C5 precision mode — same rounding points, rows independent,
+    so pooled (both call forms) and every kept hidden row equal gdr_t5_encoder_forward_bf16 bit for bit."""
+    from gdr_amd import ops
+    cfg = GDRConfig.base()
+    sd = synth.make_state_dict(cfg, seed=1234, with_decoder=False)
+    enc = ops.T5EncoderHandle(cfg, sd, dev, dtype=torch.bfloat16)
+    ids, mask = synth.make_tokens(B, L=L, seed=11 + B)
+    it, mt = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    h0, p0 = enc.forward(it, mt)
+    h1, p1 = enc.forward(it, mt, ragged=True, live_rows_hint=int(mask.sum()))
+    _, p2 = enc.forward(it, mt, ragged=True, want_hidden=False)
+    keep = torch.from_numpy(_kept(mask)).to(dev)
+    assert torch.equal(p1, p0) and torch.equal(p2, p0)
+    assert torch.equal(h1[keep], h0[keep]) and int((h1[~keep] != 0).sum().item()) == 0
