@@ -236,8 +236,13 @@ def stages(dev, cfg, D, D_dev, a):
             retr = GDRRetriever(model, D_dev, look, args)
             batch = {"source_ids": ids, "source_mask": mask}
             t3 = timed(lambda: retr.validation_step_i(batch), reps=5, warm=2)
+            nb = 8                                       # a stream of batches, two in flight (GDRRetriever.validation_steps)
+            tp = timed(lambda: list(retr.validation_steps(iter([batch] * nb), depth=2)), reps=3, warm=1) / nb
             out["c3_two_stage"] = {"batch": B, "beams": R, "ms": t3 * 1e3, "queries_per_s": B / t3,
-                                   "note": "encoder -> beam decode -> id_mapping -> in-cluster rerank over 7 alphas"}
+                                   "pipelined_ms_per_batch": tp * 1e3, "pipelined_queries_per_s": B / tp,
+                                   "note": "encoder -> beam decode -> id_mapping -> in-cluster rerank over 7 alphas; "
+                                           "`ms` = one batch start to finish, `pipelined_*` = a stream of batches with two in "
+                                           "flight on separate HIP streams while the host post-processes the previous one"}
     out["generate"] = gen
     out["generate"]["mflop_per_row_step"] = {"decoder": mf_dec, "adaptor": mf_adp, "head": mf_head}
     del model, retr

@@ -72,6 +72,9 @@ _FLAGS = [
     ("trivia", int, 0),                      # infer.sh:15 passes it; only main_metrics.py reads it
     ("synthetic", int, 1), ("data_npz", str, ""), ("doc_embed_npy", str, ""), ("corpus_rows", int, 320000),
     ("n_queries", int, 512), ("res1_save_path", str, ""), ("device", str, "cuda:0"),
+    ("pipeline_depth", int, 2),              # eval batches in flight on the GPU (each on its own stream) while the host decodes
+                                             #    / formats the previous one; 1 = strictly one after another
+    ("prefix_table", int, 1),                # 1: build the device prefix table over the corpus' docid trie at load
     ("constrain_tree", int, 0),              # 1: apply the trie constraint of generation_utils_previous.py:714-729 (the
                                              #    shipped generate() ignores decode_tree even with --tree 1)
 ]
@@ -153,8 +156,10 @@ def inference(args):
     if args.constrain_tree and args.kary != args.output_vocab_size:
         raise SystemExit(f"--constrain_tree 1 needs --kary ({args.kary}) == --output_vocab_size "
                          f"({args.output_vocab_size}): the trie is indexed by the head's digit columns")
-    trie = codec.Trie.from_docids(data["index"].names, args.kary) if args.constrain_tree else None
-    model = GDRModel(cfg, sd, dev, trie=trie)
+    need_trie = args.constrain_tree or (args.prefix_table and args.kary == args.output_vocab_size)
+    trie = codec.Trie.from_docids(data["index"].names, args.kary) if need_trie else None
+    model = GDRModel(cfg, sd, dev, trie=trie if args.constrain_tree else None,
+                     prefix_trie=trie if args.prefix_table else None, ragged=True)
     R = args.num_return_sequences
     two_stage = bool(args.is_train_encoder) and data["doc_embed"] is not None
     retr = GDRRetriever(model, torch.from_numpy(np.ascontiguousarray(data["doc_embed"], dtype=np.float32)).to(dev),
@@ -162,28 +167,31 @@ def inference(args):
     n = data["source_ids"].shape[0] if args.n_test < 0 else min(args.n_test, data["source_ids"].shape[0])
     texts = data.get("texts") or ["q%d" % i for i in range(data["source_ids"].shape[0])]
     inf_result_cache, outputs = [], []
-    t_model = 0.0
-    for lo in range(0, n, args.eval_batch_size):
-        hi = min(n, lo + args.eval_batch_size)
-        ids = torch.from_numpy(data["source_ids"][lo:hi]).to(dev)
-        mask = torch.from_numpy(data["source_mask"][lo:hi]).to(dev)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if two_stage:
-            out = retr.validation_step_i({"source_ids": ids, "source_mask": mask, "texts": texts[lo:hi],
-                                          "gt": data["gt_cluster"][lo:hi], "oldid": data["gt_doc"][lo:hi]})
+    spans = [(lo, min(n, lo + args.eval_batch_size)) for lo in range(0, n, args.eval_batch_size)]
+
+    def batches():
+        for lo, hi in spans:
+            yield {"source_ids": torch.from_numpy(data["source_ids"][lo:hi]).to(dev),
+                   "source_mask": torch.from_numpy(data["source_mask"][lo:hi]).to(dev), "texts": texts[lo:hi],
+                   "gt": data["gt_cluster"][lo:hi], "oldid": data["gt_doc"][lo:hi]}
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if two_stage:
+        for out in retr.validation_steps(batches(), depth=max(1, args.pipeline_depth)):
             outputs.append(out)
             inf_result_cache.extend(out["inf_result_batch"])
-        else:
-            outs, _ = model.generate(ids, attention_mask=mask, use_cache=False, max_length=args.max_output_length,
-                                     num_beams=R, length_penalty=args.length_penalty, num_return_sequences=R,
-                                     early_stopping=False, decode_embedding=args.decode_embedding,
+    else:
+        for (lo, hi), b in zip(spans, batches()):
+            outs, _ = model.generate(b["source_ids"], attention_mask=b["source_mask"], use_cache=False,
+                                     max_length=args.max_output_length, num_beams=R, length_penalty=args.length_penalty,
+                                     num_return_sequences=R, early_stopping=False, decode_embedding=args.decode_embedding,
                                      decode_vocab_size=args.output_vocab_size * args.max_output_length + 2)
             dec = codec.dec_2d(codec.decode_token(args, outs.cpu().numpy()), R)
             for j, pred in enumerate(dec):                       # main.py:227-238
                 inf_result_cache.append([texts[lo + j], ",".join(pred), data["gt_cluster"][lo + j], 1])
-        torch.cuda.synchronize()
-        t_model += time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_model = time.perf_counter() - t0
     # main.py:243-247: sort by (query, rank), keep rank 1, write the TSV
     res1 = sorted((r for r in inf_result_cache if r[3] == 1), key=lambda r: (r[0], r[3]))
     os.makedirs(os.path.dirname(args.res1_save_path) or ".", exist_ok=True)

@@ -143,11 +143,8 @@ class GDRModel:
         assert 1 < max_length, "The context has 1 number of tokens, but `max_length` is only %d" % max_length
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
-        input_ids, attention_mask = input_ids.to(self.device), attention_mask.to(self.device)
-        enc_h, _ = self.enc.forward(input_ids, attention_mask, want_pooled=False, ragged=self.ragged)
-        ids, lens, scores = self.dec.generate(enc_h, attention_mask, num_beams, max_length, length_penalty,
-                                              num_return_sequences, trie=self.trie, prefix_table=self.prefix_table,
-                                              graph=self.graph)
+        enc_h, ids, lens, scores = self._generate_launch(input_ids, attention_mask, num_beams, max_length, length_penalty,
+                                                          num_return_sequences)
         decoded, score_list = ops.finish_generate_output(ids, lens, scores, max_length)
         output = (decoded, score_list) if output_scores else decoded
         if output_encoder_embedding:
@@ -156,6 +153,17 @@ class GDRModel:
             expanded = enc_h.repeat_interleave(num_beams, dim=0)
             return output, ModelOutput(last_hidden_state=expanded)
         return output, None
+
+    def _generate_launch(self, input_ids, attention_mask, num_beams, max_length, length_penalty, num_return_sequences):
+        """The device part of generate(): encoder + beam decode enqueued on the current stream, nothing read back.
+        Returns (encoder states [B,L,d], ids, lens, scores) — device tensors that ops.finish_generate_output turns into
+        what generate() returns."""
+        input_ids, attention_mask = input_ids.to(self.device), attention_mask.to(self.device)
+        enc_h, _ = self.enc.forward(input_ids, attention_mask, want_pooled=False, ragged=self.ragged)
+        ids, lens, scores = self.dec.generate(enc_h, attention_mask, num_beams, max_length, length_penalty,
+                                              num_return_sequences, trie=self.trie, prefix_table=self.prefix_table,
+                                              graph=self.graph)
+        return enc_h, ids, lens, scores
 
 
 class EncoderModel:
@@ -289,16 +297,56 @@ class GDRRetriever:
         Returns the reference's step output {"inf_result_batch", "inf_result_batch_prob", "inf_index_batch"}
         (main_models.py:1640-1641; rows are filled when "texts" is given) plus the raw pieces: "clusters" [B][R] decoded
         cluster strings, "doc_ids" [B][A][R] doc ids as strings, "rerank_values" fp32[B,A,R]."""
+        return self._step_finish(self._step_launch(batch), reencode=reencode)
+
+    @torch.no_grad()
+    def validation_steps(self, batches, depth=2, reencode=False):
+        """The same steps for a sequence of batches with up to `depth` of them in flight, each on a HIP stream of its own:
+        while the host decodes batch k's docids, looks up its candidates and formats its rows (the part of
+        validation_step_i that needs the beam output on the host, main_models.py:1398-1462), the GPU already runs batch
+        k+1's encoder and beam decode; per-stream scratch (ops.Workspace) keeps the calls apart.  Yields the step outputs
+        in order — identical to calling validation_step_i batch by batch."""
+        if depth <= 1:
+            for b in batches:
+                yield self.validation_step_i(b, reencode=reencode)
+            return
+        if not hasattr(self, "_streams") or len(self._streams) < depth:
+            self._streams = [torch.cuda.Stream(device=self.model.device) for _ in range(depth)]
+        cur = torch.cuda.current_stream(self.model.device)
+        pending, k = [], 0
+        for b in batches:
+            st = self._streams[k % depth]
+            st.wait_stream(cur)                              # inputs prepared on the caller's stream
+            with torch.cuda.stream(st):
+                pending.append((st, self._step_launch(b)))
+            k += 1
+            if len(pending) == depth:
+                st0, state = pending.pop(0)
+                with torch.cuda.stream(st0):
+                    out = self._step_finish(state, reencode=reencode)
+                yield out
+        for st0, state in pending:
+            with torch.cuda.stream(st0):
+                out = self._step_finish(state, reencode=reencode)
+            yield out
+
+    def _step_launch(self, batch):
         a = self.args
         R = a.num_return_sequences
-        decode_vocab_size = a.output_vocab_size * a.max_output_length + 2
-        (outs, scores), encoder_outs = self.model.generate(
-            batch["source_ids"], attention_mask=batch["source_mask"], use_cache=False,
-            max_length=a.max_output_length, num_beams=R, length_penalty=a.length_penalty, num_return_sequences=R,
-            early_stopping=False, decode_embedding=2, decode_vocab_size=decode_vocab_size, output_scores=True,
-            output_encoder_embedding=True)
+        mask = batch["source_mask"] if batch.get("source_mask") is not None else torch.ones_like(batch["source_ids"])
+        enc_h, ids, lens, scores = self.model._generate_launch(batch["source_ids"], mask, R, a.max_output_length,
+                                                               a.length_penalty, R)
+        for t in (enc_h, ids, lens, scores):                 # produced on this stream, possibly consumed after a switch
+            t.record_stream(torch.cuda.current_stream(t.device))
+        return {"batch": batch, "enc_h": enc_h, "ids": ids, "lens": lens, "scores": scores}
+
+    def _step_finish(self, state, reencode=False):
+        a = self.args
+        R = a.num_return_sequences
+        batch = state["batch"]
+        outs, scores = ops.finish_generate_output(state["ids"], state["lens"], state["scores"], a.max_output_length)
         dec = codec.dec_2d(codec.decode_token(a, outs.cpu().numpy()), R)
-        query_embeds = self.encoder(query_enc=encoder_outs.last_hidden_state[::R]).contiguous()
+        query_embeds = self.encoder(query_enc=state["enc_h"]).contiguous()      # CLS rows (main_models.py:1466)
         offs, ids, max_cand = self.index.candidates(dec)
         B = len(dec)
         beam_scores = torch.tensor(scores, dtype=torch.float32, device=query_embeds.device).view(B, R)

@@ -63,16 +63,19 @@ def linear_bf16(a, w, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None
 
 
 class Workspace:
-    """Grow-only device scratch buffer (256-byte aligned by the caching allocator)."""
+    """Grow-only device scratch (256-byte aligned by the caching allocator), one buffer per HIP stream: calls that are in
+    flight on different streams (GDRRetriever.validation_steps, two generate() calls) never share scratch."""
 
     def __init__(self, device):
         self.device = device
-        self.buf = None
+        self.bufs = {}
 
     def get(self, nbytes):
-        if self.buf is None or self.buf.numel() < nbytes:
-            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
-        return self.buf
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = self.bufs[key] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+        return buf
 
 
 def to_bf16(x):

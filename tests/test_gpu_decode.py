@@ -344,3 +344,38 @@ def test_generate_graph_replay_is_identical(dev):
         (d1, s1), _ = graphed.generate(it, **kw)
         assert torch.equal(d0, d1) and s0 == s1
     assert len(graphed.dec._graphs) == 1
+
+
+def test_validation_steps_pipelined_equals_step_by_step(dev):
+    """GDRRetriever.validation_steps keeps several batches in flight, each on its own HIP stream with its own scratch, while
+    the host post-processes the previous one: the step outputs must equal validation_step_i called batch by batch."""
+    from gdr_amd import codec
+    from gdr_amd.modeling import GDRModel, GDRRetriever
+    cfg = GDRConfig.tiny()
+    sd = synth.make_state_dict(cfg, seed=5)
+    V, R, csize = cfg.output_vocab_size, 4, 3
+    names = ["-".join(str(x) for x in synth.cluster_digits(c, 2, V)) for c in range(V * V)]
+    N = len(names) * csize
+    offsets = (np.arange(len(names) + 1) * csize).astype(np.int32)
+    members = np.random.Generator(np.random.PCG64(3)).permutation(N).astype(np.int32)
+    D = torch.from_numpy(synth.make_corpus(N, cfg.d_model, cluster_size=csize, seed=8)).to(dev)
+    args = types.SimpleNamespace(num_return_sequences=R, output_vocab_size=V, max_output_length=cfg.max_output_length,
+                                 length_penalty=0.8, kary=V, position=1, score_rate=[0, 1.0, 2.5], loss_func="tanh")
+    trie = codec.Trie.from_docids(names, V)
+    model = GDRModel(cfg, sd, dev, trie=trie, prefix_trie=trie)          # constrained: every decoded id names a cluster
+    retr = GDRRetriever(model, D, codec.ClusterIndex(names, offsets, members), args)
+    batches = []
+    for k in range(5):
+        ids, mask = synth.make_tokens(3 + (k % 2), L=10, vocab_hi=cfg.vocab_size, seed=20 + k, min_len=2)
+        batches.append({"source_ids": torch.from_numpy(ids).to(dev), "source_mask": torch.from_numpy(mask).to(dev),
+                        "texts": [f"q{k}-{j}" for j in range(ids.shape[0])]})
+    ref = [retr.validation_step_i(b) for b in batches]
+    for depth in (1, 2, 3):
+        got = list(retr.validation_steps(iter(batches), depth=depth))
+        assert len(got) == len(ref)
+        for a, b in zip(ref, got):
+            assert a["clusters"] == b["clusters"] and a["doc_ids"] == b["doc_ids"]
+            assert a["inf_result_batch"] == b["inf_result_batch"] and a["inf_index_batch"] == b["inf_index_batch"]
+            assert a["inf_result_batch_prob"] == b["inf_result_batch_prob"]
+            assert torch.equal(a["rerank_values"], b["rerank_values"])
+    assert any(any(x != "-1" for x in row[0]) for out in ref for row in out["doc_ids"])     # candidates were found
