@@ -228,21 +228,22 @@ def stages(dev, cfg, D, D_dev, a):
             "decode_floor_ms": floor * 1e3, "floor_bound": "mfma" if flops / (F32_MFMA_PEAK_TFLOPS * 1e12) >= wbytes / (HBM_PEAK_GBS * 1e9) else "hbm",
             "frac_of_floor": floor / (t - t_enc), "decode_tflops": flops / (t - t_enc) / 1e12,
             "decode_weight_stream_gbs": wbytes / (t - t_enc) / 1e9}
-        if (B, R) == (64, 10):
-            (dec, _), _ = g()
-            strs = sorted({s for s in codec.decode_token(args, dec.cpu().numpy())})
-            # random weights decode full-length rows that name no cluster: give every decoded string a real 12-doc cluster
-            look = codec.ClusterIndex(strs + names[len(strs):], offsets, members)
-            retr = GDRRetriever(model, D_dev, look, args)
-            batch = {"source_ids": ids, "source_mask": mask}
-            t3 = timed(lambda: retr.validation_step_i(batch), reps=5, warm=2)
-            nb = 8                                       # a stream of batches, two in flight (GDRRetriever.validation_steps)
-            tp = timed(lambda: list(retr.validation_steps(iter([batch] * nb), depth=2)), reps=3, warm=1) / nb
-            out["c3_two_stage"] = {"batch": B, "beams": R, "ms": t3 * 1e3, "queries_per_s": B / t3,
-                                   "pipelined_ms_per_batch": tp * 1e3, "pipelined_queries_per_s": B / tp,
-                                   "note": "encoder -> beam decode -> id_mapping -> in-cluster rerank over 7 alphas; "
-                                           "`ms` = one batch start to finish, `pipelined_*` = a stream of batches with two in "
-                                           "flight on separate HIP streams while the host post-processes the previous one"}
+        (dec, _), _ = g()
+        a_r = types.SimpleNamespace(**{**vars(args), "num_return_sequences": R})
+        strs = sorted({s for s in codec.decode_token(a_r, dec.cpu().numpy())})
+        # random weights decode full-length rows that name no cluster: give every decoded string a real 12-doc cluster
+        look = codec.ClusterIndex(strs + names[len(strs):], offsets, members)
+        retr = GDRRetriever(model, D_dev, look, a_r)
+        batch = {"source_ids": ids, "source_mask": mask}
+        t3 = timed(lambda: retr.validation_step_i(batch), reps=5, warm=2)
+        nb, depth = (8, 2) if B > 1 else (16, 4)         # a stream of batches, `depth` in flight (GDRRetriever.validation_steps)
+        tp = timed(lambda: list(retr.validation_steps(iter([batch] * nb), depth=depth)), reps=3, warm=1) / nb
+        out["c3_two_stage" if B > 1 else "c3_two_stage_infer_sh"] = {
+            "batch": B, "beams": R, "ms": t3 * 1e3, "queries_per_s": B / t3, "pipelined_depth": depth,
+            "pipelined_ms_per_batch": tp * 1e3, "pipelined_queries_per_s": B / tp,
+            "note": "encoder -> beam decode -> id_mapping -> in-cluster rerank over 7 alphas; `ms` = one batch start to finish, "
+                    "`pipelined_*` = a stream of batches with `pipelined_depth` in flight on separate HIP streams while the "
+                    "host post-processes the previous one"}
     out["generate"] = gen
     out["generate"]["mflop_per_row_step"] = {"decoder": mf_dec, "adaptor": mf_adp, "head": mf_head}
     del model, retr

@@ -452,7 +452,10 @@ class T5DecoderHandle:
             return ids, lens, scores
 
         if graph and not trace:
-            key = (B, L, R, max_length, nret, float(length_penalty), id(trie), id(prefix_table))
+            # one graph (and one set of static buffers) per call shape AND per stream: calls in flight on different
+            # streams (GDRRetriever.validation_steps) replay different instances
+            key = (B, L, R, max_length, nret, float(length_penalty), id(trie), id(prefix_table),
+                   torch.cuda.current_stream(dev_).cuda_stream)
             if not hasattr(self, "_graphs"):
                 self._graphs = {}
             entry = self._graphs.get(key)
