@@ -269,6 +269,56 @@ def test_trie_flattening_matches_reference_treebuilder_semantics():
         walk(nested, 0, 0)
 
 
+def test_trie_breadth_first_relabelling_keeps_the_language():
+    """codec.Trie.breadth_first (the node order of the device prefix table, gdr_hip.h GdrPrefixTable): same accepted docids,
+    every depth a contiguous id range, parent / token arrays consistent with the child table."""
+    from gdr_amd import codec, synth
+    V = 6
+    names, depth, _, _ = synth.make_cluster_ids(5000, cluster_size=12, V=V)      # 417 ids of depth 4
+    names = [n for i, n in enumerate(names) if i % 3]                              # holes
+    t = codec.Trie.from_docids(names, V)
+    b, level_off, parent, tok = t.breadth_first()
+    assert b.child.shape == t.child.shape and int(level_off[0]) == 0 and int(level_off[1]) == 1 and parent[0] == -1
+    assert int(level_off[-1]) == b.child.shape[0] and len(level_off) == depth + 2
+    for s in range(len(level_off) - 1):                                            # children of level s live in level s+1
+        kids = b.child[level_off[s]:level_off[s + 1]]
+        kids = kids[kids >= 0]
+        if s + 2 < len(level_off):
+            assert kids.min() >= level_off[s + 1] and kids.max() < level_off[s + 2]
+        else:
+            assert kids.size == 0
+    for node in range(1, b.child.shape[0]):
+        p = int(parent[node])
+        d = int(np.searchsorted(level_off, p, side="right") - 1)                   # depth of the parent
+        c = int(tok[node]) - (d * V + 2)
+        assert 0 <= c < V and b.child[p, c] == node
+
+    def accepts(trie, name):
+        n = 0
+        for d, c in enumerate(int(x) for x in name.split("-")):
+            n = trie.child[n, c]
+            if n < 0:
+                return False
+        return bool(trie.eos_ok[n])
+
+    probe = names[:40] + ["0-0-0-5", "5-5-5-5", "1-2"]
+    assert [accepts(t, n) for n in probe] == [accepts(b, n) for n in probe] and all(accepts(b, n) for n in names[:40])
+
+
+def test_main_calculate_mode_recomputes_the_metrics_of_a_tsv(tmp_path, capsys):
+    """`--mode calculate` (main.py:253-258, 495-496): recall / MRR100 of an existing res1 TSV, no GPU involved."""
+    from gdr_amd import main as gmain
+    g = golden("g7_metrics")
+    path = tmp_path / "res1.tsv"
+    with open(path, "w") as f:
+        for r in g["rows"]:
+            f.write("\t".join(str(x) for x in r) + "\n")
+    rec, mrr = gmain.main(["--mode", "calculate", "--res1_save_path", str(path), "--recall_num", "1", "5", "10", "20", "50", "100"])
+    assert rec == pytest.approx(float(g["recall_v"][-1])) and mrr == pytest.approx(float(g["mrr100"]))
+    out = capsys.readouterr().out
+    assert "recall@1:" in out and "MRR100:" in out
+
+
 def test_artifact_converters_on_synthetic_pickles(tmp_path):
     """tools/convert_artifacts.py on pickles shaped like the reference's (doc_embedding.pkl: list of [1,d] tensors;
     indexmap.pkl: dict cluster-string -> doc ids; Lightning ckpt with model./encoder.model. prefixes)."""
