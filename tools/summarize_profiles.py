@@ -22,8 +22,8 @@ src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/{tag}"
 
 
 def one(pattern):
-    m = sorted(glob.glob(os.path.join(src, pattern)))
-    return m[0] if m else None
+    m = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)   # the newest run (gpurun merges, never deletes)
+    return m[-1] if m else None
 
 
 def copy(pattern, dst):
