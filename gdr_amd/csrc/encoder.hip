@@ -135,7 +135,14 @@ static int t5_encoder_impl(const GdrT5EncoderWeights* w, const int64_t* ids, con
     GDR_CHECK_ARG(ly.ln_attn && ly.wqkv && ly.wo && ly.ln_ff && ly.wi && ly.wo_ff, "t5_encoder: layer %d null weight", i);
     if (fused16) {
       if ((rc = launch_rmsnorm_bf16(h, ly.ln_attn, abf, M, d, dm.eps, stream))) return rc;
-      if ((rc = lin16(abf, ly.wqkv, qkv, 3 * inner, 3 * inner, d, 0, nullptr, 0))) return rc;
+      // d_kv = 64 (the MFMA attention form): q, k, v leave the linear as bf16 and are widened inside the attention kernel
+      const bool qkv16 = dk == 64 && L <= 128;
+      if ((rc = lin16(abf, ly.wqkv, qkv, 3 * inner, 3 * inner, d, 0, nullptr, qkv16 ? 1 : 0))) return rc;
+      if (qkv16) {
+        const __bf16* q16 = reinterpret_cast<const __bf16*>(qkv);
+        at.q = reinterpret_cast<const float*>(q16), at.k = reinterpret_cast<const float*>(q16 + inner);
+        at.v = reinterpret_cast<const float*>(q16 + 2 * inner), at.qkv_bf16 = 1;
+      }
       at.out_bf16 = abf;  // ctx as bf16 [M, inner] (nx is dead)
       if ((rc = launch_attention(at, stream))) return rc;
       if ((rc = lin16(abf, ly.wo, h, d, d, inner, 0, h, 0))) return rc;
@@ -266,7 +273,12 @@ static int ragged_impl(const GdrT5EncoderWeights* w, const int64_t* ids, const i
     };
     if ((rc = launch_embed_packed(w->embed, ids, row_src, rows_dev, M, d, dm.vocab_size, h, stream))) return rc;
     AttnArgs at{};
-    at.q = qkv, at.k = qkv + inner, at.v = qkv + 2 * inner, at.out = nullptr, at.out_bf16 = abf;
+    {
+      const __bf16* q16 = reinterpret_cast<const __bf16*>(qkv);  // the packed form always runs the d_kv = 64 MFMA attention
+      at.q = reinterpret_cast<const float*>(q16), at.k = reinterpret_cast<const float*>(q16 + inner);
+      at.v = reinterpret_cast<const float*>(q16 + 2 * inner), at.qkv_bf16 = 1;
+    }
+    at.out = nullptr, at.out_bf16 = abf;
     at.ldq = at.ldk = at.ldv = 3 * inner, at.ldo = inner;
     at.q_bstride = at.k_bstride = at.o_bstride = L;
     at.B = B, at.H = H, at.dk = dk, at.Lq = L, at.Lk = L;
@@ -281,7 +293,7 @@ static int ragged_impl(const GdrT5EncoderWeights* w, const int64_t* ids, const i
       const GdrT5EncLayer& ly = w->layers[i];
       GDR_CHECK_ARG(ly.ln_attn && ly.wqkv && ly.wo && ly.ln_ff && ly.wi && ly.wo_ff, "t5_encoder_ragged: layer %d null weight", i);
       if ((rc = launch_rmsnorm_bf16_dev(h, ly.ln_attn, abf, rows_dev, M, d, dm.eps, stream))) return rc;
-      if ((rc = lin16(abf, ly.wqkv, qkv, 3 * inner, M, rows_dev, 3 * inner, d, 0, nullptr, 0))) return rc;
+      if ((rc = lin16(abf, ly.wqkv, qkv, 3 * inner, M, rows_dev, 3 * inner, d, 0, nullptr, 1))) return rc;  // q,k,v as bf16
       if ((rc = launch_attention(at, stream))) return rc;  // ctx -> abf as bf16 [rows, inner]
       if (pooled_only && i == dm.num_layers - 1) {
         // bf16 rows are inner/2 (d/2, d_ff/2) floats wide for the row mover

@@ -40,6 +40,8 @@ struct AttnArgs {
   // dk = 64 full self-attention form (attention_mfma16_kernel) reads these.
   const int32_t* seq_off;
   const int32_t* seq_len;
+  int qkv_bf16;                // q, k, v point to bf16 data (ldq / ldk / ldv in bf16 elements): the qkv linear of the bf16
+                               // precision mode emits them so; attention_mfma16_kernel only (d_kv = 64 self-attention)
   const int64_t* b_count_dev;  // Lq = 1 decode form only, may be null: only batch entries b < *b_count_dev are computed
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);

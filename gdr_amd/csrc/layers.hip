@@ -684,6 +684,34 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
     if (j < L) v = (a.key_mask && a.key_mask[(int64_t)b * a.mask_bstride + j] == 0) ? (a.causal_neg_inf ? -INFINITY : -1e9f) : 0.f;
     Mk[j] = v;
   }
+  if (a.qkv_bf16) {
+    // bf16 q / k / v (the qkv linear of the bf16 precision mode emits them so): 16-byte loads of 8 elements, widened to
+    // fp32 in the LDS image — the MFMAs below are unchanged (products of bf16 values are exact in fp32)
+    const __bf16* q16 = reinterpret_cast<const __bf16*>(a.q);
+    const __bf16* k16 = reinterpret_cast<const __bf16*>(a.k);
+    const __bf16* v16 = reinterpret_cast<const __bf16*>(a.v);
+    auto widen = [](uint4 u, float4& lo, float4& hi) {
+      lo = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+      hi = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                       __uint_as_float(u.w & 0xffff0000u));
+    };
+    for (int e = tid; e < L * (DK / 8); e += NTHR) {
+      const int r = e >> 3, c = e & 7;
+      float4 lo, hi;
+      widen(*reinterpret_cast<const uint4*>(q16 + (qrow0 + r) * a.ldq + h * DK + 8 * c), lo, hi);
+      lo.x *= a.scale, lo.y *= a.scale, lo.z *= a.scale, lo.w *= a.scale;
+      hi.x *= a.scale, hi.y *= a.scale, hi.z *= a.scale, hi.w *= a.scale;
+      *reinterpret_cast<float4*>(Qs + r * DS + 8 * c) = lo;
+      *reinterpret_cast<float4*>(Qs + r * DS + 8 * c + 4) = hi;
+      widen(*reinterpret_cast<const uint4*>(k16 + (krow0 + r) * a.ldk + h * DK + 8 * c), lo, hi);
+      *reinterpret_cast<float4*>(Ks + r * DS + 8 * c) = lo;
+      *reinterpret_cast<float4*>(Ks + r * DS + 8 * c + 4) = hi;
+      widen(*reinterpret_cast<const uint4*>(v16 + (krow0 + r) * a.ldv + h * DK + 8 * c), lo, hi);
+      *reinterpret_cast<float4*>(Vs + r * DS + 8 * c) = lo;
+      *reinterpret_cast<float4*>(Vs + r * DS + 8 * c + 4) = hi;
+    }
+  } else {
   for (int e = tid; e < L * (DK / 4); e += NTHR) {
     const int r = e >> 4, c = e & 15;
     float4 q = *reinterpret_cast<const float4*>(a.q + (qrow0 + r) * a.ldq + h * DK + 4 * c);
@@ -693,6 +721,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
     *reinterpret_cast<float4*>(Qs + r * DS + 4 * c) = q;
     *reinterpret_cast<float4*>(Ks + r * DS + 4 * c) = k;
     *reinterpret_cast<float4*>(Vs + r * DS + 4 * c) = v;
+  }
   }
   __syncthreads();
 
@@ -876,10 +905,12 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     GDR_CHECK_LAUNCH("attention_decode_kernel");
     return GDR_OK;
   }
-  const bool packed = a.seq_off != nullptr;
-  GDR_CHECK_ARG(!packed || (a.seq_len && a.Lq == a.Lk && a.q_pos0 == 0 && !a.kv_rows && a.kv_group == 1 && !a.q_same_pos &&
+  const bool packed = a.seq_off != nullptr || a.qkv_bf16;  // both exist in the 16x16x4 MFMA form only
+  GDR_CHECK_ARG(!a.seq_off || a.seq_len, "attention: seq_off without seq_len");
+  GDR_CHECK_ARG(!packed || (a.Lq == a.Lk && a.q_pos0 == 0 && !a.kv_rows && a.kv_group == 1 && !a.q_same_pos &&
                             a.dk == 64 && a.ldo % 4 == 0),
-                "attention: the packed (ragged) form serves full self-attention with d_kv = 64 only");
+                "attention: the packed (ragged) form and bf16 q/k/v serve full self-attention with d_kv = 64 only");
+  GDR_CHECK_ARG(!a.qkv_bf16 || (a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0), "attention: bf16 q/k/v need row strides %% 8 == 0");
   if (a.Lq == a.Lk && a.q_pos0 == 0 && !a.kv_rows && a.kv_group == 1 && !a.q_same_pos && a.dk == 64 && a.ldo % 4 == 0) {
     static const bool tiles16 = [] {
       const char* e = getenv("GDR_ATTN_MFMA16");  // A/B knob: 0 = 32x32x2 tiles

@@ -145,7 +145,8 @@ int gdr_t5_encoder_forward_ragged_bf16(const GdrT5EncoderWeights* w, const int64
 /* bf16 precision mode (BASELINE config C5): the SAME structs, but the four linear weights of every layer (wqkv, wo, wi,
  * wo_ff) point to bf16 [N,K] matrices (round-to-nearest-even of the fp32 checkpoint, e.g. gdr_cast_f32_bf16); the
  * `const float*` field type is nominal for them.  Each linear rounds its activation operand to bf16 and accumulates in
- * fp32; embedding, norms, attention (QK^T, softmax, PV), the residual stream and both outputs stay fp32.  The
+ * fp32; with d_kv = 64 (the MFMA attention form) the qkv linear also EMITS q, k, v as bf16 — QK^T and PV take those
+ * rounded operands, accumulate in fp32, softmax in fp32; embedding, norms, the residual stream and both outputs stay fp32.  The
  * reference has no such mode (it runs precision=32, main.py:61,91): parity is against the fp32 path within bf16
  * tolerance and against the oracle's bf16 emulation (oracle/t5_ref.py bf16_linears). */
 size_t gdr_t5_encoder_bf16_workspace_bytes(const GdrT5Dims* dims, int B, int L);

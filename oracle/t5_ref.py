@@ -70,11 +70,14 @@ def _lin(x, w):
     return x @ w.T
 
 
-def t5_attention(x, kv, sd, prefix, H, dk, position_bias):
-    """modeling_t5.py:316-421 without cache.  No 1/sqrt(d) scaling; fp32 softmax."""
+def t5_attention(x, kv, sd, prefix, H, dk, position_bias, round_qkv=False):
+    """modeling_t5.py:316-421 without cache.  No 1/sqrt(d) scaling; fp32 softmax.
+    round_qkv: the bf16 precision mode's encoder emits q, k, v as bf16 when d_kv = 64 (gdr_hip.h)."""
     bs = x.shape[0]
 
     def shape(t):
+        if round_qkv:
+            t = t.to(torch.bfloat16).to(torch.float32)
         return t.view(bs, -1, H, dk).transpose(1, 2)
 
     q = shape(_lin(x, sd[prefix + ".q.weight"]))
@@ -106,7 +109,8 @@ def encoder_forward(sd, cfg, input_ids, attention_mask, return_bias=False):
     for i in range(cfg.num_layers):
         p = f"encoder.block.{i}"
         nx = t5_layer_norm(h, sd[p + ".layer.0.layer_norm.weight"], eps)
-        h = h + t5_attention(nx, None, sd, p + ".layer.0.SelfAttention", H, dk, position_bias)
+        h = h + t5_attention(nx, None, sd, p + ".layer.0.SelfAttention", H, dk, position_bias,
+                             round_qkv=GEMM_BF16 and dk == 64 and L <= 128)
         nx = t5_layer_norm(h, sd[p + ".layer.1.layer_norm.weight"], eps)
         h = h + t5_ff(nx, sd, p + ".layer.1.DenseReluDense")
     h = t5_layer_norm(h, sd["encoder.final_layer_norm.weight"], eps)      # :803
