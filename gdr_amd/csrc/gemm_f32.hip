@@ -623,48 +623,49 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
 #undef P_MFMA16
 }
 
-// ---- stream-K form of the persistent kernel -----------------------------------------------------------------------
-// The persistent kernel above deals whole tiles: with T tiles on G = 512 resident workgroups a CU ends up with
-// ceil(T/256) tiles against T/256 on average — 582 tiles (ragged C2 batch, N = 768) cost three tile times where 2.27 would
-// do, and the whole encoder ran at 98 TFLOP/s instead of 129.  Here the unit of work is the K-STEP: the T*nk steps of a
-// launch are cut into G equal contiguous ranges, so a range covers the end of one tile (begun by the previous workgroup),
-// some whole tiles, and the beginning of another (finished by the next workgroup).  A tile that spans two workgroups is
-// NOT reduced from two partial sums (that would change the summation order): the first workgroup stores its raw
-// accumulators and raises a flag, the second one loads them and simply continues the k loop — the result is bit-identical
-// to the one-workgroup tile.  Every workgroup runs its BEGINNING fragment first (it depends on nobody), then its whole
-// tiles, and the CONTINUED fragment last, by which time the predecessor published long ago; the wait is a bounded spin.
-// Same flattened K-step stream, same K-step body and schedule as above.
-// Memory model: the XCDs' L2s are not coherent with each other inside a kernel.  The producer's accumulator stores are
-// followed by an agent-scope release fence (L2 write-back — cheap, because the begun fragment is the first thing a
-// workgroup does and its L2 holds nothing dirty yet) and the flag store; the consumer spins on the flag with relaxed
-// agent-scope loads, then an agent-scope acquire fence drops whatever stale lines of the buffer (from an earlier launch)
-// its own caches hold before it reads the accumulators.
+// ---- stream-K tail for the persistent kernel ----------------------------------------------------------------------
+// The persistent kernel above deals whole tiles: with T tiles on G = 512 resident workgroups it takes ceil(T/G) rounds
+// where T/G would do — 582 tiles (ragged C2 batch, N = 768) cost two rounds for 1.14 rounds of work.  This kernel runs all
+// rounds but the last full one exactly like the persistent kernel (workgroup b takes tiles b, b+G, ...: lockstep, operand
+// slices shared in time through the L2) and deals the remaining G + (T mod G) tiles by the K-STEP: their K-steps are cut
+// into G equal contiguous ranges (1..2 tiles' worth), so a range covers the end of one tile (begun by the previous
+// workgroup), possibly a whole tile, and the beginning of another (finished by the next workgroup).  A tile that spans two
+// workgroups is NOT reduced from two partial sums (that would change the summation order): the first workgroup stores its
+// raw accumulators and raises a flag, the second one loads them and simply continues the k loop — the result is
+// bit-identical to the one-workgroup tile.  In the tail a workgroup runs its BEGINNING fragment first (it depends on
+// nobody), then its whole tile, and the CONTINUED fragment last, by which time the predecessor published long ago (a range
+// is at least one tile long, so the predecessor's fragment is shorter than what precedes the take-over); the wait is a
+// bounded spin.  Same flattened K-step stream, same K-step body and schedule as above.
+// Memory model (MI355X_MICROARCH.md, visibility): the XCDs' L2s are not coherent with each other inside a kernel.  The
+// producer stores its accumulators write-through (sc1 buffer stores: no L2 write-back fence needed), every wave drains its
+// stores (s_waitcnt vmcnt(0)), the workgroup meets, one lane stores the flag (relaxed, agent scope).  The consumer's lane 0
+// polls the flag relaxed, issues ONE agent-scope acquire (drops this CU's stale L1 lines of the buffer, left by an earlier
+// launch), drains it, the workgroup meets, then plain loads.  (Round 2's first form — plain stores + __threadfence() by
+// every thread + a release flag store — cost 30 us more per launch on the o projection: 176 -> 139 us.)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct StreamKArgs {
   float* part;
   int32_t* flag;
   int32_t epoch;
 };
-// Stream-K pays for its balance with L2 locality: workgroups sit at different k of different tiles, so operand slices
-// are no longer shared in time the way the lockstep rounds of the whole-tile form share them (measured on the padded C2
-// batch: 31.0 ms against 28.2).  It is therefore used only where whole tiles quantise badly: with T tiles on 256 CUs x 2
-// workgroups the whole-tile form takes 2*floor(T/512) + {0, 1 (<= 256 left: they run alone on their CUs), 2} single-tile
-// times against T/256 ideally; stream-K runs when that loss exceeds GDR_GEMM_STREAMK percent (default 12; 0 = never,
-// 1 = always).  The tile count comes from the caller's row hint when the real count lives on the device — a tuning
-// input only: both kernels are correct for any row count.
+// When it runs: the whole-tile form takes ceil(T/G) rounds (measured: a last round with <= 256 tiles is no shorter), this
+// form T/G rounds plus the hand-off (one 64 KB write-through publish and one 64 KB take-over per workgroup, ~5 K-steps of
+// time at 2 workgroups per CU).  It is used when the whole-tile form's idle tail, (G - T mod G)/G of a round, exceeds
+// GDR_GEMM_STREAMK K-steps (default 6; 0 = never, 1 = always) — tools/run_sk.sh sweeps 8 batch sizes x 4 shapes
+// (profiles/r02_streamk_sweep.txt).  The tile count comes from the caller's row hint when the real count lives on the
+// device — a tuning input only: both kernels are correct for any row count.
 static bool streamk_fits(int64_t M, int64_t lda, int N, int64_t ldw) {  // 32-bit element offsets inside the kernel
   return M * lda < 0x7fffffffLL && (int64_t)N * ldw < 0x7fffffffLL;
 }
-static bool streamk_wanted(int64_t tiles) {
-  static const int pct = [] {
+static bool streamk_wanted(int64_t tiles, int nk) {
+  static const int thr = [] {
     const char* e = getenv("GDR_GEMM_STREAMK");
-    return e ? atoi(e) : 12;
+    return e ? atoi(e) : 6;
   }();
-  if (pct <= 0) return false;
-  if (pct == 1) return true;
-  if (tiles < 512) return false;
+  if (thr <= 0 || tiles < 512) return false;
+  if (thr == 1) return true;
   const int64_t rem = tiles % 512;
-  const double whole = 2.0 * (double)(tiles / 512) + (rem == 0 ? 0.0 : rem <= 256 ? 1.0 : 2.0);
-  return whole / ((double)tiles / 256.0) - 1.0 > 0.01 * pct;
+  return rem != 0 && (512 - rem) * nk > (int64_t)thr * 512;
 }
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(const GemmArgs g, const int total_tiles_host,
                                                                               const StreamKArgs sk) {
@@ -765,12 +766,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
   // ---- this workgroup's range of K-steps and its segments, in processing order:
   //      [begun fragment: tile t_last, k 0..k_last) -> stored]  [whole tiles t_full0 .. t_full0+n_full)]
   //      [continued fragment: tile t_first, k k_first..nk) <- loaded]
-  int t_first, k_first, t_last, k_last;
+  int t_first, k_first, t_last, k_last, dp_rounds = 0;
   if (total_tiles >= G) {
-    const int64_t iters = (int64_t)total_tiles * nk;
+    {  // all rounds but the last full one as whole tiles in lockstep, the rest (G..2G-1 tiles) by K-step ranges
+      const int rounds = total_tiles / G;
+      dp_rounds = total_tiles - rounds * G ? rounds - 1 : rounds;
+    }
+    const int sk_base = dp_rounds * G;
+    const int64_t iters = (int64_t)(total_tiles - sk_base) * nk;
     const int64_t lo = (int64_t)bid * iters / G, hi = (int64_t)(bid + 1) * iters / G;
     t_first = (int)(lo / nk), k_first = (int)(lo - (int64_t)t_first * nk);
     t_last = (int)(hi / nk), k_last = (int)(hi - (int64_t)t_last * nk);
+    t_first += sk_base, t_last += sk_base;
   } else {  // fewer tiles than workgroups (device-side row count): whole tiles, one each
     t_first = min((int)bid, total_tiles), k_first = 0;
     t_last = min((int)bid + 1, total_tiles), k_last = 0;
@@ -778,12 +785,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
   const bool has_head = k_first != 0, has_tail = k_last != 0;
   const int t_full0 = has_head ? t_first + 1 : t_first;
   const int n_full = t_last - t_full0;
-  const int nseg = (has_tail ? 1 : 0) + n_full + (has_head ? 1 : 0);
+  const int nseg = dp_rounds + (has_tail ? 1 : 0) + n_full + (has_head ? 1 : 0);
   // segment s -> tile, first K-step, end K-step
 #define SK_SEG(s_, tile_, k0_, k1_)                                   \
   {                                                                   \
-    int q_ = (s_);                                                    \
-    if (has_tail && q_ == 0) {                                        \
+    int q_ = (s_) - dp_rounds;                                        \
+    if (q_ < 0) {                                                     \
+      tile_ = (int)bid + (s_) * G, k0_ = 0, k1_ = nk;                 \
+    } else if (has_tail && q_ == 0) {                                 \
       tile_ = t_last, k0_ = 0, k1_ = k_last;                          \
     } else {                                                          \
       q_ -= has_tail ? 1 : 0;                                         \
@@ -804,9 +813,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
         __builtin_amdgcn_s_sleep(8);                                                                              \
         if (++spins_ > (1 << 24)) __builtin_trap(); /* seconds: the predecessor never ran — fail, do not hang */  \
       }                                                                                                           \
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* one lane: drops this CU's stale L1 lines of the buffer */ \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
     }                                                                                                             \
     __syncthreads();                                                                                              \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* drop stale lines of the hand-off buffer from this XCD's caches */ \
     const float4* src_ = reinterpret_cast<const float4*>(sk.part + (size_t)(bid - 1) * (BM * BN)) + tid;          \
     _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)             \
         _Pragma("unroll") for (int r4 = 0; r4 < 4; ++r4) {                                                        \
@@ -875,20 +885,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
     if (++kt == kend) {
      if (kend != nk) {
       // a BEGUN fragment (always this workgroup's first segment): hand the raw accumulators to the successor
-      float4* dst = reinterpret_cast<float4*>(sk.part + (size_t)bid * (BM * BN)) + tid;
+      // write-through (sc1) stores need no L2 write-back fence: every wave drains its own stores, the workgroup meets,
+      // one lane raises the flag (MI355X_MICROARCH.md, visibility: "publish-large", 3.0 us against 8.2 for plain + release)
+      const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(sk.part + (size_t)bid * (BM * BN), 0, BM * BN * 4, 0x00020000);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
-            dst[((mi * 2 + ni) * 4 + r4) * GEMM_THREADS] = make_float4(acc[mi][ni][4 * r4], acc[mi][ni][4 * r4 + 1],
-                                                                       acc[mi][ni][4 * r4 + 2], acc[mi][ni][4 * r4 + 3]);
+            u32x4 v_;
+            v_[0] = __float_as_uint(acc[mi][ni][4 * r4]), v_[1] = __float_as_uint(acc[mi][ni][4 * r4 + 1]);
+            v_[2] = __float_as_uint(acc[mi][ni][4 * r4 + 2]), v_[3] = __float_as_uint(acc[mi][ni][4 * r4 + 3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v_, dst, ((((mi * 2 + ni) * 4 + r4) * GEMM_THREADS) + tid) * 16, 0, 16);
             acc[mi][ni][4 * r4] = acc[mi][ni][4 * r4 + 1] = acc[mi][ni][4 * r4 + 2] = acc[mi][ni][4 * r4 + 3] = 0.f;
           }
-      __threadfence();  // release: the stores above are visible device-wide before the flag
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(sk.flag + bid, sk.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(sk.flag + bid, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
      } else {
       // epilogue of this tile: stores only (plus the residual / bias loads), no LDS — the other waves are already
       // in the next tile's first K-step.  Accumulator map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -1171,7 +1185,7 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
       // outputs only.  Time is unchanged either way (the kernel is MFMA-bound); this is traffic and energy.
       g.ksplit = gm_env > 0 ? gm_env : (g.tiles_n >= 12 ? 8 : 1);
     }
-    if (sk && streamk_wanted(tiles) && streamk_fits(M, lda, N, ldw)) {
+    if (sk && streamk_wanted(tiles, K / BK) && streamk_fits(M, lda, N, ldw)) {
       const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch};
       hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3((unsigned)SLOTS), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
       GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel");
@@ -1219,7 +1233,7 @@ int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t l
   if (tiles > 512) {
     g.ksplit = g.tiles_n >= 12 ? 8 : 1;  // supertile height, as in launch_linear_f32_ws
     const int64_t tiles_live = prof_rows >= 0 ? ((prof_rows + BM - 1) / BM) * g.tiles_n : tiles;
-    if (sk && streamk_wanted(tiles_live) && streamk_fits(M_max, lda, N, ldw)) {
+    if (sk && streamk_wanted(tiles_live, K / BK) && streamk_fits(M_max, lda, N, ldw)) {
       const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch};
       hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3(512), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
       GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel(dev rows)");
