@@ -273,6 +273,21 @@ def stages(dev, cfg, D, D_dev, a):
     t = timed(g16, reps=3, warm=1)
     out["bf16_mode_generate_B64_beam30"] = {"generate_ms": t * 1e3, "queries_per_s": 64 / t,
                                             "note": "C5's decode leg: 1920 beam rows, bf16 linear operands, fp32 accumulate"}
+    del model16
+    torch.cuda.empty_cache()
+    # ---- the passage side of the path: BERT/DPR doc tower, bert-base, 256 passages x 128 tokens, fp32
+    from gdr_amd.modeling import EncoderModel
+    bc = synth.bert_config(False)
+    tower = EncoderModel.from_state_dict(bc, synth.make_bert_state_dict(bc), dev)
+    pids, pmask = synth.make_tokens(256, L=128, vocab_hi=bc["vocab_size"], seed=3, min_len=32)
+    pids, pmask = torch.from_numpy(pids).to(dev), torch.from_numpy(pmask).to(dev)
+    t = timed(lambda: tower(passage={"input_ids": pids, "attention_mask": pmask}), reps=5, warm=2)
+    Lp, nl, dff, dm = 128, bc["num_layers"], bc["d_ff"], bc["hidden_size"]
+    gflop = 256 * (Lp * nl * 2 * (4 * dm * dm + 2 * dm * dff) + nl * 4 * Lp * Lp * dm) / 1e9
+    out["doc_tower_bert_base_L128"] = {"ms_per_256_passages": t * 1e3, "passages_per_s": 256 / t, "gflop": gflop,
+                                       "tflops": gflop / t / 1e3, "frac_of_f32_mfma_peak": gflop / t / 1e3 / F32_MFMA_PEAK_TFLOPS,
+                                       "corpus_320k_embed_s": 320000 / (256 / t),
+                                       "note": "padded form (every one of the 128 positions computed); CLS -> pooler"}
     return out
 
 

@@ -43,8 +43,10 @@ __global__ __launch_bounds__(256) void take_rows_kernel(const float* __restrict_
   for (int c = threadIdx.x & 63; c < d4; c += 64) o[c] = s[c];
 }
 
+constexpr size_t BERT_SCRATCH_BYTES = (size_t)112 << 20;  // split-K partial slabs of small batches / stream-K hand-off scratch
+static_assert(STREAMK_BYTES <= BERT_SCRATCH_BYTES, "stream-K scratch must fit the GEMM scratch region");
 struct BertWs {
-  size_t x, t, qkv, ctx, ff, total;
+  size_t x, t, qkv, ctx, ff, scratch, total;
 };
 static BertWs bert_ws(const GdrBertWeights& w, int64_t M) {
   BertWs b{};
@@ -55,6 +57,7 @@ static BertWs bert_ws(const GdrBertWeights& w, int64_t M) {
   b.qkv = o, o += align_up(M * 3 * d * 4, 256);
   b.ctx = o, o += align_up(M * d * 4, 256);
   b.ff = o, o += align_up(M * (size_t)w.d_ff * 4, 256);
+  b.scratch = o, o += BERT_SCRATCH_BYTES;
   b.total = o;
   return b;
 }
@@ -89,7 +92,14 @@ extern "C" int gdr_bert_encoder_forward(const GdrBertWeights* w, const int64_t* 
   float* qkv = reinterpret_cast<float*>(base + ws.qkv);
   float* ctx = reinterpret_cast<float*>(base + ws.ctx);
   float* ff = reinterpret_cast<float*>(base + ws.ff);
+  float* scr = reinterpret_cast<float*>(base + ws.scratch);
   int rc;
+  StreamK sk{};  // the linears' stream-K tail (gemm_f32.hip): scratch inside the GEMM scratch region, flags zeroed per call
+  sk.part = scr, sk.flag = reinterpret_cast<int32_t*>(base + ws.scratch + STREAMK_PART_BYTES), sk.epoch = 0;
+  if (hipMemsetAsync(sk.flag, 0, 512 * sizeof(int32_t), stream) != hipSuccess) {
+    set_error("bert: memset of the stream-K flags failed");
+    return GDR_EHIP;
+  }
   hipLaunchKernelGGL(bert_embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, w->word_emb, w->pos_emb,
                      w->type_emb, ids, token_type_ids, M, L, d / 4, w->vocab_size, w->type_vocab, t);
   GDR_CHECK_LAUNCH("bert_embed_kernel");
@@ -109,13 +119,17 @@ extern "C" int gdr_bert_encoder_forward(const GdrBertWeights* w, const int64_t* 
     GDR_CHECK_ARG(ly.wqkv && ly.bqkv && ly.wo && ly.bo && ly.ln1_w && ly.ln1_b && ly.wi && ly.bi && ly.wo2 && ly.bo2 &&
                       ly.ln2_w && ly.ln2_b,
                   "bert: layer %d null weight", i);
-    if ((rc = launch_linear_f32(x, d, ly.wqkv, d, qkv, 3 * d, M, 3 * d, d, GDR_EPI_BIAS, ly.bqkv, nullptr, 0, stream))) return rc;
+    if ((rc = launch_linear_f32_ws(x, d, ly.wqkv, d, qkv, 3 * d, M, 3 * d, d, GDR_EPI_BIAS, ly.bqkv, nullptr, 0, scr, BERT_SCRATCH_BYTES,
+                                   stream, &sk))) return rc;
     if ((rc = launch_attention(at, stream))) return rc;
-    if ((rc = launch_linear_f32(ctx, d, ly.wo, d, t, d, M, d, d, GDR_EPI_BIAS_RESIDUAL, ly.bo, x, d, stream))) return rc;
+    if ((rc = launch_linear_f32_ws(ctx, d, ly.wo, d, t, d, M, d, d, GDR_EPI_BIAS_RESIDUAL, ly.bo, x, d, scr, BERT_SCRATCH_BYTES, stream,
+                                   &sk))) return rc;
     if ((rc = launch_layernorm(t, ly.ln1_w, ly.ln1_b, x, M, d, w->eps, nullptr, stream))) return rc;
-    if ((rc = launch_linear_f32(x, d, ly.wi, d, ff, w->d_ff, M, w->d_ff, d, GDR_EPI_BIAS_GELU, ly.bi, nullptr, 0, stream)))
+    if ((rc = launch_linear_f32_ws(x, d, ly.wi, d, ff, w->d_ff, M, w->d_ff, d, GDR_EPI_BIAS_GELU, ly.bi, nullptr, 0, scr,
+                                   BERT_SCRATCH_BYTES, stream, &sk)))
       return rc;
-    if ((rc = launch_linear_f32(ff, w->d_ff, ly.wo2, w->d_ff, t, d, M, d, w->d_ff, GDR_EPI_BIAS_RESIDUAL, ly.bo2, x, d, stream)))
+    if ((rc = launch_linear_f32_ws(ff, w->d_ff, ly.wo2, w->d_ff, t, d, M, d, w->d_ff, GDR_EPI_BIAS_RESIDUAL, ly.bo2, x, d, scr,
+                                   BERT_SCRATCH_BYTES, stream, &sk)))
       return rc;
     float* dst = (i + 1 == w->num_layers && out_hidden) ? out_hidden : x;
     if ((rc = launch_layernorm(t, ly.ln2_w, ly.ln2_b, dst, M, d, w->eps, nullptr, stream))) return rc;
