@@ -107,9 +107,11 @@ with open(f"profiles/{tag}_bench_pmc_hbm.md", "w") as o:
                     "(read + write) — `roofline.traffic` of this mode.\n")
     o.write("\nAlgorithmic bytes of the linear GEMM, averaged over its four call shapes per layer (A + W + C (+ residual)): "
             "290 MB/launch padded (20 480 rows), 176 MB ragged (12 308 rows).  The excess is operand panels re-read through the "
-            "Infinity Cache when an XCD's 4 MiB L2 cannot hold the panels its tiles touch; the stream-K form re-reads more than "
-            "the whole-tile form (its workgroups sit at different k of different tiles, so operand slices are not shared in "
-            "time) — the reason it only runs where whole tiles quantise badly.\n")
+            "Infinity Cache when an XCD's 4 MiB L2 cannot hold the panels its tiles touch.  In the whole-tile rounds the 64 "
+            "workgroups of an XCD move through k in lockstep and share 16 panels (8 row x 8 column); in the stream-K tail (the "
+            "last 1-2 rounds' worth of tiles of a launch, DESIGN.md §4) they sit at different k of different tiles and every "
+            "tile fetches its two panels for itself — 8x the fetch per tile.  The tail made every launch faster (the kernel is "
+            "MFMA-bound: 26.9 k q/s against 25.3 k, padded 17.1 k against 16.6 k), so this is energy, not time.\n")
 traffic["source"] = f"profiles/{tag}_bench_pmc_hbm.md"
 json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
 
