@@ -1,14 +1,10 @@
+for pr in 0 1; do
+echo "== PRIO=$pr"; GDR_GEMM_STREAMK_PRIO=$pr python tools/exp_streamk.py 2>&1 | tail -3
+done
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for B in 256 320 416 512 608 704 832 1024; do
-for cfg in "0 0" "1 1"; do set -- $cfg
-export GDR_GEMM_STREAMK_DP=$1 GDR_GEMM_STREAMK=$2 EXP_B=$B
+for pr in 0 1; do
+export GDR_GEMM_STREAMK_PRIO=$pr EXP_B=512
 rm -rf /tmp/skt; rocprofv3 --kernel-trace --output-format csv -d /tmp/skt -- python3 $R/tools/exp_ragged_only.py 2>/dev/null | grep "live rows"
-echo "== B=$B DP=$1 TH=$2"; python3 $R/tools/sk_by_shape.py $(ls /tmp/skt/*/*kernel_trace.csv | head -1) 45
-done; done
-export EXP_PADDED=1 EXP_B=512
-for cfg in "0 0" "1 1"; do set -- $cfg
-export GDR_GEMM_STREAMK_DP=$1 GDR_GEMM_STREAMK=$2
-rm -rf /tmp/skt; rocprofv3 --kernel-trace --output-format csv -d /tmp/skt -- python3 $R/tools/exp_ragged_only.py 2>/dev/null | grep "live rows"
-echo "== PADDED B=512 DP=$1 TH=$2"; python3 $R/tools/sk_by_shape.py $(ls /tmp/skt/*/*kernel_trace.csv | head -1) 48
+echo "== B=512 PRIO=$pr"; python3 $R/tools/sk_by_shape.py $(ls /tmp/skt/*/*kernel_trace.csv | head -1) 45
 done
