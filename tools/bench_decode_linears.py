@@ -11,7 +11,7 @@ shapes = [("self/cross o, q_c (N=768,K=768)", 768, 768), ("qkv (N=2304,K=768)", 
           ("wo (N=768,K=3072)", 768, 3072), ("adaptor lin1 (N=2048,K=768)", 2048, 768), ("adaptor lin2 (N=768,K=2048)", 768, 2048),
           ("head (N=23808,K=768)", 23808, 768)]
 out = []
-for M in (100, 640, 1920):
+for M in [int(x) for x in os.environ.get("MS", "100,640,1920").split(",")]:
     for name, N, K in shapes:
         A = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) * 0.03
