@@ -81,7 +81,8 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
 // what launch_linear_f32_ws(M = M_max) gives that row.
 int launch_linear_f32_ws_dev(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M_max,
                              const int64_t* m_dev, int N, int K, int epilogue, const float* bias, const float* residual,
-                             int64_t ldr, float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream);
+                             int64_t ldr, float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream,
+                             StreamK* sk = nullptr);
 int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M_max,
                           const int64_t* m_dev, int N, int K, int epilogue, const float* bias, const float* residual,
                           int64_t ldr, int64_t prof_rows, hipStream_t stream, StreamK* sk = nullptr);

@@ -33,6 +33,7 @@ namespace gdr {
 constexpr int PAD_ID = 0, EOS_ID = 1, START_ID = 0;
 constexpr int MAXLEN_CAP = 32;
 constexpr size_t SPLITK_WS_BYTES = (size_t)48 << 20;  // <= 640 partial 128x128 tiles + slack
+static_assert(STREAMK_BYTES <= SPLITK_WS_BYTES, "stream-K scratch must fit the split-K region");
 
 struct BeamBufs {
   int32_t* seq[2];      // [rows][maxlen] token history, double buffered
@@ -753,10 +754,10 @@ struct SideLease {
 // (RNE) and the GEMM accumulates in fp32; bias / residual / output stay fp32.
 static int dec_linear(bool bf16, void* abf, const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
                       int64_t M, const int64_t* m_dev, int N, int K, int epi, const float* bias, const float* res, int64_t ldr,
-                      float* skw, hipStream_t st) {
+                      float* skw, hipStream_t st, StreamK* sk = nullptr) {
   if (!bf16)
-    return m_dev ? launch_linear_f32_ws_dev(A, lda, W, ldw, C, ldc, M, m_dev, N, K, epi, bias, res, ldr, skw, SPLITK_WS_BYTES, st)
-                 : launch_linear_f32_ws(A, lda, W, ldw, C, ldc, M, N, K, epi, bias, res, ldr, skw, SPLITK_WS_BYTES, st);
+    return m_dev ? launch_linear_f32_ws_dev(A, lda, W, ldw, C, ldc, M, m_dev, N, K, epi, bias, res, ldr, skw, SPLITK_WS_BYTES, st, sk)
+                 : launch_linear_f32_ws(A, lda, W, ldw, C, ldc, M, N, K, epi, bias, res, ldr, skw, SPLITK_WS_BYTES, st, sk);
   if (M == 0) return GDR_OK;
   GDR_CHECK_ARG(lda == K && K % 8 == 0, "decode(bf16): the activation operand must be dense with K %% 8 == 0");
   if (int rc = launch_cast_f32_bf16(A, abf, M * (int64_t)K, st)) return rc;
@@ -767,7 +768,7 @@ static int dec_linear(bool bf16, void* abf, const float* A, int64_t lda, const f
 // finished row (one launch instead of two or three); otherwise the linear and the norm kernels run one after another.
 static int dec_linear_norm(bool bf16, void* abf, const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
                            int64_t M, const int64_t* m_dev, int N, int K, int epi, const float* bias, const float* res,
-                           int64_t ldr, float* skw, hipStream_t st, const NormEpilogue& ne) {
+                           int64_t ldr, float* skw, hipStream_t st, const NormEpilogue& ne, StreamK* sk = nullptr) {
   if (M == 0) return GDR_OK;
   static const bool fuse_on = [] {
     const char* e = getenv("GDR_DECODE_FUSE_NORM");  // A/B knob: 0 = always separate launches
@@ -784,7 +785,7 @@ static int dec_linear_norm(bool bf16, void* abf, const float* A, int64_t lda, co
                                            m_dev, &ne);
     if (rc <= 0) return rc;
   }
-  if (int rc = dec_linear(bf16, abf, A, lda, W, ldw, C, ldc, M, m_dev, N, K, epi, bias, res, ldr, skw, st)) return rc;
+  if (int rc = dec_linear(bf16, abf, A, lda, W, ldw, C, ldc, M, m_dev, N, K, epi, bias, res, ldr, skw, st, sk)) return rc;
   if (ne.kind == 1)
     return m_dev ? launch_rmsnorm_dev(C, ne.w1, ne.Y, m_dev, M, N, ne.eps, st) : launch_rmsnorm(C, ne.w1, ne.Y, M, N, ne.eps, nullptr, 1, st);
   // LayerNorm(s): the second one reads the first one's output through Y
@@ -904,13 +905,13 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   const size_t ckv_layer = (size_t)B * L * 2 * inner;
 
 #define LIN(A_, lda_, W_, ldw_, C_, ldc_, M_, N_, K_, epi_, bias_, res_, ldr_) \
-  dec_linear(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream)
+  dec_linear(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream, &sk1)
 #define LIN2(A_, lda_, W_, ldw_, C_, ldc_, M_, N_, K_, epi_, bias_, res_, ldr_) \
-  dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw2, as)
+  dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw2, as, &sk2)
 #define LINN(A_, lda_, W_, ldw_, C_, ldc_, M_, N_, K_, epi_, bias_, res_, ldr_, ne_) \
-  dec_linear_norm(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream, ne_)
+  dec_linear_norm(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream, ne_, &sk1)
 #define LIN2N(A_, lda_, W_, ldw_, C_, ldc_, M_, md_, N_, K_, epi_, bias_, res_, ldr_, ne_) \
-  dec_linear_norm(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, M_, md_, N_, K_, epi_, bias_, res_, ldr_, skw2, as, ne_)
+  dec_linear_norm(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, M_, md_, N_, K_, epi_, bias_, res_, ldr_, skw2, as, ne_, &sk2)
   auto rms = [&](const float* wgt, float* y) { return NormEpilogue{1, wgt, nullptr, nullptr, nullptr, nullptr, dm.eps, y, (int64_t)dm.d_model}; };
   auto ln = [&](const float* w1, const float* b1, float* y) {
     return NormEpilogue{2, w1, b1, nullptr, nullptr, nullptr, w->adaptor_eps, y, (int64_t)dm.d_model};
@@ -924,6 +925,15 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   } while (0)
 
   GDR_TRY(beam_begin(bb, bd, stream));
+  // stream-K hand-off scratch of the two chains' big linears (gemm_f32.hip) inside their split-K regions — a launch uses one
+  // or the other; both flag blocks are zeroed here, on the caller's stream, before the adaptor stream is first forked
+  StreamK sk1{skw, reinterpret_cast<int32_t*>(base + g.splitk + STREAMK_PART_BYTES), 0};
+  StreamK sk2{skw2, reinterpret_cast<int32_t*>(base + g.splitk2 + STREAMK_PART_BYTES), 0};
+  if (hipMemsetAsync(sk1.flag, 0, 512 * sizeof(int32_t), stream) != hipSuccess ||
+      hipMemsetAsync(sk2.flag, 0, 512 * sizeof(int32_t), stream) != hipSuccess) {
+    set_error("generate: memset of the stream-K flags failed");
+    return GDR_EHIP;
+  }
   // cross-attention K/V once per query and layer (modeling_t5.py:365-368 recomputes them per beam row per step)
   for (int l = 0; l < dm.num_layers; ++l)
     GDR_TRY(LIN(enc_hidden, d, w->layers[l].wkv_c, d, crosskv + l * ckv_layer, 2 * inner, (int64_t)B * L,
@@ -984,7 +994,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       GDR_CHECK_LAUNCH("embed_rows_kernel");
     }
 #define LIN2D(A_, lda_, W_, ldw_, C_, ldc_, N_, K_, epi_, bias_, res_, ldr_) \
-  dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, rows, nm, N_, K_, epi_, bias_, res_, ldr_, skw2, as)
+  dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, rows, nm, N_, K_, epi_, bias_, res_, ldr_, skw2, as, &sk2)
     auto ad_layer_tab = [&](int l) -> int {
         const GdrAdaptorLayer& al = w->alayers[l];
         float* cache = acache + l * alayer;

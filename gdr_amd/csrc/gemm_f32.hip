@@ -1058,7 +1058,7 @@ int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, 
 // along K into partial slabs + a fixed-order reduction that applies the epilogue.
 int launch_linear_f32_ws_dev(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M_max,
                              const int64_t* m_dev, int N, int K, int epilogue, const float* bias, const float* residual,
-                             int64_t ldr, float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream) {
+                             int64_t ldr, float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream, StreamK* sk) {
   if (M_max == 0) return GDR_OK;
   GDR_CHECK_ARG(m_dev, "linear(dev rows): null row count");
   const int64_t tiles = ((M_max + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -1078,7 +1078,7 @@ int launch_linear_f32_ws_dev(const float* A, int64_t lda, const float* W, int64_
                                            splitk_ws_bytes, stream, m_dev);
     if (rc <= 0) return rc;
   }
-  return launch_linear_f32_dev(A, lda, W, ldw, C, ldc, M_max, m_dev, N, K, epilogue, bias, residual, ldr, -1, stream);
+  return launch_linear_f32_dev(A, lda, W, ldw, C, ldc, M_max, m_dev, N, K, epilogue, bias, residual, ldr, -1, stream, sk);
 }
 
 int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,

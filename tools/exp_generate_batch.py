@@ -1,4 +1,4 @@
-"""generate() throughput against the query batch size (beam 10): where does the decode chain stop being launch-bound?"""
+"""generate() throughput against the query batch size: where does the decode chain stop being launch-bound?"""
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from gdr_amd import codec, synth
@@ -9,8 +9,7 @@ dev = torch.device("cuda:0")
 cfg = GDRConfig.base()
 names = synth.make_cluster_ids(320000, cluster_size=12, V=30)[0]
 model = GDRModel(cfg, synth.make_state_dict(cfg, seed=1234), dev, ragged=True, prefix_trie=codec.Trie.from_docids(names, 30))
-for B in (64, 128, 256, 512):
-    R = 10
+for B, R in ((64, 10), (64, 30), (128, 10), (256, 10), (512, 10)):
     ids, mask = synth.make_tokens(B, L=40, seed=11)
     ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
     f = lambda: model.generate(ids, attention_mask=mask, max_length=10, num_beams=R, length_penalty=0.8, num_return_sequences=R, output_scores=True)
@@ -19,4 +18,4 @@ for B in (64, 128, 256, 512):
     for _ in range(4): f()
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / 4
-    print(f"B={B} beams={R}: {t*1e3:.2f} ms  {B/t:.0f} q/s")
+    print(f"MID={os.environ.get('GDR_GEMM_STREAMK_MID','512')} SK={os.environ.get('GDR_GEMM_STREAMK','6')} B={B} beams={R}: {t*1e3:.2f} ms  {B/t:.0f} q/s")
