@@ -210,7 +210,7 @@ def stages(dev, cfg, D, D_dev, a):
     args = types.SimpleNamespace(num_return_sequences=10, output_vocab_size=30, max_output_length=10, length_penalty=0.8,
                                  kary=30, position=1, score_rate=[0, 0.5, 1, 1.5, 2, 2.5, 3], loss_func="tanh")
     gen = {}
-    for B, R in ((64, 10), (1, 100)):
+    for B, R in ((64, 10), (1, 100), (512, 10)):       # C3 at infer.sh's eval batch, one query x 100 beams, C2's batch
         ids, mask = synth.make_tokens(B, L=40, seed=11)
         ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
         steps = 9
@@ -232,13 +232,14 @@ def stages(dev, cfg, D, D_dev, a):
         a_r = types.SimpleNamespace(**{**vars(args), "num_return_sequences": R})
         strs = sorted({s for s in codec.decode_token(a_r, dec.cpu().numpy())})
         # random weights decode full-length rows that name no cluster: give every decoded string a real 12-doc cluster
+        strs = strs[:len(names)]                   # a small --corpus has fewer clusters than a big batch decodes strings
         look = codec.ClusterIndex(strs + names[len(strs):], offsets, members)
         retr = GDRRetriever(model, D_dev, look, a_r)
         batch = {"source_ids": ids, "source_mask": mask}
         t3 = timed(lambda: retr.validation_step_i(batch), reps=5, warm=2)
-        nb, depth = (8, 2) if B > 1 else (16, 4)         # a stream of batches, `depth` in flight (GDRRetriever.validation_steps)
+        nb, depth = (16, 4) if B == 1 else (8, 2) if B <= 64 else (4, 2)   # a stream of batches, `depth` in flight (GDRRetriever.validation_steps)
         tp = timed(lambda: list(retr.validation_steps(iter([batch] * nb), depth=depth)), reps=3, warm=1) / nb
-        out["c3_two_stage" if B > 1 else "c3_two_stage_infer_sh"] = {
+        out["c3_two_stage_infer_sh" if B == 1 else "c3_two_stage" if B == 64 else f"c3_two_stage_B{B}"] = {
             "batch": B, "beams": R, "ms": t3 * 1e3, "queries_per_s": B / t3, "pipelined_depth": depth,
             "pipelined_ms_per_batch": tp * 1e3, "pipelined_queries_per_s": B / tp,
             "note": "encoder -> beam decode -> id_mapping -> in-cluster rerank over 7 alphas; `ms` = one batch start to finish, "

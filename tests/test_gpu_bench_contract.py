@@ -47,6 +47,8 @@ def test_bench_line_contract_fp32():
         assert g["generate_ms"] > g["encoder_ms"] > 0 and 0 < g["frac_of_floor"] < 1
     assert st["c3_two_stage"]["queries_per_s"] > 0 and st["bf16_mode_c2_step"]["queries_per_s"] > 0
     assert st["prefix_table"]["nodes"] > 1
+    assert st["c3_two_stage_B512"]["queries_per_s"] > st["c3_two_stage"]["queries_per_s"] > 0
+    assert 0 < st["doc_tower_bert_base_L128"]["frac_of_f32_mfma_peak"] < 1
 
 
 def test_bench_padded_encoder_form_gives_the_same_recall():
