@@ -373,9 +373,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   const int Lk = a.Lk, Lkp = (Lk + 3) & ~3;
   float* Ks = smem;
   float* Vs = Ks + Lk * dks;
-  float* Qs = Vs + Lk * dks;   // [4][dk]
-  float* Ps = Qs + 4 * dk;     // [4][Lkp]
-  float* Bs = Ps + 4 * Lkp;    // [num_buckets]
+  // query rows are dealt to gridDim.y workgroups per (batch, head): with few (batch, head) pairs and many rows (one
+  // query decoded with 100 beams) a single workgroup per pair left the chip idle
+  const int rows_per = (a.Lq + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int i0 = (int)blockIdx.y * rows_per, i1 = min(a.Lq, i0 + rows_per);
+  const int iters = i1 > i0 ? (i1 - i0 + 3) >> 2 : 0;
+  // up to 32 query rows per workgroup are staged together with K / V (one global round trip for the whole workgroup);
+  // beyond that a wave loads its row when it gets to it
+  const bool pre = rows_per <= 32;
+  const int qrows = pre ? ((rows_per + 3) & ~3) : 4;
+  float* Qs = Vs + Lk * dks;      // [qrows][dk]
+  float* Ps = Qs + qrows * dk;    // [4][Lkp]
+  float* Bs = Ps + 4 * Lkp;       // [num_buckets]
   const int tid = threadIdx.x;
   const int kb = b / a.kv_group;
   for (int e = tid; e < Lk * c4; e += 256) {
@@ -386,25 +395,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     *reinterpret_cast<float4*>(Vs + j * dks + 4 * c) =
         *reinterpret_cast<const float4*>(a.v + rk * a.ldv + h * dk + 4 * c);
   }
+  if (pre) {
+    for (int e = tid; e < (i1 - i0) * c4; e += 256) {
+      const int r = e / c4, c = e - r * c4;
+      float4 q = *reinterpret_cast<const float4*>(a.q + ((int64_t)b * a.q_bstride + i0 + r) * a.ldq + h * dk + 4 * c);
+      q.x *= a.scale, q.y *= a.scale, q.z *= a.scale, q.w *= a.scale;
+      *reinterpret_cast<float4*>(Qs + r * dk + 4 * c) = q;
+    }
+  }
   if (a.rel_bias && tid < a.num_buckets) Bs[tid] = a.rel_bias[tid * a.H + h];
   const int wave = tid >> 6, lane = tid & 63;
-  float* qs = Qs + wave * dk;
   float* ps = Ps + wave * Lkp;
+  __syncthreads();  // K / V, the bias table and the staged query rows are visible; from here on a wave only touches its own
+                    // strips (q row, probabilities), whose LDS operations complete in order: no workgroup barrier below
   const int half = a.num_buckets >> 1;
   const float masked = a.causal_neg_inf ? -INFINITY : -1e9f;
-  // query rows are dealt to gridDim.y workgroups per (batch, head): with few (batch, head) pairs and many rows (one
-  // query decoded with 100 beams) a single workgroup per pair left the chip idle
-  const int rows_per = (a.Lq + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int i0 = (int)blockIdx.y * rows_per, i1 = min(a.Lq, i0 + rows_per);
-  const int iters = i1 > i0 ? (i1 - i0 + 3) >> 2 : 0;
   for (int it = 0; it < iters; ++it) {
     const int i = i0 + it * 4 + wave;
     const bool active = i < i1;
-    if (active) {
+    float* qs = Qs + (pre ? it * 4 + wave : wave) * dk;
+    if (active && !pre) {
       const float* qr = a.q + ((int64_t)b * a.q_bstride + i) * a.ldq + h * dk;
       for (int d = lane; d < dk; d += 64) qs[d] = qr[d] * a.scale;
     }
-    __syncthreads();  // K/V staged (first pass) and this wave's q row visible
+    __builtin_amdgcn_wave_barrier();
     float sc[2];
     float mx = -INFINITY;
     if (active) {
@@ -462,7 +476,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
       sum = wave_sum(sum);
       sc[0] = sum;
     }
-    __syncthreads();  // probabilities visible to the whole wave
+    __builtin_amdgcn_wave_barrier();  // probabilities written before any lane reads them back
     if (active) {
       const float inv = 1.0f / sc[0];
       float* orow = a.out + ((int64_t)b * a.o_bstride + i) * a.ldo + h * dk;
@@ -483,7 +497,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
           orow[d] = o;
       }
     }
-    __syncthreads();  // before the next row overwrites qs / ps
+    __builtin_amdgcn_wave_barrier();  // before the next row overwrites qs / ps
   }
 }
 
@@ -891,6 +905,100 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const AttnArgs a)
   }
 }
 
+// The same Lq = 1 attention with COALESCED K / V reads.  In the kernel above a lane owns a key and walks its K row with
+// 16-byte loads: one wave instruction touches 64 different rows (64 cache lines for 1 KB of payload), and the texture
+// path, not the arithmetic, sets the pace (138 us per call at 5 120 rows x 12 heads).  Here LPR consecutive lanes read one
+// row together (a 256-byte row = 16 lanes x 16 B), so an instruction covers 64/LPR rows in full cache lines; the 4-element
+// partial dot products are summed over the LPR lanes of a row group by a butterfly, scores / probabilities pass through
+// a per-wave LDS strip, and P·V accumulates a float4 per lane that is finally summed over the row groups.
+template <int LPR>  // lanes per K / V row: 16 (dk <= 64) or 32 (dk <= 128)
+__global__ __launch_bounds__(256) void attention_decode_rows_kernel(const AttnArgs a) {
+  constexpr int RPI = 64 / LPR;  // rows per wave instruction
+  __shared__ float strip[4][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= a.B * a.H) return;
+  const int b = item / a.H, h = item % a.H;
+  if (a.b_count_dev && b >= (int)*a.b_count_dev) return;  // only the first *b_count_dev batch entries are live
+  const int dk = a.dk, c4 = dk >> 2, Lk = a.Lk, kb = b / a.kv_group;
+  const int g = lane / LPR, c = lane % LPR;
+  const bool col_ok = c < c4;
+  const int i_abs = a.q_pos0;
+  const int half = a.num_buckets >> 1;
+  const float masked = a.causal_neg_inf ? -INFINITY : -1e9f;
+  float* S = strip[wave];
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col_ok) {
+    q = *reinterpret_cast<const float4*>(a.q + (int64_t)b * a.q_bstride * a.ldq + h * dk + 4 * c);
+    q.x *= a.scale, q.y *= a.scale, q.z *= a.scale, q.w *= a.scale;
+  }
+  auto row_of = [&](int j) -> int64_t {
+    return a.kv_rows ? (int64_t)a.kv_rows[(int64_t)b * Lk + j] : (int64_t)kb * a.k_bstride + j;
+  };
+  // ---- scores: key j = j0 + g, its row read by the LPR lanes of group g
+  float mx = -INFINITY;
+  for (int j0 = 0; j0 < Lk; j0 += RPI) {
+    const int j = j0 + g;
+    float part = 0.f;
+    if (j < Lk && col_ok) {
+      const float4 kk = *reinterpret_cast<const float4*>(a.k + row_of(j) * a.ldk + h * dk + 4 * c);
+      part = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
+    }
+#pragma unroll
+    for (int off = LPR >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (j < Lk) {
+      float add = 0.f;
+      if (a.rel_bias) {
+        int n = i_abs - j, bucket = 0;
+        if (a.bidirectional) {
+          if (n < 0) {
+            bucket = half;
+            n = -n;
+          }
+        } else if (n < 0) {
+          n = 0;
+        }
+        bucket += a.lut.v[n < 127 ? n : 127];
+        add = a.rel_bias[bucket * a.H + h];
+      }
+      bool allowed = true;
+      if (a.causal) allowed = j <= i_abs;
+      if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)kb * a.mask_bstride + j] != 0);
+      if (!allowed) add += masked;
+      const float sj = part + add;
+      if (c == 0) S[j] = sj;
+      mx = fmaxf(mx, sj);
+    }
+  }
+  mx = wave_max(mx);
+  __builtin_amdgcn_wave_barrier();  // the strip is private to this wave: LDS operations of one wave complete in order
+  // ---- softmax over the strip (lane <-> key), probabilities back into the strip
+  float p0 = 0.f, p1 = 0.f;
+  if (lane < Lk) p0 = expf(S[lane] - mx);
+  if (lane + 64 < Lk) p1 = expf(S[lane + 64] - mx);
+  const float inv = 1.0f / wave_sum(p0 + p1);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < Lk) S[lane] = p0 * inv;
+  if (lane + 64 < Lk) S[lane + 64] = p1 * inv;
+  __builtin_amdgcn_wave_barrier();
+  // ---- O = P·V: group g takes keys j0 + g, lane (g, c) accumulates columns 4c..4c+3; then the groups are summed
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int j0 = 0; j0 < Lk; j0 += RPI) {
+    const int j = j0 + g;
+    if (j < Lk && col_ok) {
+      const float4 vv = *reinterpret_cast<const float4*>(a.v + row_of(j) * a.ldv + h * dk + 4 * c);
+      const float pj = S[j];
+      o.x = fmaf(pj, vv.x, o.x), o.y = fmaf(pj, vv.y, o.y), o.z = fmaf(pj, vv.z, o.z), o.w = fmaf(pj, vv.w, o.w);
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    o.x += __shfl_xor(o.x, off), o.y += __shfl_xor(o.y, off), o.z += __shfl_xor(o.z, off), o.w += __shfl_xor(o.w, off);
+  }
+  if (g == 0 && col_ok) *reinterpret_cast<float4*>(a.out + (int64_t)b * a.o_bstride * a.ldo + h * dk + 4 * c) = o;
+}
+
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
   GDR_CHECK_ARG(a.dk % 4 == 0 && a.dk >= 4 && a.dk <= 256, "attention: dk=%d unsupported", a.dk);
   GDR_CHECK_ARG(a.Lk >= 1 && a.Lk <= 128, "attention: Lk=%d must be in [1,128]", a.Lk);
@@ -901,7 +1009,20 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   ProfScope prof(PROF_ATTENTION, 4.0 * a.B * a.H * (double)a.Lq * a.Lk * a.dk, stream);
   GDR_CHECK_ARG(!a.out_bf16 || a.Lq > 1, "attention: bf16 output is not available in the Lq = 1 decode form");
   if (a.Lq == 1) {
-    hipLaunchKernelGGL(attention_decode_kernel, dim3((unsigned)((a.B * a.H + 3) / 4)), dim3(256), 0, stream, a);
+    static const bool rows_form = [] {
+      const char* e = getenv("GDR_ATTN_DECODE_ROWS");  // A/B knob: 0 = the lane-per-key kernel
+      return e ? atoi(e) != 0 : true;
+    }();
+    const dim3 grid((unsigned)((a.B * a.H + 3) / 4));
+    if (rows_form && a.dk <= 128 && a.ldo % 4 == 0) {
+      if (a.dk <= 64)
+        hipLaunchKernelGGL(attention_decode_rows_kernel<16>, grid, dim3(256), 0, stream, a);
+      else
+        hipLaunchKernelGGL(attention_decode_rows_kernel<32>, grid, dim3(256), 0, stream, a);
+      GDR_CHECK_LAUNCH("attention_decode_rows_kernel");
+      return GDR_OK;
+    }
+    hipLaunchKernelGGL(attention_decode_kernel, grid, dim3(256), 0, stream, a);
     GDR_CHECK_LAUNCH("attention_decode_kernel");
     return GDR_OK;
   }
@@ -936,12 +1057,14 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     }
   }
   const int dks = a.dk + 4, Lkp = (a.Lk + 3) & ~3;
-  const size_t lds = sizeof(float) * ((size_t)2 * a.Lk * dks + 4 * a.dk + 4 * Lkp + 256);
-  GDR_CHECK_ARG(lds <= 160 * 1024, "attention: Lk=%d dk=%d needs %zu B of LDS", a.Lk, a.dk, lds);
-  if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(attention_kernel), 160 * 1024, "attention")) return rc__;
   int chunks = (512 + a.B * a.H - 1) / (a.B * a.H);  // aim at ~2 workgroups per CU, at least 4 rows (one per wave) each
   const int max_chunks = (a.Lq + 3) / 4;
   chunks = chunks < 1 ? 1 : (chunks > max_chunks ? max_chunks : chunks);
+  const int rows_per = (a.Lq + chunks - 1) / chunks;
+  const int qrows = rows_per <= 32 ? ((rows_per + 3) & ~3) : 4;  // as the kernel lays its query strip out
+  const size_t lds = sizeof(float) * ((size_t)2 * a.Lk * dks + (size_t)qrows * a.dk + 4 * Lkp + 256);
+  GDR_CHECK_ARG(lds <= 160 * 1024, "attention: Lk=%d dk=%d needs %zu B of LDS", a.Lk, a.dk, lds);
+  if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(attention_kernel), 160 * 1024, "attention")) return rc__;
   hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(a.B * a.H), (unsigned)chunks), dim3(256), lds, stream, a);
   GDR_CHECK_LAUNCH("attention_kernel");
   return GDR_OK;
