@@ -666,8 +666,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int DK = 64, DS = DK + 4, LP = 16 * NT, NTHR = 64 * NT;
   const int Lr = a.Lk;
-  float* Qs = smem;
-  float* Ks = Qs + Lr * DS;
+  float* Ks = smem;  // q never passes through LDS: a wave reads the fragments of its own 16 query rows straight from global
   float* Vs = Ks + Lr * DS;
   float* RelB = Vs + Lr * DS;   // [2*LP]
   float* Mk = RelB + 2 * LP;    // [LP]
@@ -676,6 +675,32 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
   const int64_t qrow0 = a.seq_off ? a.seq_off[b] : (int64_t)b * a.q_bstride;
   const int64_t krow0 = a.seq_off ? a.seq_off[b] : (int64_t)b * a.k_bstride;
   const int64_t orow0 = a.seq_off ? a.seq_off[b] : (int64_t)b * a.o_bstride;
+  // this wave's query fragments (B operand of S^T = K·Q^T): lane (c16, q4) holds Q[16w + c16][16jj + 4q4 .. +3], issued
+  // first so that the loads are in flight while K / V are staged
+  float4 qv[DK / 16];
+  {
+    const int wq = tid >> 6, lq = tid & 63;
+    const int64_t qr = qrow0 + min(16 * wq + (lq & 15), L - 1);
+    if (16 * wq < L) {
+      if (a.qkv_bf16) {
+        const __bf16* q16 = reinterpret_cast<const __bf16*>(a.q) + qr * a.ldq + h * DK + 4 * (lq >> 4);
+#pragma unroll
+        for (int jj = 0; jj < DK / 16; ++jj) {
+          const uint2 u = *reinterpret_cast<const uint2*>(q16 + 16 * jj);
+          qv[jj] = make_float4(__uint_as_float(u.x << 16) * a.scale, __uint_as_float(u.x & 0xffff0000u) * a.scale,
+                               __uint_as_float(u.y << 16) * a.scale, __uint_as_float(u.y & 0xffff0000u) * a.scale);
+        }
+      } else {
+        const float* q32 = a.q + qr * a.ldq + h * DK + 4 * (lq >> 4);
+#pragma unroll
+        for (int jj = 0; jj < DK / 16; ++jj) {
+          float4 t = *reinterpret_cast<const float4*>(q32 + 16 * jj);
+          t.x *= a.scale, t.y *= a.scale, t.z *= a.scale, t.w *= a.scale;
+          qv[jj] = t;
+        }
+      }
+    }
+  }
   for (int e = tid; e < 2 * LP; e += NTHR) {
     float v = 0.f;
     if (a.rel_bias) {
@@ -701,7 +726,6 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
   if (a.qkv_bf16) {
     // bf16 q / k / v (the qkv linear of the bf16 precision mode emits them so): 16-byte loads of 8 elements, widened to
     // fp32 in the LDS image — the MFMAs below are unchanged (products of bf16 values are exact in fp32)
-    const __bf16* q16 = reinterpret_cast<const __bf16*>(a.q);
     const __bf16* k16 = reinterpret_cast<const __bf16*>(a.k);
     const __bf16* v16 = reinterpret_cast<const __bf16*>(a.v);
     auto widen = [](uint4 u, float4& lo, float4& hi) {
@@ -713,11 +737,6 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
     for (int e = tid; e < L * (DK / 8); e += NTHR) {
       const int r = e >> 3, c = e & 7;
       float4 lo, hi;
-      widen(*reinterpret_cast<const uint4*>(q16 + (qrow0 + r) * a.ldq + h * DK + 8 * c), lo, hi);
-      lo.x *= a.scale, lo.y *= a.scale, lo.z *= a.scale, lo.w *= a.scale;
-      hi.x *= a.scale, hi.y *= a.scale, hi.z *= a.scale, hi.w *= a.scale;
-      *reinterpret_cast<float4*>(Qs + r * DS + 8 * c) = lo;
-      *reinterpret_cast<float4*>(Qs + r * DS + 8 * c + 4) = hi;
       widen(*reinterpret_cast<const uint4*>(k16 + (krow0 + r) * a.ldk + h * DK + 8 * c), lo, hi);
       *reinterpret_cast<float4*>(Ks + r * DS + 8 * c) = lo;
       *reinterpret_cast<float4*>(Ks + r * DS + 8 * c + 4) = hi;
@@ -728,11 +747,8 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
   } else {
   for (int e = tid; e < L * (DK / 4); e += NTHR) {
     const int r = e >> 4, c = e & 15;
-    float4 q = *reinterpret_cast<const float4*>(a.q + (qrow0 + r) * a.ldq + h * DK + 4 * c);
     const float4 k = *reinterpret_cast<const float4*>(a.k + (krow0 + r) * a.ldk + h * DK + 4 * c);
     const float4 v = *reinterpret_cast<const float4*>(a.v + (krow0 + r) * a.ldv + h * DK + 4 * c);
-    q.x *= a.scale, q.y *= a.scale, q.z *= a.scale, q.w *= a.scale;
-    *reinterpret_cast<float4*>(Qs + r * DS + 4 * c) = q;
     *reinterpret_cast<float4*>(Ks + r * DS + 4 * c) = k;
     *reinterpret_cast<float4*>(Vs + r * DS + 4 * c) = v;
   }
@@ -746,17 +762,15 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
   for (int t = 0; t < NT; ++t) st[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // ---- S^T tiles: A = K rows (keys), B = Q rows (queries); d index permuted inside chunks of 16 (element s of the
   //      float4 read at d = 16*jj + 4*q4 is the operand of MFMA step s) identically on both operands
-  const float* qrow = Qs + min(16 * w + c16, L - 1) * DS + 4 * q4;
 #pragma unroll
   for (int jj = 0; jj < DK / 16; ++jj) {
-    const float4 qv = *reinterpret_cast<const float4*>(qrow + 16 * jj);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float4 kv = *reinterpret_cast<const float4*>(Ks + min(16 * t + c16, L - 1) * DS + 4 * q4 + 16 * jj);
-      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qv.x, st[t], 0, 0, 0);
-      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qv.y, st[t], 0, 0, 0);
-      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qv.z, st[t], 0, 0, 0);
-      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qv.w, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qv[jj].x, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qv[jj].y, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qv[jj].z, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qv[jj].w, st[t], 0, 0, 0);
     }
   }
   // ---- bias + mask + softmax over keys: this lane holds keys 16t + 4*q4 + r of query i
@@ -816,7 +830,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
 
 template <int NT>
 static int launch_attention_mfma16(const AttnArgs& a, hipStream_t stream) {
-  const size_t lds = sizeof(float) * ((size_t)3 * a.Lk * 68 + 3 * 16 * NT);
+  const size_t lds = sizeof(float) * ((size_t)2 * a.Lk * 68 + 3 * 16 * NT);
   if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(attention_mfma16_kernel<NT>), 160 * 1024, "attention")) return rc__;
   hipLaunchKernelGGL(attention_mfma16_kernel<NT>, dim3((unsigned)(a.B * a.H)), dim3(64 * NT), lds, stream, a);
   GDR_CHECK_LAUNCH("attention_mfma16_kernel");
