@@ -757,6 +757,9 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
 
   const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, q4 = lane >> 4;
   if (16 * w >= L) return;  // ragged: a query tile past this sequence's end (no barrier follows)
+  // key tiles past this sequence's end are skipped (wave-uniform): their keys carry -inf, i.e. probability exactly 0 and a
+  // contribution of exactly +0 to every sum below — the result is bit-identical to computing them
+  const int nt_live = (L + 15) >> 4;
   f32x4_t st[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) st[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -766,6 +769,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
   for (int jj = 0; jj < DK / 16; ++jj) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      if (t >= nt_live) continue;
       const float4 kv = *reinterpret_cast<const float4*>(Ks + min(16 * t + c16, L - 1) * DS + 4 * q4 + 16 * jj);
       st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qv[jj].x, st[t], 0, 0, 0);
       st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qv[jj].y, st[t], 0, 0, 0);
@@ -779,6 +783,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
   float mx = -INFINITY;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
+    if (t >= nt_live) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int j = 16 * t + 4 * q4 + r;
@@ -794,6 +799,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
   float sum = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
+    if (t >= nt_live) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float p = __expf(st[t][r] - mx);  // padded keys: exp(-inf) = 0
@@ -810,6 +816,7 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
     f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      if (t >= nt_live) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = 16 * t + 4 * q4 + r;
