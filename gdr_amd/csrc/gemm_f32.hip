@@ -1367,8 +1367,24 @@ extern "C" int gdr_linear_f32(const float* A, int64_t lda, const float* W, int64
 extern "C" int gdr_linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
                                      int64_t M, int N, int K, int epilogue, const float* bias, const float* residual,
                                      int64_t ldr, void* workspace, size_t workspace_bytes, void* stream) {
-  return gdr::launch_linear_f32_ws(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, residual, ldr,
-                                   static_cast<float*>(workspace), workspace_bytes, static_cast<hipStream_t>(stream));
+  using namespace gdr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // a workspace that can hold the stream-K hand-off scratch also serves the balanced forms of the big grids (the same
+  // region: a launch uses it for split-K slabs or for the hand-off, never both); its 2 KB of flags are zeroed per call
+  const int64_t tiles = ((M + BM - 1) / BM) * (int64_t)((N + BN - 1) / BN);
+  if (workspace && workspace_bytes >= STREAMK_BYTES && K > 0 && K % BK == 0 && M > 0 && N > 0 && lda >= K && ldw >= K &&
+      (streamk_mid_wanted(tiles) || (tiles > 512 && streamk_wanted(tiles, K / BK))) && streamk_fits(M, lda, N, ldw)) {
+    StreamK sk{static_cast<float*>(workspace),
+               reinterpret_cast<int32_t*>(static_cast<char*>(workspace) + STREAMK_PART_BYTES), 0};
+    if (hipMemsetAsync(sk.flag, 0, 512 * sizeof(int32_t), st) != hipSuccess) {
+      set_error("linear: memset of the stream-K flags failed");
+      return GDR_EHIP;
+    }
+    return launch_linear_f32_ws(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, residual, ldr, static_cast<float*>(workspace),
+                                workspace_bytes, st, &sk);
+  }
+  return launch_linear_f32_ws(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, residual, ldr, static_cast<float*>(workspace),
+                              workspace_bytes, st);
 }
 
 extern "C" int gdr_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M,

@@ -69,7 +69,10 @@ int gdr_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, flo
                    int64_t ldr, void* stream);
 /* Same, with a scratch buffer: when the 128x128 tile grid cannot fill the 256 CUs (decode-time linears with
  * M = batch*beams rows) the K dimension is split into partial slabs [S][M][N] in `workspace` and reduced in fixed
- * order (deterministic) by a second kernel that applies the epilogue.  workspace may be NULL (= gdr_linear_f32). */
+ * order (deterministic) by a second kernel that applies the epilogue.  workspace may be NULL (= gdr_linear_f32).
+ * A workspace of at least 33 558 528 bytes (512 x 64 KiB + 4 KiB) also serves grids of more than 256 tiles: the last
+ * tiles of a launch are then dealt by K-step ranges with an exact accumulator hand-off between workgroups (bit-identical
+ * to whole tiles, DESIGN.md §4 "stream-K tail") instead of leaving CUs idle in a partial last round of tiles. */
 int gdr_linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
                           int64_t M, int N, int K, int epilogue, const float* bias, const float* residual,
                           int64_t ldr, void* workspace, size_t workspace_bytes, void* stream);

@@ -21,13 +21,14 @@ def timed(fn, n=20):
 
 
 rows = []
+ws = torch.empty(48 << 20, dtype=torch.uint8, device=dev)   # split-K / stream-K scratch, as the encoder's linears have it
 for M in (20480, 12308):
     for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
         A = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) * 0.03
         C = torch.empty(M, N, device=dev)
         fl = 2.0 * M * N * K
-        t_ours = timed(lambda: ops.linear(A, W, out=C))
+        t_ours = timed(lambda: ops.linear(A, W, out=C, splitk_ws=ws))
         t_lib = timed(lambda: torch.matmul(A, W.t(), out=C))
         Ab, Wb = A.to(torch.bfloat16), W.to(torch.bfloat16)
         t_ours16 = timed(lambda: ops.linear_bf16(Ab, Wb, out=C))
