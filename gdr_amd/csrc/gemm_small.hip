@@ -161,7 +161,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const float* _
   if (m >= M || n >= N) return;
   const float* p = partial + (int64_t)tile * S * (SB * SB) + r * SB + c;
   float4 v = *reinterpret_cast<const float4*>(p);
-  for (int s = 1; s < S; ++s) {
+  int s = 1;
+  for (; s + 4 <= S; s += 4) {  // fixed summation order s = 0..S-1, four slab loads in flight per round trip
+    const float4 t0 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 0) * (SB * SB));
+    const float4 t1 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 1) * (SB * SB));
+    const float4 t2 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 2) * (SB * SB));
+    const float4 t3 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 3) * (SB * SB));
+    v.x += t0.x, v.y += t0.y, v.z += t0.z, v.w += t0.w;
+    v.x += t1.x, v.y += t1.y, v.z += t1.z, v.w += t1.w;
+    v.x += t2.x, v.y += t2.y, v.z += t2.z, v.w += t2.w;
+    v.x += t3.x, v.y += t3.y, v.z += t3.z, v.w += t3.w;
+  }
+  for (; s < S; ++s) {
     const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)s * (SB * SB));
     v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
   }
@@ -206,19 +217,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __
     if (c4 < n4) {
       const int n = c4 << 2, tn = n / SB, c = n - tn * SB;
       const float* p = partial + ((int64_t)(tm * tiles_n + tn) * S) * (SB * SB) + r * SB + c;
+      // the slabs are summed in the fixed order s = 0..S-1, but loaded four at a time (plus bias / residual up front):
+      // one memory round trip per four slabs instead of one per slab
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f), q = b;
+      if (bias) b = *reinterpret_cast<const float4*>(bias + n);
+      if (residual) q = *reinterpret_cast<const float4*>(residual + m * ldr + n);
       v = *reinterpret_cast<const float4*>(p);
-      for (int s = 1; s < S; ++s) {
+      int s = 1;
+      for (; s + 4 <= S; s += 4) {
+        const float4 t0 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 0) * (SB * SB));
+        const float4 t1 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 1) * (SB * SB));
+        const float4 t2 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 2) * (SB * SB));
+        const float4 t3 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 3) * (SB * SB));
+        v.x += t0.x, v.y += t0.y, v.z += t0.z, v.w += t0.w;
+        v.x += t1.x, v.y += t1.y, v.z += t1.z, v.w += t1.w;
+        v.x += t2.x, v.y += t2.y, v.z += t2.z, v.w += t2.w;
+        v.x += t3.x, v.y += t3.y, v.z += t3.z, v.w += t3.w;
+      }
+      for (; s < S; ++s) {
         const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)s * (SB * SB));
         v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
       }
-      if (bias) {
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
-        v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
-      }
-      if (residual) {
-        const float4 q = *reinterpret_cast<const float4*>(residual + m * ldr + n);
-        v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
-      }
+      if (bias) v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+      if (residual) v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
       if (act == 1) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
       *reinterpret_cast<float4*>(C + m * ldc + n) = v;
     }
