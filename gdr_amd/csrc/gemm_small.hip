@@ -309,6 +309,85 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __
   }
 }
 
+// The same reduction + epilogue + norm with ONE ROW PER WORKGROUP (thread <-> float4 column, N <= 1024), for the row counts
+// of a single decoded query (M = beams): the wave-per-row kernel above puts 100 rows on 25 workgroups and walks the slabs
+// in two or three dependent round trips; here every slab load of a row (S <= 8) is in flight at once on M workgroups, and
+// the row statistics are combined across the four waves through LDS.  Same fixed slab order s = 0..S-1.
+__global__ __launch_bounds__(256) void splitk_reduce_norm_row_kernel(const float* __restrict__ partial, int S, int tiles_n,
+                                                                    int64_t M, int N, float* __restrict__ C, int64_t ldc,
+                                                                    const float* __restrict__ bias,
+                                                                    const float* __restrict__ residual, int64_t ldr, int act,
+                                                                    const int64_t* __restrict__ m_dev, const NormEpilogue ne) {
+  __shared__ float red[4];
+  if (m_dev) M = *m_dev;
+  const int64_t m = blockIdx.x;
+  if (m >= M) return;  // uniform
+  const int tid = threadIdx.x, n4 = N >> 2, wave = tid >> 6;
+  const bool on = tid < n4;
+  const int tm = (int)(m / SB), r = (int)(m - (int64_t)tm * SB);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (on) {
+    const int n = tid << 2, tn = n / SB, c = n - tn * SB;
+    const float* p = partial + ((int64_t)(tm * tiles_n + tn) * S) * (SB * SB) + r * SB + c;
+    float4 b = v, q = v, t[8];
+    if (bias) b = *reinterpret_cast<const float4*>(bias + n);
+    if (residual) q = *reinterpret_cast<const float4*>(residual + m * ldr + n);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (s < S) t[s] = *reinterpret_cast<const float4*>(p + (int64_t)s * (SB * SB));
+    v = t[0];
+#pragma unroll
+    for (int s = 1; s < 8; ++s)
+      if (s < S) v.x += t[s].x, v.y += t[s].y, v.z += t[s].z, v.w += t[s].w;
+    for (int s = 8; s < S; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(p + (int64_t)s * (SB * SB));
+      v.x += u.x, v.y += u.y, v.z += u.z, v.w += u.w;
+    }
+    if (bias) v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+    if (residual) v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+    if (act == 1) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+    *reinterpret_cast<float4*>(C + m * ldc + n) = v;
+  }
+  auto block_sum = [&](float x) {  // every thread gets the sum over the workgroup (fixed order: lanes by butterfly, waves 0..3)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    __syncthreads();  // the previous reduction's reads are done
+    if ((tid & 63) == 0) red[wave] = x;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
+  };
+  float* yr = ne.Y + m * ne.ldy;
+  if (ne.kind == 1) {
+    const float ss = block_sum(on ? v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w : 0.f);
+    const float denom = sqrtf(ss / (float)N + ne.eps);
+    if (on) {
+      const float4 g = reinterpret_cast<const float4*>(ne.w1)[tid];
+      *reinterpret_cast<float4*>(yr + 4 * tid) = make_float4(g.x * (v.x / denom), g.y * (v.y / denom), g.z * (v.z / denom),
+                                                             g.w * (v.w / denom));
+    }
+    return;
+  }
+  const float inv_d = 1.0f / (float)N;
+  auto layer_norm = [&](const float* w, const float* b) {
+    const float mean = block_sum(on ? v.x + v.y + v.z + v.w : 0.f) * inv_d;
+    const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+    const float rstd = 1.0f / sqrtf(block_sum(on ? a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 : 0.f) * inv_d + ne.eps);
+    if (on) {
+      const float4 g = reinterpret_cast<const float4*>(w)[tid], bb = reinterpret_cast<const float4*>(b)[tid];
+      v = make_float4(a0 * rstd * g.x + bb.x, a1 * rstd * g.y + bb.y, a2 * rstd * g.z + bb.z, a3 * rstd * g.w + bb.w);
+    }
+  };
+  layer_norm(ne.w1, ne.b1);
+  if (ne.kind == 3) {
+    if (on) {
+      const float4 t = reinterpret_cast<const float4*>(ne.addv)[tid];
+      v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+    }
+    layer_norm(ne.w2, ne.b2);
+  }
+  if (on) *reinterpret_cast<float4*>(yr + 4 * tid) = v;
+}
+
 // Returns 1 when the shape is left to the 128x128 core, 0 after launching, < 0 on error.
 int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
@@ -357,6 +436,16 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
     const unsigned grid = (unsigned)((M + 3) / 4);
     const float* bp = has_bias ? bias : nullptr;
     const float* rp = has_residual ? residual : nullptr;
+    static const int row_max = [] {
+      const char* e = getenv("GDR_REDUCE_NORM_ROW_MAX");  // A/B knob: largest M served by the row-per-workgroup form; 0 = off
+      return e ? atoi(e) : 4096;  // measured better at every row count of the decode path (10 .. 640 rows: -2 .. -7 % per generate())
+    }();
+    if (M <= row_max && N <= 1024) {
+      hipLaunchKernelGGL(splitk_reduce_norm_row_kernel, dim3((unsigned)M), dim3(256), 0, stream, ws, S, tiles_n, M, N, C, ldc, bp, rp,
+                         ldr, act, m_dev, *ne);
+      GDR_CHECK_LAUNCH("splitk_reduce_norm_row_kernel");
+      return 0;
+    }
     const int nv = (N / 4 + 63) / 64;
 #define GDR_RN(NV_) \
   hipLaunchKernelGGL(splitk_reduce_norm_kernel<NV_>, dim3(grid), dim3(256), 0, stream, ws, S, tiles_n, M, N, C, ldc, bp, rp, ldr, act, m_dev, *ne)
