@@ -101,10 +101,18 @@ struct NormEpilogue {
   float* Y;                 // normed rows [M, ldy]
   int64_t ldy;
 };
+// Split-K slabs left UN-reduced for a consumer that sums them itself (the decode cross-attention reads its q rows so and the
+// reduction launch disappears): element (m, n) = sum over s < S, in that order, of
+//   part[((m/64 * tiles_n + n/64) * S + s) * 4096 + (m%64)*64 + n%64].   S == 1: nothing was split, C holds the result.
+struct SlabRef {
+  const float* part;
+  int S, tiles_n;
+};
 int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev = nullptr,
-                            const NormEpilogue* ne = nullptr);  // with ne: returns 2 if the fused form does not apply
+                            const NormEpilogue* ne = nullptr,  // with ne: returns 2 if the fused form does not apply
+                            SlabRef* slabs = nullptr);         // with slabs (no epilogue allowed): the reduction is left to the caller
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, int out_bf16, hipStream_t stream, const int64_t* m_dev = nullptr);

@@ -945,6 +945,10 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
     GDR_TRY(LIN(enc_hidden, d, w->layers[l].wkv_c, d, crosskv + l * ckv_layer, 2 * inner, (int64_t)B * L,
                               2 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
 
+  static const bool slab_q_on = [] {
+    const char* e = getenv("GDR_DECODE_SLAB_Q");  // A/B knob: 0 = reduce the cross-attention q projection in its own launch
+    return e ? atoi(e) != 0 : true;
+  }();
   const BucketLut lut_uni = make_bucket_lut(dm.rel_buckets, dm.rel_max_distance);
   const BucketLut lut_bi = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
   int cur = 0;
@@ -1044,7 +1048,17 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       GDR_TRY(launch_attention(at, stream));
       GDR_TRY(LINN(ctx, inner, ly.wo, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, rms(ly.ln_cross, nx)));
       // cross attention over the encoder states of the row's query
-      GDR_TRY(LIN(nx, d, ly.wq_c, d, qc, inner, rows, inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
+      // the q projection's split-K slabs go to the attention kernel un-reduced (it sums them while it stages the beam rows'
+      // queries): one dependent launch less per layer and step
+      SlabRef qsl{nullptr, 1, 0};
+      bool q_from_slabs = false;
+      if (slab_q_on && !bf16 && ((rows + 127) / 128) * ((inner + 127) / 128) < 192 && rows <= 1536 && d % 32 == 0 && d / 32 >= 4) {
+        const int rc_ = launch_linear_f32_small(nx, d, ly.wq_c, d, qc, inner, rows, inner, d, 0, 0, 0, nullptr, nullptr, 0, skw,
+                                                SPLITK_WS_BYTES, stream, nullptr, nullptr, &qsl);
+        if (rc_ < 0) return rc_;
+        q_from_slabs = rc_ == 0;
+      }
+      if (!q_from_slabs) GDR_TRY(LIN(nx, d, ly.wq_c, d, qc, inner, rows, inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
       AttnArgs ca{};
       const float* ckv = crosskv + l * ckv_layer;
       // the R beam rows of a query are consecutive and share its K/V: one workgroup per (query, head) stages K/V
@@ -1056,6 +1070,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       ca.rel_bias = w->cross_rel_bias, ca.bidirectional = 1, ca.num_buckets = dm.rel_buckets, ca.lut = lut_bi;
       ca.key_mask = enc_mask, ca.mask_bstride = L, ca.causal = 0, ca.causal_neg_inf = 0;
       ca.kv_rows = nullptr, ca.kv_group = 1;
+      if (q_from_slabs && qsl.S > 1) ca.q_part = qsl.part, ca.q_S = qsl.S, ca.q_tiles_n = qsl.tiles_n;
       GDR_TRY(launch_attention(ca, stream));
       GDR_TRY(LINN(ctx, inner, ly.wo_c, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, rms(ly.ln_ff, nx)));
       GDR_TRY(LIN(nx, d, ly.wi, d, ff, dm.d_ff, rows, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0));

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_row_kernel(const float
 int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev,
-                            const NormEpilogue* ne) {
+                            const NormEpilogue* ne, SlabRef* slabs) {
   static const int target = [] {
     const char* e = getenv("GDR_SMALL_TARGET");  // tuning knob: workgroups wanted per launch; 0 disables this kernel
     return e ? atoi(e) : 512;
@@ -418,6 +418,10 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
   g.m_dev = m_dev;
   const double flops = 2.0 * (double)M * (double)N * (double)K;
   if (ne && (S == 1 || N % 4 != 0 || N > 256 * 4 * 4 || act > 1)) return 2;  // the fused norm needs split slabs of a row it can hold
+  if (slabs) {
+    if (has_bias || has_residual || act || ne) return 1;  // slabs carry raw partial sums only
+    slabs->part = nullptr, slabs->S = 1, slabs->tiles_n = tiles_n;
+  }
   if (S == 1) {
     g.C = C, g.has_bias = has_bias, g.has_residual = has_residual, g.act = act;
     ProfScope prof(PROF_LINEAR, flops, stream);
@@ -431,6 +435,10 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
     hipLaunchKernelGGL(gemm_nt_f32_small_kernel, dim3((unsigned)(tiles * S)), dim3(256), 0, stream, g);
   }
   GDR_CHECK_LAUNCH("gemm_nt_f32_small_kernel(split)");
+  if (slabs) {  // the consumer reduces
+    slabs->part = ws, slabs->S = S, slabs->tiles_n = tiles_n;
+    return 0;
+  }
   ProfScope prof_r(PROF_REDUCE, 0.0, stream);
   if (ne) {
     const unsigned grid = (unsigned)((M + 3) / 4);

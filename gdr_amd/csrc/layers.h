@@ -43,6 +43,10 @@ struct AttnArgs {
   int qkv_bf16;                // q, k, v point to bf16 data (ldq / ldk / ldv in bf16 elements): the qkv linear of the bf16
                                // precision mode emits them so; attention_mfma16_kernel only (d_kv = 64 self-attention)
   const int64_t* b_count_dev;  // Lq = 1 decode form only, may be null: only batch entries b < *b_count_dev are computed
+  // q left as split-K slabs by the projection in front (common.h SlabRef; generic kernel only): when q_part != null the
+  // query element (row m, column n) is the sum over s < q_S of the slabs, in order, and `q` is not read
+  const float* q_part;
+  int q_S, q_tiles_n;
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 

@@ -398,7 +398,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   if (pre) {
     for (int e = tid; e < (i1 - i0) * c4; e += 256) {
       const int r = e / c4, c = e - r * c4;
-      float4 q = *reinterpret_cast<const float4*>(a.q + ((int64_t)b * a.q_bstride + i0 + r) * a.ldq + h * dk + 4 * c);
+      float4 q;
+      if (a.q_part) {  // the projection's split-K slabs, summed here in the reduction kernel's order
+        const int64_t m = (int64_t)b * a.q_bstride + i0 + r;
+        const int n = h * dk + 4 * c;
+        const float* p = a.q_part + ((m >> 6) * a.q_tiles_n + (n >> 6)) * (int64_t)a.q_S * 4096 + (m & 63) * 64 + (n & 63);
+        float4 t[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          if (s < a.q_S) t[s] = *reinterpret_cast<const float4*>(p + (int64_t)s * 4096);
+        q = t[0];
+#pragma unroll
+        for (int s = 1; s < 8; ++s)
+          if (s < a.q_S) q.x += t[s].x, q.y += t[s].y, q.z += t[s].z, q.w += t[s].w;
+        for (int s = 8; s < a.q_S; ++s) {
+          const float4 u = *reinterpret_cast<const float4*>(p + (int64_t)s * 4096);
+          q.x += u.x, q.y += u.y, q.z += u.z, q.w += u.w;
+        }
+      } else {
+        q = *reinterpret_cast<const float4*>(a.q + ((int64_t)b * a.q_bstride + i0 + r) * a.ldq + h * dk + 4 * c);
+      }
       q.x *= a.scale, q.y *= a.scale, q.z *= a.scale, q.w *= a.scale;
       *reinterpret_cast<float4*>(Qs + r * dk + 4 * c) = q;
     }
@@ -1029,6 +1048,8 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   if (a.B == 0 || a.Lq == 0) return GDR_OK;
   ProfScope prof(PROF_ATTENTION, 4.0 * a.B * a.H * (double)a.Lq * a.Lk * a.dk, stream);
   GDR_CHECK_ARG(!a.out_bf16 || a.Lq > 1, "attention: bf16 output is not available in the Lq = 1 decode form");
+  GDR_CHECK_ARG(!a.q_part || (a.Lq > 1 && a.q_same_pos && a.dk % 4 == 0 && a.q_S >= 1 && (a.H * a.dk) % 4 == 0),
+                "attention: slab-sourced q serves the shared-K/V decode form (generic kernel) only");
   if (a.Lq == 1) {
     static const bool rows_form = [] {
       const char* e = getenv("GDR_ATTN_DECODE_ROWS");  // A/B knob: 0 = the lane-per-key kernel
@@ -1081,7 +1102,11 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   int chunks = (512 + a.B * a.H - 1) / (a.B * a.H);  // aim at ~2 workgroups per CU, at least 4 rows (one per wave) each
   const int max_chunks = (a.Lq + 3) / 4;
   chunks = chunks < 1 ? 1 : (chunks > max_chunks ? max_chunks : chunks);
-  const int rows_per = (a.Lq + chunks - 1) / chunks;
+  int rows_per = (a.Lq + chunks - 1) / chunks;
+  if (a.q_part && rows_per > 32) {  // slab-sourced q rows are summed while they are staged: keep a workgroup's share stageable
+    chunks = (a.Lq + 31) / 32;
+    rows_per = (a.Lq + chunks - 1) / chunks;
+  }
   const int qrows = rows_per <= 32 ? ((rows_per + 3) & ~3) : 4;  // as the kernel lays its query strip out
   const size_t lds = sizeof(float) * ((size_t)2 * a.Lk * dks + (size_t)qrows * a.dk + 4 * Lkp + 256);
   GDR_CHECK_ARG(lds <= 160 * 1024, "attention: Lk=%d dk=%d needs %zu B of LDS", a.Lk, a.dk, lds);

@@ -10,3 +10,4 @@ tot=sum(int(r['TotalDurationNs']) for r in rows)
 for r in rows[:22]: print(r['Name'][:84].ljust(84), r['Calls'].rjust(6), f"{int(r['TotalDurationNs'])/1e6:8.2f}ms", f"{float(r['AverageNs'])/1e3:8.1f}us", r['Percentage'])
 print('total', tot/1e6)
 PY
+python3 $R/tools/trace_gaps.py $(ls /tmp/gp/*/*kernel_trace.csv | head -1) 2>/dev/null | head -8
