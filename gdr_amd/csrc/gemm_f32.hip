@@ -1031,7 +1031,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   if (m >= M || n >= N) return;
   const float* p = partial + (int64_t)local_tile * S * (BM * BN) + r * BN + c;
   float4 v = *reinterpret_cast<const float4*>(p);
-  for (int s = 1; s < S; ++s) {
+  int s = 1;
+  for (; s + 4 <= S; s += 4) {  // fixed summation order s = 0..S-1, four slab loads in flight per round trip
+    const float4 t0 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 0) * (BM * BN));
+    const float4 t1 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 1) * (BM * BN));
+    const float4 t2 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 2) * (BM * BN));
+    const float4 t3 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 3) * (BM * BN));
+    v.x += t0.x, v.y += t0.y, v.z += t0.z, v.w += t0.w;
+    v.x += t1.x, v.y += t1.y, v.z += t1.z, v.w += t1.w;
+    v.x += t2.x, v.y += t2.y, v.z += t2.z, v.w += t2.w;
+    v.x += t3.x, v.y += t3.y, v.z += t3.z, v.w += t3.w;
+  }
+  for (; s < S; ++s) {
     const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)s * (BM * BN));
     v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
   }
