@@ -346,7 +346,10 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims b
   __syncthreads();
   // Bitonic sort, descending.  A wave owns a block of epw consecutive keys: every stage whose compare-exchange pairs stay
   // inside a block (2*stride <= epw) needs no workgroup barrier — LDS operations of one wave execute in order — so of the
-  // 78 stages of a 4096-key sort (100 beams) only the 10 with stride >= 256 cost a barrier pair (52 -> 14 us per step).
+  // 78 stages of a 4096-key sort (100 beams) only the 10 with stride >= 256 cost a barrier pair.  The kernel takes 49 us
+  // per step at 100 beams (rocprofv3); keeping the keys in registers (4 per lane: in-thread swaps, 64-bit shuffles inside a
+  // wave, LDS only across waves) was built and measured no faster (54 us) — 8 ds_bpermute per shuffle stage cost what the
+  // LDS round trip of a stage costs.
   const int epw = npad / nwaves;
   for (int size = 2; size <= npad; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
