@@ -498,3 +498,28 @@ def test_integration_md_stub_runs_as_written(dev):
         os.chdir(cwd)
     rv, ri = (torch.from_numpy(Q) @ torch.from_numpy(D).T).topk(10)
     order_insensitive_topk_match(rv.numpy(), ri.numpy(), v.cpu().numpy(), i.cpu().numpy(), TOL)
+
+
+@pytest.mark.parametrize("M,N,K", [(12308, 768, 768), (12308, 2304, 768), (5120, 2304, 768), (2560, 2304, 768),
+                                   (3000, 3072, 768), (9000, 768, 3072)])
+def test_linear_with_streamk_scratch_is_bit_identical_to_whole_tiles(dev, M, N, K):
+    """gdr_linear_f32_splitk with a workspace that holds the stream-K hand-off scratch (include/gdr_hip.h): grids of more than
+    256 tiles take the stream-K forms (tail of a multi-round launch, or the 256-workgroup launch between one and two tiles
+    per CU) and must give the SAME BITS as gdr_linear_f32's whole tiles — every output element is one k-ordered fmaf chain
+    either way.  With residual (in place, as the encoder's o / wo projections run) and ReLU epilogues."""
+    from gdr_amd import ops, _ffi
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    R = torch.randn(M, N, generator=g).to(dev)
+    ws = torch.empty(48 << 20, dtype=torch.uint8, device=dev)
+    for epi, kw in ((_ffi.EPI_NONE, {}), (_ffi.EPI_RELU, {}), (_ffi.EPI_RESIDUAL, dict(residual=R))):
+        whole = ops.linear(A, W, epilogue=epi, **kw)
+        tail = ops.linear(A, W, epilogue=epi, splitk_ws=ws, **kw)
+        assert torch.equal(whole, tail), f"epilogue {epi}"
+    h0, h1 = R.clone(), R.clone()
+    ops.linear(A, W, epilogue=_ffi.EPI_RESIDUAL, residual=h0, out=h0)
+    ops.linear(A, W, epilogue=_ffi.EPI_RESIDUAL, residual=h1, out=h1, splitk_ws=ws)
+    assert torch.equal(h0, h1)
+    ref = (A[:64].cpu().double() @ W.cpu().double().T).float()                # and it is the right product
+    torch.testing.assert_close(ops.linear(A, W, splitk_ws=ws)[:64].cpu(), ref, rtol=TOL, atol=TOL)
