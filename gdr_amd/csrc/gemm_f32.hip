@@ -588,25 +588,52 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
             }
         }
       } else {
+        // edge tile (the last, partial row panel of a packed batch; a column tail): the same batched structure — rows and
+        // columns past the matrix are CLAMPED for the loads (legal addresses, one batch) and masked for the stores.  With a
+        // per-element `continue` every residual load sat behind its own vmcnt(0) and the 6..24 edge tiles of a launch finished
+        // after everyone else: 12 350 live rows (62 in the last panel) 17.2 -> 16.05 ms of linears per encoder pass
+        // (tools/exp_edge.py; 12 416 rows = 97 full panels: 15.8 ms).
+        const int64_t mrow = m0 + wm * 64 + 4 * h;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const int n = n0 + wn * 64 + ni * 32 + l31;
           const bool n_ok = n < g.N;
-          const float bia = (g.has_bias && n_ok) ? g.bias[n] : 0.f;
+          const int nc = n_ok ? n : g.N - 1;
+          if (g.has_bias) {
+            const float bia = g.bias[nc];
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] += bia;
+          }
+          if (g.has_residual) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int64_t m = mrow + mi * 32 + (r & 3) + 8 * (r >> 2);
+                acc[mi][ni][r] += g.residual[(m < Mrows ? m : Mrows - 1) * g.ldr + nc];
+              }
+          }
+          if (g.act == ACT_RELU) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaxf(acc[mi][ni][r], 0.f);
+          } else if (g.act == ACT_GELU) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] = gelu_erf(acc[mi][ni][r]);
+          }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-              float v = acc[mi][ni][r] + bia;
+              const int64_t m = mrow + mi * 32 + (r & 3) + 8 * (r >> 2);
+              if (n_ok && m < Mrows) g.C[m * g.ldc + n] = acc[mi][ni][r];
               acc[mi][ni][r] = 0.f;
-              if (!n_ok || m >= Mrows) continue;
-              if (g.has_residual) v += g.residual[m * g.ldr + n];
-              if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
-              if (g.act == ACT_GELU) v = gelu_erf(v);
-              g.C[m * g.ldc + n] = v;
             }
-          }
         }
       }
       kt = 0;
@@ -962,25 +989,52 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
             }
         }
       } else {
+        // edge tile (the last, partial row panel of a packed batch; a column tail): the same batched structure — rows and
+        // columns past the matrix are CLAMPED for the loads (legal addresses, one batch) and masked for the stores.  With a
+        // per-element `continue` every residual load sat behind its own vmcnt(0) and the 6..24 edge tiles of a launch finished
+        // after everyone else: 12 350 live rows (62 in the last panel) 17.2 -> 16.05 ms of linears per encoder pass
+        // (tools/exp_edge.py; 12 416 rows = 97 full panels: 15.8 ms).
+        const int64_t mrow = m0 + wm * 64 + 4 * h;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const int n = n0 + wn * 64 + ni * 32 + l31;
           const bool n_ok = n < g.N;
-          const float bia = (g.has_bias && n_ok) ? g.bias[n] : 0.f;
+          const int nc = n_ok ? n : g.N - 1;
+          if (g.has_bias) {
+            const float bia = g.bias[nc];
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] += bia;
+          }
+          if (g.has_residual) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int64_t m = mrow + mi * 32 + (r & 3) + 8 * (r >> 2);
+                acc[mi][ni][r] += g.residual[(m < Mrows ? m : Mrows - 1) * g.ldr + nc];
+              }
+          }
+          if (g.act == ACT_RELU) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaxf(acc[mi][ni][r], 0.f);
+          } else if (g.act == ACT_GELU) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] = gelu_erf(acc[mi][ni][r]);
+          }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-              float v = acc[mi][ni][r] + bia;
+              const int64_t m = mrow + mi * 32 + (r & 3) + 8 * (r >> 2);
+              if (n_ok && m < Mrows) g.C[m * g.ldc + n] = acc[mi][ni][r];
               acc[mi][ni][r] = 0.f;
-              if (!n_ok || m >= Mrows) continue;
-              if (g.has_residual) v += g.residual[m * g.ldr + n];
-              if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
-              if (g.act == ACT_GELU) v = gelu_erf(v);
-              g.C[m * g.ldc + n] = v;
             }
-          }
         }
       }
      }
