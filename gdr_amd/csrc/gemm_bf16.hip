@@ -193,16 +193,18 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     return;
   }
   // ---- epilogue: row m = block*16 + lane&15, columns n = block*16 + 4*(lane>>4) + 0..3 ----
-  const bool interior = m0 + 128 <= Mv && n0 + 128 <= g.N && (g.ldc & 3) == 0 &&
-                        (!g.has_residual || (g.ldr & 3) == 0);
+  // 16-byte accesses need whole column quads inside N and aligned rows; rows past the live count (the partial last row
+  // panel of a packed batch) are simply skipped — a per-ROW test, so the valid rows of an edge panel keep the vector path
+  const bool cols_vec = n0 + 128 <= g.N && (g.ldc & 3) == 0 && (!g.has_residual || (g.ldr & 3) == 0);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const int64_t m = m0 + wm * 64 + mi * 16 + r16;
+    if (m >= Mv) continue;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = (int)n0 + wn * 64 + ni * 16 + 4 * q4;
       float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-      if (interior) {
+      if (cols_vec) {
         if (g.has_bias) {
           const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
           v[0] += b.x, v[1] += b.y, v[2] += b.z, v[3] += b.w;
