@@ -48,6 +48,17 @@ struct GemmArgs {
   SimEpilogue sim;
 };
 
+// Device-side row count of a packed batch, rounded UP to whole 128-row panels (never past the buffers' M rows): the rows
+// between the live count and the panel's end are scratch — nothing reads them — so the last panel runs the interior tile
+// path like every other instead of the clamped / masked edge path (20 live rows in the 97th panel of the C2 batch cost
+// 1.5 % of the linears' time).  Live rows are unaffected: a GEMM row depends on nothing but itself.
+__device__ __forceinline__ int64_t live_rows_padded(const GemmArgs& g) {
+  if (!g.m_dev) return g.M;
+  const int64_t up = (*g.m_dev + (BM - 1)) / BM * BM;
+  return up < g.M ? up : g.M;
+}
+
+
 enum { EPI_LINEAR = 0, EPI_SIM_SAMPLE = 100, EPI_SIM_FILTER = 101 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
@@ -91,7 +102,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
   const int n0 = nt * BN;
   int64_t Mrows = g.M;
   if (EPI == EPI_LINEAR && g.m_dev) {
-    Mrows = *g.m_dev;
+    Mrows = live_rows_padded(g);
     if (m0 >= Mrows) return;  // uniform: a tile past the device-side row count
   }
 
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
   const int a_rd = (wm * 64 + l31) * LDS_STRIDE + 4 * h;
   const int b_rd = (wn * 64 + l31) * LDS_STRIDE + 4 * h;
   const int nk = g.K / BK;
-  const int64_t Mrows = g.m_dev ? *g.m_dev : g.M;  // ragged batches: the row count is a device-side value <= g.M
+  const int64_t Mrows = live_rows_padded(g);  // ragged batches: a device-side value <= g.M, in whole row panels
   const int tiles_m = (int)((Mrows + BM - 1) / BM);
   const int total_tiles = g.m_dev ? tiles_m * g.tiles_n : total_tiles_host;
 
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
   const int a_rd = (wm * 64 + l31) * LDS_STRIDE + 4 * h;
   const int b_rd = (wn * 64 + l31) * LDS_STRIDE + 4 * h;
   const int nk = g.K / BK;
-  const int64_t Mrows = g.m_dev ? *g.m_dev : g.M;  // ragged batches: the row count is a device-side value <= g.M
+  const int64_t Mrows = live_rows_padded(g);  // ragged batches: a device-side value <= g.M, in whole row panels
   const int tiles_m = (int)((Mrows + BM - 1) / BM);
   const int total_tiles = g.m_dev ? tiles_m * g.tiles_n : total_tiles_host;
 
