@@ -10,6 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDR_HIP_LIB") or os.path.join(_HERE, "libgdr_hip.so")   # override: A/B builds in the lab
 
 GDR_OK, GDR_EINVAL, GDR_ENOSPC, GDR_EHIP = 0, -1, -2, -3
+ABI_VERSION = 3                  # what this binding was written against (gdr_abi_version(), csrc/common.hip)
+RERANK_POSITIONS = 1
 SIM_EXHAUSTIVE = 1
 SIM_NO_STREAM = 2
 EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL, EPI_BIAS_GELU = range(7)
@@ -55,6 +57,11 @@ class GdrPrefixTable(C.Structure):
                 ("kv", C.c_void_p), ("W", C.c_void_p)]
 
 
+class GdrClusterIndex(C.Structure):
+    _fields_ = [("n_clusters", C.c_int32), ("key_len", C.c_int32), ("table_size", C.c_int32), ("slots", C.c_void_p),
+                ("keys", C.c_void_p), ("key_lens", C.c_void_p), ("offsets", C.c_void_p), ("members", C.c_void_p)]
+
+
 class GdrT5DecLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln_self", "wqkv", "wo", "ln_cross", "wq_c", "wkv_c", "wo_c", "ln_ff", "wi",
                                           "wo_ff")]
@@ -83,6 +90,7 @@ SIGNATURES = {
     "gdr_linear_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "gdr_linear_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "gdr_linear_f32_splitk": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "gdr_l2_normalize": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
     "gdr_t5_encoder_workspace_bytes": (_sz, [C.POINTER(GdrT5Dims), _i, _i]),
     "gdr_t5_encoder_forward": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "gdr_t5_encoder_ragged_workspace_bytes": (_sz, [C.POINTER(GdrT5Dims), _i, _i]),
@@ -97,7 +105,13 @@ SIGNATURES = {
     "gdr_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "gdr_topk_pack": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "gdr_topk_merge_packed": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "gdr_rerank_topk": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "gdr_rerank_workspace_bytes": (_sz, [_i, _i]),
+    "gdr_rerank_topk": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, C.c_int32, C.c_int32, _i,
+                             _vp, _sz, _vp]),
+    "gdr_rerank_topk_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, C.c_int32, C.c_int32,
+                                  _i, _vp, _sz, _vp]),
+    "gdr_cluster_key_hash": (C.c_uint64, [C.POINTER(C.c_int32), _i]),
+    "gdr_cluster_candidates": (_i, [C.POINTER(GdrClusterIndex), _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "gdr_t5_relative_bucket_table": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
     "gdr_bert_encoder_workspace_bytes": (_sz, [C.POINTER(GdrBertWeights), _i, _i]),
     "gdr_bert_encoder_forward": (_i, [C.POINTER(GdrBertWeights), _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -131,6 +145,10 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)            # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
+        got = l.gdr_abi_version()
+        if got != ABI_VERSION:               # a stale build (or a GDR_HIP_LIB override) with another argument layout
+            raise GdrError(f"{LIB_PATH} reports ABI version {got}, this binding needs {ABI_VERSION}: rebuild it with "
+                           "`make -C gdr_amd/csrc` (or drop the GDR_HIP_LIB override)")
         _lib = l
     return _lib
 

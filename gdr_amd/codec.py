@@ -78,6 +78,35 @@ class ClusterIndex:
             return []                       # unknown / undecodable cluster: empty segment
         return self.members[self.offsets[c]:self.offsets[c + 1]].tolist()
 
+    def token_bodies(self, V, position=1, kary=30):
+        """For every cluster name the token body whose decode_token() image is that name — the inverse of
+        main_models.py:322-346 with separator '-': token_i = x_i + (i*V + 2 if position else 2) — or None when no token
+        sequence prints as the name (not a '-'-joined list of canonical integers: such a name can never be decoded, the
+        reference's dict would simply never be asked for it).  '' is the empty body (a row START, EOS)."""
+        if not kary:
+            raise ValueError("token_bodies needs a '-'-separated id scheme (--kary > 0)")
+        out = []
+        for name in self.names:
+            if name == "":
+                out.append([])
+                continue
+            xs, i, n, ok = [], 0, len(name), True
+            while i < n:
+                j = i + 1 if name[i] == "-" else i
+                e = j
+                while e < n and name[e].isdigit():
+                    e += 1
+                if e == j or (e < n and name[e] != "-") or e == n - 1:   # no digits / junk / trailing separator
+                    ok = False
+                    break
+                xs.append(int(name[i:e]))
+                i = e + 1
+            if not ok or "-".join(str(x) for x in xs) != name:
+                out.append(None)
+                continue
+            out.append([x + (k * V + 2 if position else 2) for k, x in enumerate(xs)])
+        return out
+
     def candidates(self, dec):
         """dec: list[B] of list[R] cluster strings -> (cand_offsets int32[B*R+1], cand_ids int32[total], max per query)
         in the order validation_step_i builds them (main_models.py:1441-1443)."""

@@ -421,6 +421,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
   const int64_t Mrows = live_rows_padded(g);  // ragged batches: a device-side value <= g.M, in whole row panels
   const int tiles_m = (int)((Mrows + BM - 1) / BM);
   const int total_tiles = g.m_dev ? tiles_m * g.tiles_n : total_tiles_host;
+  // a device-side row count of 0 (prefix-table decode when every beam hits the table): no tile exists to park the load
+  // stream on — the prologue below would divide by gm_ = 0 and clamp rows to -1.  Uniform exit before anything is loaded.
+  if (total_tiles <= 0) return;
 
   int64_t a_ld[4];  // element offsets from g.A / g.W — kept as integers: pointers that pass through the tile-crossing
   int64_t w_ld[4];  // select lose their address space and the loads degrade to flat_load (vmcnt AND lgkmcnt)
@@ -685,7 +688,35 @@ struct StreamKArgs {
   float* part;
   int32_t* flag;
   int32_t epoch;
+  int32_t* err;  // host-mapped word (streamk_err_word): a take-over that timed out raises it; may be null
 };
+// A take-over spin that runs out (the predecessor workgroup never became resident for seconds — a co-tenant kernel that
+// starves it; the kernel itself assumes its <= 512 workgroups are co-resident, 2 per CU) used to trap, which aborts the
+// whole process.  Now the waiting lane raises this process-wide word (pinned host memory, mapped into every device) and
+// the workgroup goes on with whatever the hand-off buffer holds: the launch completes, its output is WRONG, and the next
+// stream-K launch from the host (streamk_poll_error) reports GDR_EHIP once.  No hang, no abort.
+static int32_t* streamk_err_word() {
+  static int32_t* word = [] {
+    int32_t* h = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+      (void)hipGetLastError();
+      return static_cast<int32_t*>(nullptr);
+    }
+    *h = 0;
+    return h;
+  }();
+  return word;
+}
+static int streamk_poll_error() {
+  int32_t* w = streamk_err_word();
+  if (w && __atomic_load_n(w, __ATOMIC_RELAXED) != 0) {
+    __atomic_store_n(w, 0, __ATOMIC_RELAXED);
+    set_error("linear(stream-K): a hand-off between workgroups timed out in an EARLIER launch (its 512 workgroups were not "
+              "co-resident: another kernel held the CUs for seconds); that launch's output is invalid");
+    return GDR_EHIP;
+  }
+  return GDR_OK;
+}
 // When it runs: the whole-tile form takes ceil(T/G) rounds (measured: a last round with <= 256 tiles is no shorter), this
 // form T/G rounds plus the hand-off (one 64 KB write-through publish and one 64 KB take-over per workgroup, ~5 K-steps of
 // time at 2 workgroups per CU).  It is used when the whole-tile form's idle tail, (G - T mod G)/G of a round, exceeds
@@ -859,7 +890,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
       int spins_ = 0;                                                                                             \
       while (__hip_atomic_load(sk.flag + (bid - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {    \
         __builtin_amdgcn_s_sleep(8);                                                                              \
-        if (++spins_ > (1 << 24)) __builtin_trap(); /* seconds: the predecessor never ran — fail, do not hang */  \
+        if (++spins_ > (1 << 24)) { /* seconds: the predecessor never ran — flag the launch as failed, do not hang */ \
+          if (sk.err) __hip_atomic_store(sk.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);                 \
+          break;                                                                                                  \
+        }                                                                                                         \
       }                                                                                                           \
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* one lane: drops this CU's stale L1 lines of the buffer */ \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
@@ -1262,7 +1296,8 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
   }();
   if (sk && streamk_mid_wanted(tiles) && K % BK == 0 && streamk_fits(M, lda, N, ldw)) {
     g.ksplit = g.tiles_n >= 12 ? 8 : 1;
-    const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch};
+    if (int rc_ = streamk_poll_error()) return rc_;
+      const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch, streamk_err_word()};
     hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3(256), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
     GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel(256)");
     return GDR_OK;
@@ -1279,7 +1314,8 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
       g.ksplit = gm_env > 0 ? gm_env : (g.tiles_n >= 12 ? 8 : 1);
     }
     if (sk && streamk_wanted(tiles, K / BK) && streamk_fits(M, lda, N, ldw)) {
-      const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch};
+      if (int rc_ = streamk_poll_error()) return rc_;
+      const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch, streamk_err_word()};
       hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3((unsigned)SLOTS), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
       GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel");
       return GDR_OK;
@@ -1326,7 +1362,8 @@ int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t l
   const int64_t tiles_live = prof_rows >= 0 ? ((prof_rows + BM - 1) / BM) * g.tiles_n : tiles;
   if (sk && tiles > 256 && streamk_mid_wanted(tiles_live) && streamk_fits(M_max, lda, N, ldw)) {
     g.ksplit = g.tiles_n >= 12 ? 8 : 1;
-    const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch};
+    if (int rc_ = streamk_poll_error()) return rc_;
+      const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch, streamk_err_word()};
     hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3(256), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
     GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel(256, dev rows)");
     return GDR_OK;
@@ -1334,7 +1371,8 @@ int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t l
   if (tiles > 512) {
     g.ksplit = g.tiles_n >= 12 ? 8 : 1;  // supertile height, as in launch_linear_f32_ws
     if (sk && streamk_wanted(tiles_live, K / BK) && streamk_fits(M_max, lda, N, ldw)) {
-      const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch};
+      if (int rc_ = streamk_poll_error()) return rc_;
+      const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch, streamk_err_word()};
       hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3(512), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
       GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel(dev rows)");
       return GDR_OK;

@@ -297,6 +297,19 @@ int launch_rmsnorm_bf16_dev(const float* x, const float* w, void* y_bf16, const 
   return GDR_OK;
 }
 
+// y = x / max(||x||_2, eps) per row: torch.nn.functional.normalize(rep, dim=-1) of DensePooler (dense.py:24-25)
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows,
+                                                           int d, float eps) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + row * d;
+  float ss = 0.f;
+  for (int c = lane; c < d; c += 64) ss += xr[c] * xr[c];
+  const float nrm = fmaxf(sqrtf(wave_sum(ss)), eps);
+  for (int c = lane; c < d; c += 64) y[row * d + c] = xr[c] / nrm;
+}
+
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y,
                                                         int64_t rows, int d4, float eps,
@@ -1137,5 +1150,15 @@ extern "C" int gdr_t5_relative_bucket_table(int bidirectional, int num_buckets, 
       }
       out_host[i * klen + j] = bucket + lut.v[n < 127 ? n : 127];
     }
+  return GDR_OK;
+}
+
+extern "C" int gdr_l2_normalize(const float* x, float* y, int64_t rows, int d, float eps, void* stream_) {
+  using namespace gdr;
+  GDR_CHECK_ARG(x && y && rows >= 0 && d > 0, "l2_normalize: bad arguments");
+  if (rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream_), x, y,
+                     rows, d, eps);
+  GDR_CHECK_LAUNCH("l2_normalize_kernel");
   return GDR_OK;
 }

@@ -20,6 +20,13 @@ Overflow contract (gdr_hip.h, gdr_sim_topk): with exact=True (default) the local
 exhaustively before the exchange (one status read-back per step), so every status is 0; with exact=False nothing
 synchronises and the merged status tells the caller which rows are the top-k of a subset.
 
+GDR mode (two-stage retrieval, BASELINE config C5; the arithmetic of main_models.py:1434-1462,1574-1637) shards the same
+way — whole clusters per rank, so a cluster never straddles ranks: `rerank_own` all-gathers every rank's queries with their
+decoded candidate lists (ONE fixed-size buffer), each rank scores the candidates whose doc ids fall in its [lo, hi) and
+keeps a per-(query, alpha) top-k of {score, candidate position}, ONE all-to-all hands every rank the per-shard lists of its
+own queries, and the merge by "higher score, then lower position" equals the unsharded rerank bit for bit (a candidate's
+score does not depend on the shard that computed it).
+
 The compute callables default to the HIP ops; tests inject CPU stand-ins to exercise the collective logic
 under gloo (there is no CPU compute path in the product).
 """
@@ -51,9 +58,11 @@ class _Pending:
 
 
 class ShardedIndex:
-    def __init__(self, D_shard, lo, group=None, local_topk=None, pack=None, merge_packed=None, exact=True):
+    def __init__(self, D_shard, lo, group=None, local_topk=None, pack=None, merge_packed=None, exact=True, local_rerank=None):
         """local_topk(Q, D, k, idx_offset) -> (values [B,k], ids int32 [B,k], status int32 [B]);
-        pack(values, ids, status) -> int64 [B,k+1];  merge_packed(pairs [G,B,k+1]) -> (values, ids, status)."""
+        pack(values, ids, status) -> int64 [B,k+1];  merge_packed(pairs [G,B,k+1]) -> (values, ids, status);
+        local_rerank(q, D, cand_offsets [B,R+1], cand_ids [B,stride], beam_scores, alphas, k, lo, hi, func, positions)
+        -> (values [B,A,k], int32 [B,A,k]) — ops.rerank_topk in the per-query block layout."""
         self.D, self.lo, self.group = D_shard, int(lo), group
         if local_topk is None or pack is None or merge_packed is None:
             from . import ops
@@ -62,7 +71,12 @@ class ShardedIndex:
                 Q, D, k, idx_offset=off, workspace=ws, return_status=True, exact_on_overflow=exact))
             pack = pack or ops.topk_pack
             merge_packed = merge_packed or (lambda pairs: ops.topk_merge_packed(pairs, return_status=True))
-        self.local_topk, self.pack, self.merge_packed = local_topk, pack, merge_packed
+        if local_rerank is None:
+            from . import ops as _ops
+            local_rerank = (lambda q, D, offs, ids, beam, alphas, k, lo, hi, func, positions: _ops.rerank_topk(
+                q, D, offs, ids, beam, alphas, k, func=func, max_cand=ids.shape[1], doc_range=(lo, hi), positions=positions,
+                cand_stride=ids.shape[1]))
+        self.local_topk, self.pack, self.merge_packed, self.local_rerank = local_topk, pack, merge_packed, local_rerank
         self.distributed = dist.is_initialized()      # a 1-rank group still runs the collectives (exercises RCCL)
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
@@ -133,3 +147,36 @@ class ShardedIndex:
                 t.record_stream(side)
             out = self._exchange_own(v, i, st, B, k)
         return _Pending(out, side)
+
+    # ------------------------------------------------------------------ GDR mode: sharded in-cluster rerank
+    def rerank_own(self, q_local, cand_offsets, cand_ids, beam_scores, alphas, k, func="tanh"):
+        """Stage 2 of GDR over the row-sharded corpus for THIS rank's queries.
+        q_local fp32 [Bl,d]; cand_offsets int32 [Bl,R+1] / cand_ids int32 [Bl,stride]: the per-query block layout
+        (ops.DeviceClusterIndex.candidates — the same stride on every rank: num_beams x largest cluster); beam_scores fp32
+        [Bl,R].  Returns (values fp32 [Bl,A,k], doc ids int32 [Bl,A,k]) — bit-identical to the unsharded
+        ops.rerank_topk over the whole corpus.  Collectives: ONE all-gather (queries + candidate lists, fixed size), ONE
+        all-to-all (per-shard {score, position} lists of B*A rows in the wire form of the brute-force search)."""
+        Bl, d = q_local.shape
+        R, stride, hi = beam_scores.shape[1], cand_ids.shape[1], self.lo + self.D.shape[0]
+        A = len(alphas)
+        if not self.distributed:
+            return self.local_rerank(q_local, self.D, cand_offsets, cand_ids, beam_scores, alphas, k, self.lo, hi, func, False)
+        i32 = torch.int32
+        mine = torch.cat([q_local.contiguous().view(i32).view(Bl, d), beam_scores.contiguous().view(i32).view(Bl, R),
+                          cand_offsets.to(i32).view(Bl, R + 1), cand_ids.to(i32).view(Bl, stride)], dim=1).contiguous()
+        W = mine.shape[1]
+        allb = torch.empty((self.world * Bl, W), dtype=i32, device=mine.device)
+        dist.all_gather_into_tensor(allb, mine, group=self.group)
+        B = self.world * Bl
+        q_all = allb[:, :d].contiguous().view(torch.float32)
+        beam_all = allb[:, d:d + R].contiguous().view(torch.float32)
+        offs_all = allb[:, d + R:d + 2 * R + 1].contiguous()
+        ids_all = allb[:, d + 2 * R + 1:].contiguous()
+        v, pos = self.local_rerank(q_all, self.D, offs_all, ids_all, beam_all, alphas, k, self.lo, hi, func, True)
+        send = self.pack(v.reshape(B * A, k), pos.reshape(B * A, k), None)          # [B*A, k+1]; block g = rank g's queries
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        mv, mp, _st = self.merge_packed(recv.view(self.world, Bl * A, k + 1))
+        mp = mp.view(Bl, A * k).long()
+        ids = torch.where(mp >= 0, cand_ids.view(Bl, stride).long().gather(1, mp.clamp(min=0)), mp)
+        return mv.view(Bl, A, k), ids.view(Bl, A, k).to(i32)

@@ -220,7 +220,7 @@ class DensePooler:
         else:
             raise ValueError
         if self.normalize:
-            rep = torch.nn.functional.normalize(rep, dim=-1)
+            rep = ops.l2_normalize(rep)
         return rep
 
 
@@ -270,8 +270,8 @@ class GDRRetriever:
     per cluster -> top-k, for every alpha in score_rate."""
 
     def __init__(self, model: GDRModel, doc_embed, cluster_index: codec.ClusterIndex, args, doc_tower=None,
-                 doc_tokens=None):
-        """doc_embed: fp32 [N, d] resident on the GPU (the reference's `self.doc_embed`).
+                 doc_tokens=None, device_candidates=True):
+        """doc_embed: fp32 (or, in the C5 precision mode, bf16) [N, d] resident on the GPU (the reference's `self.doc_embed`).
         doc_tower + doc_tokens=(input_ids int64[N,Lp], attention_mask) enable the stage-2 re-encode path of
         main_models.py:1445-1455 (`epoch > train_encoder_epoch`): candidate docs are embedded on the fly by the
         BERT/DPR tower instead of being looked up (tokenisation itself is out of scope: tokens come pre-computed)."""
@@ -279,6 +279,9 @@ class GDRRetriever:
         self.doc_embed = doc_embed
         self.encoder = doc_tower if doc_tower is not None else EncoderModel()
         self.doc_tokens = doc_tokens
+        # device_candidates: decoded rows -> clusters -> candidate CSR on the GPU (gdr_cluster_candidates); False keeps the
+        # host form (decode_token strings + ClusterIndex.candidates) — same lists, one D2H / H2D round trip more per step
+        self.device_candidates = bool(device_candidates)
 
     def _reencode(self, cand_ids, chunk=1024):
         """Embeds the candidate docs with the doc tower (main_models.py:1445-1455).  cand_ids int32 [total] on device."""
@@ -340,29 +343,65 @@ class GDRRetriever:
             t.record_stream(torch.cuda.current_stream(t.device))
         return {"batch": batch, "enc_h": enc_h, "ids": ids, "lens": lens, "scores": scores}
 
+    def _device_index(self):
+        """The cluster index on the GPU (ops.DeviceClusterIndex), built on first use; None when the id scheme has no
+        separator (--kary 0): the host lookup below then serves, as in round 2."""
+        if not hasattr(self, "_dci"):
+            a = self.args
+            self._dci = None
+            if getattr(a, "kary", 30) and self.device_candidates:
+                self._dci = ops.DeviceClusterIndex(self.index, self.model.device, getattr(a, "output_vocab_size", a.kary),
+                                                   position=getattr(a, "position", 1), kary=a.kary)
+        return self._dci
+
     def _step_finish(self, state, reencode=False):
         a = self.args
         R = a.num_return_sequences
         batch = state["batch"]
-        outs, scores = ops.finish_generate_output(state["ids"], state["lens"], state["scores"], a.max_output_length)
-        dec = codec.dec_2d(codec.decode_token(a, outs.cpu().numpy()), R)
         query_embeds = self.encoder(query_enc=state["enc_h"]).contiguous()      # CLS rows (main_models.py:1466)
-        offs, ids, max_cand = self.index.candidates(dec)
-        B = len(dec)
-        beam_scores = torch.tensor(scores, dtype=torch.float32, device=query_embeds.device).view(B, R)
-        dev_ids = ids.to(query_embeds.device)
+        B = query_embeds.shape[0]
+        alphas, func = list(a.score_rate), getattr(a, "loss_func", "tanh")
+        dci = self._device_index()
+        stride = 0
+        if dci is not None:
+            # decode_token -> id_mapping -> candidate lists -> rerank, all enqueued before anything is read back
+            # (main_models.py:1398,1441-1443,1574-1637): the host only formats strings afterwards
+            _cl, offs, dev_ids, stride = dci.candidates(state["ids"], B, R)
+            max_cand = stride
+            beam_scores = state["scores"].to(torch.float32).view(B, R)          # fp64 -> fp32 as torch.tensor(list) rounds
+        outs = scores = None
+        if dci is None:
+            outs, scores = ops.finish_generate_output(state["ids"], state["lens"], state["scores"], a.max_output_length)
+            dec = codec.dec_2d(codec.decode_token(a, outs.cpu().numpy()), R)
+            offs, ids, max_cand = self.index.candidates(dec)
+            offs = offs.to(query_embeds.device)
+            beam_scores = torch.tensor(scores, dtype=torch.float32, device=query_embeds.device).view(B, R)
+            dev_ids = ids.to(query_embeds.device)
         if reencode:
             if self.doc_tokens is None or getattr(self.encoder, "bert", None) is None:
                 raise _ffi.GdrError("re-encode needs doc_tower= and doc_tokens=")
-            cand_embeds = self._reencode(dev_ids)                                   # [total, d], candidate order
-            local = torch.arange(dev_ids.numel(), dtype=torch.int32, device=dev_ids.device)
-            vals, pos = ops.rerank_topk(query_embeds, cand_embeds, offs.to(query_embeds.device), local, beam_scores,
-                                        list(a.score_rate), R, func=getattr(a, "loss_func", "tanh"), max_cand=max_cand)
-            idx = torch.where(pos >= 0, dev_ids[pos.clamp(min=0).long()], pos)      # candidate position -> doc id
+            if stride:                                   # block layout: the live ids of every query, query-major
+                cnt = offs[:, R].long()
+                live_mask = torch.arange(stride, device=cnt.device)[None, :] < cnt[:, None]
+                live = dev_ids[live_mask]
+                start = torch.cumsum(cnt, 0) - cnt
+                local = (start[:, None] + torch.arange(stride, device=cnt.device)[None, :]).to(torch.int32)
+            else:
+                live = dev_ids[:max(int(offs[-1].item()), 1)]
+                local = torch.arange(live.numel(), dtype=torch.int32, device=dev_ids.device)
+            if live.numel() == 0:
+                live = dev_ids.reshape(-1)[:1]
+            cand_embeds = self._reencode(live)                                      # [total, d], candidate order
+            vals, pos = ops.rerank_topk(query_embeds, cand_embeds, offs, local, beam_scores, alphas, R, func=func,
+                                        max_cand=max_cand, cand_stride=stride)
+            idx = torch.where(pos >= 0, live[pos.clamp(min=0).long()], pos)         # candidate position -> doc id
         else:
-            vals, idx = ops.rerank_topk(query_embeds, self.doc_embed, offs.to(query_embeds.device), dev_ids,
-                                        beam_scores, list(a.score_rate), R, func=getattr(a, "loss_func", "tanh"),
-                                        max_cand=max_cand)
+            vals, idx = ops.rerank_topk(query_embeds, self.doc_embed, offs, dev_ids, beam_scores, alphas, R, func=func,
+                                        max_cand=max_cand, cand_stride=stride)
+        if outs is None:                                                            # first read-back of the step
+            outs, scores = ops.finish_generate_output(state["ids"], state["lens"], state["scores"], a.max_output_length)
+        if dci is not None:
+            dec = codec.dec_2d(codec.decode_token(a, outs.cpu().numpy()), R)
         idx_h = idx.cpu().tolist()
         doc_ids = [[[str(x) for x in idx_h[b][ai]] for ai in range(len(a.score_rate))] for b in range(B)]
         inf_result, inf_index = [], []

@@ -62,6 +62,16 @@ def linear_bf16(a, w, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None
     return out.view(*a.shape[:-1], N)
 
 
+def l2_normalize(x, eps=1e-12):
+    """x / max(||x||_2, eps) over the last dim — gdr_l2_normalize (torch.nn.functional.normalize, dense.py:24-25)."""
+    _need_cuda(x)
+    x = _f32c(x)
+    out = torch.empty_like(x)
+    d = x.shape[-1]
+    check(lib().gdr_l2_normalize(ptr(x), ptr(out), x.numel() // d, d, float(eps), stream_ptr()), "gdr_l2_normalize")
+    return out
+
+
 class Workspace:
     """Grow-only device scratch (256-byte aligned by the caching allocator), one buffer per HIP stream: calls that are in
     flight on different streams (GDRRetriever.validation_steps, two generate() calls) never share scratch."""
@@ -164,22 +174,102 @@ def topk_merge_packed(pairs, return_status=False):
     return (ov, oi, st) if return_status else (ov, oi)
 
 
-def rerank_topk(q, D, cand_offsets, cand_ids, beam_scores, alphas, k, func="tanh", max_cand=None):
-    """In-cluster rerank — gdr_rerank_topk.  Returns (values fp32[B,A,k], doc ids int32[B,A,k])."""
+_RERANK_WS = {}
+
+
+def rerank_topk(q, D, cand_offsets, cand_ids, beam_scores, alphas, k, func="tanh", max_cand=None, doc_range=None,
+                positions=False, workspace=None, cand_stride=0):
+    """In-cluster rerank — gdr_rerank_topk / gdr_rerank_topk_bf16 (chosen by D.dtype; a bf16 corpus is gathered as bf16,
+    never up-cast).  Returns (values fp32[B,A,k], doc ids int32[B,A,k]).
+    cand_stride=0: cand_offsets int32[B*R+1] is ONE CSR into cand_ids (the reference's concatenation order);
+    cand_stride>0: per-query blocks — cand_offsets int32[B,R+1] relative, cand_ids int32[B,cand_stride] (DeviceClusterIndex).
+    max_cand: bound of any query's candidate count; None reads it from the CSR (one host sync).
+    doc_range=(lo, hi): D holds rows [lo, hi) of the corpus, candidates outside are skipped (sharded GDR mode, dist.py);
+    positions=True returns candidate positions within the query's list instead of doc ids (what the shard merge needs)."""
     _need_cuda(q, D, cand_offsets, cand_ids, beam_scores)
-    q, D, beam_scores = _f32c(q), _f32c(D), _f32c(beam_scores)
+    q, beam_scores = _f32c(q), _f32c(beam_scores)
+    if D.dtype == torch.bfloat16:
+        fn, D = lib().gdr_rerank_topk_bf16, D.contiguous()
+    else:
+        fn, D = lib().gdr_rerank_topk, _f32c(D)
+    if D.dim() != 2 or D.shape[1] != q.shape[1]:
+        raise _ffi.GdrError(f"rerank_topk: dim mismatch {tuple(q.shape)} vs {tuple(D.shape)}")
     B, R = beam_scores.shape
     al = torch.as_tensor(alphas, dtype=torch.float32, device=q.device)
     A = al.numel()
     if max_cand is None:
-        o = cand_offsets.view(-1)[::R]
-        max_cand = int((o[1:] - o[:-1]).max().item())
+        if cand_stride:
+            max_cand = int(cand_offsets.view(B, R + 1)[:, R].max().item())
+        else:
+            o = cand_offsets.view(-1)[::R]
+            max_cand = int((o[1:] - o[:-1]).max().item())
+    max_cand = max(int(max_cand), 1)
+    if cand_stride and cand_stride < max_cand:
+        raise _ffi.GdrError(f"rerank_topk: cand_stride {cand_stride} < max_cand {max_cand}")
+    lo, hi = (0, D.shape[0]) if doc_range is None else (int(doc_range[0]), int(doc_range[1]))
+    if hi - lo != D.shape[0]:
+        raise _ffi.GdrError(f"rerank_topk: doc_range {(lo, hi)} does not match the {D.shape[0]} rows given")
+    ws = (workspace or _RERANK_WS.setdefault(q.device, Workspace(q.device))).get(lib().gdr_rerank_workspace_bytes(B, max_cand))
     ov = torch.empty((B, A, k), dtype=torch.float32, device=q.device)
     oi = torch.empty((B, A, k), dtype=torch.int32, device=q.device)
-    check(lib().gdr_rerank_topk(ptr(q), ptr(D), q.shape[1], ptr(cand_offsets), ptr(cand_ids), ptr(beam_scores), B, R,
-                                ptr(al), A, k, 0 if func == "tanh" else 1, ptr(ov), ptr(oi), max(int(max_cand), 1),
-                                stream_ptr()), "gdr_rerank_topk")
+    check(fn(ptr(q), ptr(D), q.shape[1], ptr(cand_offsets), ptr(cand_ids), ptr(beam_scores), B, R, ptr(al), A, k,
+             0 if func == "tanh" else 1, ptr(ov), ptr(oi), max_cand, int(cand_stride), lo, hi,
+             _ffi.RERANK_POSITIONS if positions else 0,
+             ptr(ws), ws.numel(), stream_ptr()), "gdr_rerank_topk")
     return ov, oi
+
+
+class DeviceClusterIndex:
+    """codec.ClusterIndex resident on the GPU (include/gdr_hip.h GdrClusterIndex): the clusters' token bodies in an
+    exact-match hash table + the member CSR, so that gdr_cluster_candidates turns generate()'s output rows into the rerank's
+    candidate CSR without a host round trip (main_models.py:1398,1441-1443)."""
+
+    def __init__(self, index, device, V, position=1, kary=30):
+        import numpy as np
+        bodies = index.token_bodies(V, position=position, kary=kary)       # list of int lists, None = unreachable name
+        n = len(index.names)
+        key_len = max([len(b) for b in bodies if b is not None] + [1])
+        keys = np.full((max(n, 1), key_len), -1, np.int32)
+        lens = np.full(max(n, 1), -1, np.int32)
+        T = 4
+        while T < 2 * max(n, 1):
+            T <<= 1
+        slots = np.full(T, -1, np.int32)
+        hfn = lib().gdr_cluster_key_hash
+        where = {}
+        for c, b in enumerate(bodies):
+            if b is None:
+                continue
+            where[tuple(b)] = c                                            # a repeated name: the last one wins, like the dict
+        for b, c in where.items():
+            keys[c, :len(b)] = b
+            lens[c] = len(b)
+            arr = (C.c_int32 * max(len(b), 1))(*b)
+            slot = int(hfn(arr, len(b))) & (T - 1)
+            while slots[slot] >= 0:
+                slot = (slot + 1) & (T - 1)
+            slots[slot] = c
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)   # noqa: E731
+        self.slots, self.keys, self.lens = dev(slots), dev(keys), dev(lens)
+        self.offsets, self.members = dev(index.offsets.astype(np.int32)), dev(index.members.astype(np.int32) if index.members.size
+                                                                             else np.zeros(1, np.int32))
+        self.max_cluster = int(np.diff(index.offsets).max()) if n else 0
+        self.struct = _ffi.GdrClusterIndex(n, key_len, T, self.slots.data_ptr(), self.keys.data_ptr(), self.lens.data_ptr(),
+                                           self.offsets.data_ptr(), self.members.data_ptr())
+
+    def candidates(self, out_ids, B, R):
+        """out_ids int64[B*R, max_length] (device, untrimmed) -> (cluster_of int32[B*R], cand_offsets int32[B,R+1],
+        cand_ids int32[B,stride], stride = R * largest cluster) — the per-query block layout of rerank_topk
+        (cand_stride=stride, max_cand=stride); all on the device, nothing synchronises."""
+        _need_cuda(out_ids)
+        out_ids = out_ids.contiguous()
+        stride = max(R * self.max_cluster, 1)
+        cl = torch.empty((B * R,), dtype=torch.int32, device=out_ids.device)
+        offs = torch.empty((B, R + 1), dtype=torch.int32, device=out_ids.device)
+        ids = torch.empty((B, stride), dtype=torch.int32, device=out_ids.device)
+        check(lib().gdr_cluster_candidates(C.byref(self.struct), ptr(out_ids), B, R, out_ids.shape[1], ptr(cl), ptr(offs),
+                                           ptr(ids), stride, stream_ptr()), "gdr_cluster_candidates")
+        return cl, offs, ids, stride
 
 
 def relative_bucket_table(bidirectional, num_buckets, max_distance, qlen, klen):

@@ -34,7 +34,7 @@ extern "C" {
 #define GDR_OK 0
 #define GDR_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
 #define GDR_ENOSPC (-2)   /* workspace too small */
-#define GDR_EHIP (-3)     /* HIP runtime error at launch */
+#define GDR_EHIP (-3)     /* HIP runtime error at launch, or a device-side failure of an EARLIER launch (see stream-K below) */
 
 const char* gdr_last_error(void);
 int gdr_abi_version(void);
@@ -72,7 +72,12 @@ int gdr_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, flo
  * order (deterministic) by a second kernel that applies the epilogue.  workspace may be NULL (= gdr_linear_f32).
  * A workspace of at least 33 558 528 bytes (512 x 64 KiB + 4 KiB) also serves grids of more than 256 tiles: the last
  * tiles of a launch are then dealt by K-step ranges with an exact accumulator hand-off between workgroups (bit-identical
- * to whole tiles, DESIGN.md §4 "stream-K tail") instead of leaving CUs idle in a partial last round of tiles. */
+ * to whole tiles, DESIGN.md §4 "stream-K tail") instead of leaving CUs idle in a partial last round of tiles.
+ * Co-residency: that form launches at most 512 workgroups (2 per CU) and a workgroup waits for its predecessor's
+ * accumulators, so all of them must become resident while the launch runs — true on an otherwise idle or normally shared
+ * GPU.  If another kernel keeps a predecessor off the chip for seconds, the waiting workgroup stops waiting, the launch
+ * finishes with INVALID output, and the next linear launched through this library returns GDR_EHIP once (no trap, no hang);
+ * the same holds for the encoder / decode entry points, which use this form internally. */
 int gdr_linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
                           int64_t M, int N, int K, int epilogue, const float* bias, const float* residual,
                           int64_t ldr, void* workspace, size_t workspace_bytes, void* stream);
@@ -82,6 +87,10 @@ int gdr_linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t l
  * ldw multiples of 8.  K % 64 == 0 takes the LDS-DMA kernel (gemm_bf16.hip), other K the generic core. */
 int gdr_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                     int K, int epilogue, const float* bias, const float* residual, int64_t ldr, void* stream);
+
+/* y[r] = x[r] / max(||x[r]||_2, eps) — `torch.nn.functional.normalize(rep, dim=-1)` of DensePooler (dense.py:24-25;
+ * torch's eps is 1e-12).  x, y fp32 [rows, d]; y may alias x. */
+int gdr_l2_normalize(const float* x, float* y, int64_t rows, int d, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * T5 encoder forward — replaces `model.get_encoder()(input_ids, attention_mask=, return_dict=True)
@@ -203,16 +212,61 @@ int gdr_topk_merge_packed(const void* pairs, int G, int B, int k, float* out_val
 
 /* ------------------------------------------------------------------------------------------------
  * In-cluster rerank — replaces main_models.py:1574-1637, block-diagonal only.
- *   q fp32[B,d]; D fp32[N,d]; cand_offsets int32[B*R+1] CSR over the decoded clusters (query-major,
- *   beam order) into cand_ids int32[...]; beam_scores fp32[B,R] (length-penalised);
+ *   q fp32[B,d]; D fp32[N,d]; beam_scores fp32[B,R] (length-penalised); candidate lists in one of two layouts:
+ *     cand_stride == 0: cand_offsets int32[B*R+1], ONE CSR over the decoded clusters (query-major, beam order) into
+ *                       cand_ids int32[...] — the reference's concatenation (main_models.py:1441-1443);
+ *     cand_stride  > 0: a block per query — cand_offsets int32[B][R+1] relative to the block ([b][0] = 0), cand_ids
+ *                       int32[B][cand_stride]: what gdr_cluster_candidates emits and what ranks exchange (fixed size);
  *   alphas fp32[A]; out_val fp32[B,A,k], out_idx int32[B,A,k] (doc ids; -1 / -inf padding when a
  *   query has fewer than k candidates — the reference raises there).  func: 0 tanh, 1 sigmoid.
- *   max_cand: upper bound of any query's candidate count (host knows it from the CSR; <= 8192) — sizes
- *   the LDS sort buffer; candidates past it are ignored.
+ *   max_cand: upper bound of any query's candidate count (num beams x largest cluster; <= 8192) — sizes the score
+ *   scratch and the LDS sort buffer; candidates past it are ignored.  The CSR may live on the device only
+ *   (gdr_cluster_candidates below): nothing here needs its contents on the host.
+ *   Row-sharded corpus (GDR mode): D points to rows [doc_lo, doc_hi) of the corpus; candidates outside
+ *   the range are skipped.  Unsharded: doc_lo = 0, doc_hi = N.  With GDR_RERANK_POSITIONS out_idx holds the candidate's
+ *   POSITION in its query's list (0-based) instead of the doc id: merging the per-shard lists by "higher score, then
+ *   lower position" (gdr_topk_merge_packed over B*A rows) reproduces the unsharded list bit for bit, because a
+ *   candidate's score does not depend on which shard computed it.
+ *   workspace: gdr_rerank_workspace_bytes(B, max_cand).
  * ---------------------------------------------------------------------------------------------- */
+#define GDR_RERANK_POSITIONS 1
+size_t gdr_rerank_workspace_bytes(int B, int max_cand);
 int gdr_rerank_topk(const float* q, const float* D, int d, const int32_t* cand_offsets, const int32_t* cand_ids,
                     const float* beam_scores, int B, int R, const float* alphas, int A, int k, int func,
-                    float* out_val, int32_t* out_idx, int max_cand, void* stream);
+                    float* out_val, int32_t* out_idx, int max_cand, int cand_stride, int32_t doc_lo, int32_t doc_hi,
+                    int flags, void* workspace, size_t workspace_bytes, void* stream);
+/* The same over a bf16 corpus (BASELINE config C5: 1M x 768 bf16): rows are gathered as bf16 and widened (exact), the dot
+ * product is the same fp32 fmaf chain against the fp32 query, same keys, same order — i.e. gdr_rerank_topk applied to the
+ * bf16-rounded corpus.  The corpus is never up-cast as a whole. */
+int gdr_rerank_topk_bf16(const float* q, const void* D_bf16, int d, const int32_t* cand_offsets, const int32_t* cand_ids,
+                         const float* beam_scores, int B, int R, const float* alphas, int A, int k, int func,
+                         float* out_val, int32_t* out_idx, int max_cand, int cand_stride, int32_t doc_lo, int32_t doc_hi,
+                         int flags, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Decoded docid rows -> clusters -> candidate CSR on the device — replaces `decode_token` + the `id_mapping` dict lookup +
+ * the candidate concatenation of main_models.py:1398,1441-1443 (the reference walks Python strings per beam).
+ * decode_token (main_models.py:322-346) drops START, cuts at the first EOS and prints token - (i*V + 2) per position; a row
+ * WITHOUT EOS is printed whole, START included.  That string is a one-to-one image of the token body, so
+ * `id_mapping[string]` is an exact-match lookup of the body: `keys[c]` holds cluster c's body tokens (the tokens whose
+ * decode is the cluster's name), `slots` an open-addressing table (linear probing) over gdr_cluster_key_hash(body).
+ * A body that matches no cluster gives an empty segment, as the reference's KeyError path does.
+ *   out_ids int64[B*R, max_length] = gdr_t5_generate's out_ids (untrimmed);
+ *   cluster_of int32[B*R] (out: cluster index or -1); cand_offsets int32[B][R+1] and cand_ids int32[B][cand_stride] (out):
+ *   the per-query block layout of gdr_rerank_topk — members in cluster order, beams in order = the reference's
+ *   concatenation order within a query; entries past cand_stride are dropped (size it num_beams * largest cluster). */
+typedef struct {
+  int32_t n_clusters;
+  int32_t key_len;          /* ints per stored body (>= the longest body) */
+  int32_t table_size;       /* power of two > n_clusters */
+  const int32_t* slots;     /* device int32 [table_size]: cluster index or -1 */
+  const int32_t* keys;      /* device int32 [n_clusters, key_len] */
+  const int32_t* key_lens;  /* device int32 [n_clusters] */
+  const int32_t* offsets;   /* device int32 [n_clusters + 1]  CSR of the member doc ids */
+  const int32_t* members;   /* device int32 [N] */
+} GdrClusterIndex;
+uint64_t gdr_cluster_key_hash(const int32_t* tokens_host, int len);   /* host routine, the hash the device lookup uses */
+int gdr_cluster_candidates(const GdrClusterIndex* ci, const int64_t* out_ids, int B, int R, int max_length,
+                           int32_t* cluster_of, int32_t* cand_offsets, int32_t* cand_ids, int cand_stride, void* stream);
 
 /* T5 relative-position buckets (transformers/modeling_t5.py:242-288) for relative_position =
  * key_pos - query_pos, written to a HOST int32[qlen*klen] table; the attention kernels use the same

@@ -60,12 +60,13 @@ def base_weights():
     return cfg, synth.make_state_dict(cfg, seed=1234)
 
 
-@pytest.mark.parametrize("R,n_q,bs,constrain", [(10, 8, 4, 0), (10, 8, 4, 1), (100, 2, 1, 0)])
+@pytest.mark.parametrize("R,n_q,bs,constrain", [(10, 8, 4, 0), (10, 8, 4, 1), (100, 2, 1, 0), (100, 2, 1, 1)])
 def test_main_eval_entry_point_vs_oracle_composition(tmp_path, base_weights, R, n_q, bs, constrain):
     """The entry point the reference names (main.py --mode eval with infer.sh's flags) on a reduced synthetic corpus
     (30 000 docs): stage-1 rows of the res1 TSV == oracle beam decode + decode_token, and with the trie constraint
-    (valid cluster ids -> real candidates) the doc-level rows for every alpha == the oracle rerank.  Rows may permute
-    only inside tolerance-tie groups of the oracle's scores."""
+    (valid cluster ids -> real candidates) the doc-level rows for every alpha == the oracle rerank — also at infer.sh's own
+    beam width (BEAM = 100, infer.sh:10-15: 1 200 candidates per query, topk(100), main_models.py:1625).  Rows may
+    permute only inside tolerance-tie groups of the oracle's scores."""
     from oracle import beam_ref, codec_ref, retrieval_ref
     cfg, sd = base_weights
     N = 30000
@@ -213,7 +214,7 @@ def test_c4_shape_4096_queries_8_shards_packed_merge(dev):
 
 def test_c3_full_size_two_stage_vs_oracle(dev, base_weights):
     """Config C3 at full size: 320 000 docs, a batch of 64 queries, beam 10, t5-base: validation_step_i (decode ->
-    id_mapping -> in-cluster rerank) vs the oracle composition on two of the queries.  Random weights decode
+    id_mapping -> in-cluster rerank) vs the oracle composition on eight of the queries.  Random weights decode
     full-length rows that name no cluster, so every decoded string is given a real 12-doc cluster of the corpus."""
     from gdr_amd import codec
     from gdr_amd.modeling import GDRModel, GDRRetriever
@@ -240,7 +241,7 @@ def test_c3_full_size_two_stage_vs_oracle(dev, base_weights):
     index = codec.ClusterIndex(renamed, offsets, members)
     out = GDRRetriever(model, D, index, args).validation_step_i(batch)
     assert out["clusters"] == first["clusters"]
-    nq = 2
+    nq = 8
     (rd, rs), enc_x = beam_ref.generate(sd, cfg, torch.from_numpy(ids[:nq]), torch.from_numpy(mask[:nq]), R,
                                         max_length=10, restricted_head=True)
     dec = codec_ref.dec_2d(codec_ref.decode_token(rd.numpy(), output_vocab_size=30, kary=30), R)
@@ -248,17 +249,26 @@ def test_c3_full_size_two_stage_vs_oracle(dev, base_weights):
     look = {n: i for i, n in enumerate(renamed)}
     for q in range(nq):
         ranked_lists_match(dec[q], rs2[q], out["clusters"][q], TOL)
-    np.testing.assert_allclose(np.array(out["inf_result_batch_prob"]).reshape(B, R)[:nq], rs2, rtol=1e-4, atol=1e-4)
-    if [out["clusters"][q] for q in range(nq)] != dec:
-        pytest.skip("beam order differs inside a tolerance tie: the rerank candidates are laid out differently")
-    mem_q = [[m for s in row for m in members[offsets[look[s]]:offsets[look[s] + 1]].tolist()] for row in dec]
-    num_q = [[12] * R for _ in dec]
-    ref = retrieval_ref.rerank(enc_x[::R][:, 0], torch.from_numpy(Dn), mem_q, num_q, rs2.astype(np.float32).tolist(),
-                               args.score_rate, R)
+    got_scores = np.array(out["inf_result_batch_prob"]).reshape(B, R)[:nq]
+    np.testing.assert_allclose(got_scores, rs2, rtol=1e-4, atol=1e-4)
+    # Stage 2 on every one of the nq queries.  Where the product's beam order equals the oracle's, the oracle rerank runs on
+    # the oracle's own stage-1 output (end to end).  Where two beams swapped inside a tolerance tie (stage 1 above allows
+    # exactly that), the candidates are laid out in the product's order with the product's beam scores — already held to the
+    # oracle's within 1e-4 — so that stage 2 is still compared value by value and id by id, never skipped.
+    end_to_end = 0
     for q in range(nq):
+        same = out["clusters"][q] == dec[q]
+        end_to_end += int(same)
+        order = dec[q] if same else out["clusters"][q]
+        bs = (rs2[q] if same else got_scores[q]).astype(np.float32)
+        mem = [m for s_ in order for m in (members[offsets[look[s_]]:offsets[look[s_] + 1]].tolist() if s_ in look else [])]
+        num = [12 if s_ in look else 0 for s_ in order]
+        ref = retrieval_ref.rerank(enc_x[q * R:q * R + 1][:, 0], torch.from_numpy(Dn), [mem], [num], [bs.tolist()],
+                                   args.score_rate, R)[0]
         for a in range(len(args.score_rate)):
-            ranked_lists_match([str(x) for x in ref[q][a][1].tolist()], ref[q][a][0].numpy(), out["doc_ids"][q][a], TOL)
-            np.testing.assert_allclose(out["rerank_values"][q, a].cpu().numpy(), ref[q][a][0].numpy(), rtol=1e-4, atol=1e-4)
+            ranked_lists_match([str(x) for x in ref[a][1].tolist()], ref[a][0].numpy(), out["doc_ids"][q][a], TOL)
+            np.testing.assert_allclose(out["rerank_values"][q, a].cpu().numpy(), ref[a][0].numpy(), rtol=1e-4, atol=1e-4)
+    assert end_to_end >= nq - 2, end_to_end                    # swapped near-ties are the exception
 
 
 def _lightning_ckpt(t5_sd, bert_sd):

@@ -23,7 +23,7 @@ def test_header_symbols_all_bound_and_exported():
     l = _ffi.lib()                      # raises if the .so is missing or lacks a symbol
     for name in declared:
         assert hasattr(l, name)
-    assert l.gdr_abi_version() == 2
+    assert l.gdr_abi_version() == _ffi.ABI_VERSION == 3
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -244,6 +244,123 @@ def test_sharded_search_gloo(tmp_path, world):
     assert all(r[:5] == [1, 1, 1, 1, 1] for r in rows), rows
     sizes = [r[5] for r in rows]
     assert sum(sizes) == 5003 and len(set(sizes)) > 1, sizes           # the shards really were uneven
+
+
+def _cpu_rerank(q, D, offs, ids, beam, alphas, k, lo, hi, func, positions):
+    """CPU stand-in of ops.rerank_topk in the per-query block layout (test infrastructure: the collective logic of
+    dist.ShardedIndex.rerank_own is what runs as product code).  A candidate's score is computed from its own row alone
+    (float64 dot, rounded once), so it cannot depend on the shard — the property the HIP kernel has by construction."""
+    import numpy as np
+    import torch
+    qn, Dn, on, idn, bn = q.numpy(), D.numpy(), offs.numpy(), ids.numpy(), beam.numpy()
+    B, R = bn.shape
+    A = len(alphas)
+    vals = np.full((B, A, k), -np.inf, np.float32)
+    out = np.full((B, A, k), -1, np.int32)
+    for b in range(B):
+        p = torch.softmax(torch.from_numpy(bn[b]), dim=-1).numpy()
+        cand = []
+        for j in range(R):
+            for c in range(on[b, j], on[b, j + 1]):
+                doc = int(idn[b, c])
+                if lo <= doc < hi:
+                    x = np.float32((qn[b].astype(np.float64) * Dn[doc - lo].astype(np.float64)).sum())
+                    cand.append((c, j, np.float32(np.tanh(x)) if func == "tanh" else np.float32(1 / (1 + np.exp(-x)))))
+        for ai, al in enumerate(alphas):
+            scored = sorted(((np.float32(s + np.float32(np.float32(al) * p[j])), c) for c, j, s in cand), key=lambda t: (-t[0], t[1]))
+            for r, (sc, c) in enumerate(scored[:k]):
+                vals[b, ai, r] = sc
+                out[b, ai, r] = c if positions else idn[b, c]
+    return torch.from_numpy(vals), torch.from_numpy(out)
+
+
+def _gloo_rerank_worker(rank, world, port, tmp):
+    import os
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gdr_amd import synth
+        from gdr_amd.dist import ShardedIndex, shard_bounds
+        N, d, R, Bl, k, csz = 5003, 32, 4, 3, 14, 12           # 417 clusters of 12 (the last one short): uneven shards
+        stride = R * csz
+        D = synth.make_corpus(N, d, seed=4)
+        B = Bl * world
+        Q, _ = synth.make_queries(D, B, seed=5)
+        Q *= 0.2
+        rng = np.random.Generator(np.random.PCG64(77))         # the same draw on every rank
+        n_cl = (N + csz - 1) // csz
+        offs = np.zeros((B, R + 1), np.int32)
+        ids = np.full((B, stride), -7, np.int32)               # garbage past a query's list must never be read
+        for b in range(B):
+            pos = 0
+            for j in range(R):
+                if b == 1:
+                    cl = j                                     # every candidate of this query lives on rank 0
+                elif b == 2 and j > 0:
+                    cl = -1                                    # three empty segments: fewer than k candidates over all
+                elif (b + j) % 5 == 0:
+                    cl = -1
+                else:
+                    cl = int(rng.integers(0, n_cl))
+                if cl >= 0:
+                    mem = np.arange(cl * csz, min((cl + 1) * csz, N), dtype=np.int32)
+                    ids[b, pos:pos + mem.size] = mem
+                    pos += mem.size
+                offs[b, j + 1] = pos
+        beam = rng.standard_normal((B, R)).astype(np.float32)
+        alphas = [0, 0.5, 1, 3]
+        lo, hi = shard_bounds(N, world, rank, cluster_size=csz)
+
+        def pack(v, i, st):
+            Bq, kk = v.shape
+            pairs = np.zeros((Bq, kk + 1, 2), dtype=np.int32)
+            pairs[:, :kk, 0] = v.numpy().view(np.int32)
+            pairs[:, :kk, 1] = i.numpy()
+            return torch.from_numpy(pairs.view(np.int64).reshape(Bq, kk + 1))
+
+        def merge_packed(pairs):
+            G, Bq, k1 = pairs.shape
+            kk = k1 - 1
+            raw = pairs.numpy().view(np.int32).reshape(G, Bq, k1, 2)
+            v = np.ascontiguousarray(raw[:, :, :kk, 0]).view(np.float32).transpose(1, 0, 2).reshape(Bq, G * kk)
+            i = raw[:, :, :kk, 1].transpose(1, 0, 2).reshape(Bq, G * kk)
+            big = np.where(i < 0, np.iinfo(np.int32).max, i)                # padding entries (-inf, -1) sort last
+            key = np.lexsort((big, -v), axis=1)[:, :kk]                     # higher score, then lower position
+            return (torch.from_numpy(np.take_along_axis(v, key, 1)), torch.from_numpy(np.take_along_axis(i, key, 1)),
+                    torch.zeros(Bq, dtype=torch.int32))
+
+        index = ShardedIndex(torch.from_numpy(D[lo:hi]), lo, local_topk=lambda *a: None, pack=pack, merge_packed=merge_packed,
+                             local_rerank=_cpu_rerank)
+        blk = slice(rank * Bl, (rank + 1) * Bl)
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a))          # noqa: E731
+        v, i = index.rerank_own(T(Q[blk]), T(offs[blk]), T(ids[blk]), T(beam[blk]), alphas, k)
+        rv, ri = _cpu_rerank(T(Q[blk]), T(D), T(offs[blk]), T(ids[blk]), T(beam[blk]), alphas, k, 0, N, "tanh", False)
+        short = int((ri[2 - rank * Bl] < 0).any()) if rank == 0 else 1     # query 2 has fewer than k candidates
+        np.save(os.path.join(tmp, f"rr{rank}.npy"), np.array([int(torch.equal(v, rv)), int(torch.equal(i, ri)), short, hi - lo,
+                                                              int((ri >= 0).sum())]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_gdr_rerank_gloo(tmp_path, world):
+    """GDR mode of gdr_amd/dist.py (SURVEY §8e second half; main_models.py:1434-1462,1574-1637 sharded) on CPU/gloo with
+    uneven, cluster-aligned shards: ONE all-gather of queries + candidate blocks, per-shard {score, position} lists, ONE
+    all-to-all, merge — bit-identical to the unsharded rerank on every rank, including a query whose candidates all live
+    on one rank, empty segments and a query with fewer than k candidates."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gloo_rerank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rows = [np.load(tmp_path / f"rr{r}.npy").tolist() for r in range(world)]
+    assert all(r[:3] == [1, 1, 1] for r in rows), rows
+    assert len({r[3] for r in rows}) > 1 and all(r[4] > 0 for r in rows), rows
 
 
 def test_trie_flattening_matches_reference_treebuilder_semantics():
