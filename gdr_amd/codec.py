@@ -296,10 +296,12 @@ def cal_MAP(q_pred, q_gt, k):
     return total / len(q_pred)
 
 
-def _group_rows(rows, gt_as_list):
+def _group_rows(rows, gt_as_list, strict=True):
     """The q_pred / q_gt dictionaries validation_epoch_end builds from consecutive rows (main_models.py:1697-1728).
     Cluster rows keep the first row's gt LIST and `.add` on a repeat (an AttributeError in the reference, reached only
-    when a query text repeats); doc rows append."""
+    when a query text repeats); doc rows append.  strict=False (what the entry point passes): a repeated query text
+    appends its gt instead of raising — a deliberate deviation so that an eval run over real data, where texts can repeat,
+    still ends with metrics after all the GPU work is done."""
     q_gt, q_pred, prev = {}, {}, ""
     for row in rows:
         query, pred, gt = row[0], row[1], row[2]
@@ -308,7 +310,7 @@ def _group_rows(rows, gt_as_list):
             prev = query
         if query in q_gt:
             if len(q_gt[query]) <= 100:
-                if gt_as_list:
+                if gt_as_list or not strict:
                     q_gt[query].append(gt)
                 else:
                     q_gt[query].add(gt)          # the reference calls set.add on a list here (main_models.py:1708)
@@ -317,7 +319,7 @@ def _group_rows(rows, gt_as_list):
     return q_pred, q_gt
 
 
-def validation_epoch_end(outputs, args, verbose=False):
+def validation_epoch_end(outputs, args, verbose=False, strict=True):
     """The metric block of T5FineTuner.validation_epoch_end (main_models.py:1643-1908) for multiple_decoder=0.
     outputs: list of validation_step_i results {"inf_result_batch": [[query, pred_csv, gt, rank], ...],
     "inf_result_batch_prob": [...], "inf_index_batch": [batch][alpha] -> [[query, pred_csv, gt]]}.
@@ -329,7 +331,7 @@ def validation_epoch_end(outputs, args, verbose=False):
         appendix = args.score_rate[index]
         rows = [item for sub in outputs for item in sub["inf_result_batch"]]
         rows = sorted((r for r in rows), key=lambda r: (r[0], r[3]))         # sort_values(by=['query','rank'])
-        q_pred, q_gt = _group_rows([r for r in rows if r[3] == 1], gt_as_list=False)
+        q_pred, q_gt = _group_rows([r for r in rows if r[3] == 1], gt_as_list=False, strict=strict)
         ks = (1, 5, 10, 20, 50, 100)
         if args.is_train_encoder:
             index_rows = [item for sub in outputs for b in range(args.eval_batch_size)

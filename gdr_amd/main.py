@@ -215,12 +215,12 @@ def inference(args):
             by_size.setdefault(len(out["inf_index_batch"]), []).append(out)
         if len(by_size) == 1:
             eargs.eval_batch_size = next(iter(by_size))
-            logged = codec.validation_epoch_end(outputs, eargs)
+            logged = codec.validation_epoch_end(outputs, eargs, strict=False)
         else:                                                    # re-batch to size 1 so that one pass covers all rows
             flat = [{"inf_result_batch": [o["inf_result_batch"][b]], "inf_result_batch_prob": [],
                      "inf_index_batch": [o["inf_index_batch"][b]]} for o in outputs for b in range(len(o["inf_index_batch"]))]
             eargs.eval_batch_size = 1
-            logged = codec.validation_epoch_end(flat, eargs)
+            logged = codec.validation_epoch_end(flat, eargs, strict=False)
         print("stage 2 (in-cluster rerank) doc-level metrics per alpha:")
         for al in args.score_rate:
             print("  alpha=%g  recall@1 %.4f  recall@10 %.4f  recall@100 %.4f  MRR100 %.4f" % (

@@ -600,11 +600,27 @@ class PrefixTable:
     `trie` is a codec.Trie in any order; `.device_trie` is its breadth-first DeviceTrie — pass THAT one as the constraint
     trie when both are used (gdr_t5_generate checks that they share their arrays)."""
 
-    def __init__(self, dec, trie, device, max_levels=None):
+    def __init__(self, dec, trie, device, max_levels=None, max_bytes=None):
+        """max_levels: cap on the trie depth stored.  max_bytes: HBM budget of the table (default: half of what is free on
+        the device now) — the table costs n_table * (adaptor_layers*3*d + (V+1)*d) * 4 bytes (~130 KB per node at t5-base),
+        so the deepest levels are dropped until it fits (rows whose prefix is deeper simply take the computed path);
+        a table that does not even hold the root level raises."""
         import numpy as np
         bfs, level_off, parent, tok = trie.breadth_first()
         cfg = dec.cfg
         n_levels = min(len(level_off) - 1, cfg.max_output_length - 1, max_levels or (1 << 30))
+        per_node = (cfg.adaptor_layer_num * 3 * cfg.d_model + (cfg.output_vocab_size + 1) * cfg.d_model) * 4
+        if max_bytes is None:
+            max_bytes = torch.cuda.mem_get_info(device)[0] // 2
+        full = n_levels
+        while n_levels > 1 and int(level_off[n_levels]) * per_node > max_bytes:
+            n_levels -= 1
+        if int(level_off[n_levels]) * per_node > max_bytes:
+            raise _ffi.GdrError(f"PrefixTable: even {int(level_off[n_levels])} nodes need more than the {max_bytes >> 20} MiB budget")
+        if n_levels < full:
+            print(f"[gdr_amd] prefix table: {int(level_off[full])} trie nodes would need "
+                  f"{int(level_off[full]) * per_node / 2**30:.1f} GiB; keeping the first {n_levels} of {full} levels "
+                  f"({int(level_off[n_levels])} nodes, {int(level_off[n_levels]) * per_node / 2**30:.2f} GiB) — deeper prefixes are computed")
         n_table = int(level_off[n_levels])
         self.device_trie = DeviceTrie(bfs, device)
         anc_blocks, anc = [], np.zeros((1, 1), np.int32)                 # level 0: the root's ancestor list is itself

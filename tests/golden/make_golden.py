@@ -181,6 +181,7 @@ def g_sim_topk():
         S = dense.DenseModel.compute_similarity(None, torch.from_numpy(Q), torch.from_numpy(D))
         v, i = S.topk(10, dim=1, largest=True, sorted=True)
         # DensePooler contract (dense.py:18-27) on a few hidden states
+        torch.manual_seed(20240905)                              # nn.Linear's init draws from the global generator
         pool = dense.DensePooler(48, 32, normalize=True)
         g = torch.Generator().manual_seed(5)
         hid = torch.randn(3, 4, 48, generator=g)

@@ -7,7 +7,8 @@
     fixtures made by running the reference classes (g13, g3);
   * config C2 — all 512 query rows of the 320 000 x 768 top-100 against the oracle;
   * config C4 — 4096 queries x 8 shards of 40 000 rows: packed exchange form + merge == single-shard search, rows vs oracle;
-  * config C3 at full size — 320 000 docs, 64 queries, beam 10, t5-base two-stage retrieval, two queries vs the oracle;
+  * config C3 at full size — 320 000 docs, 64 queries, beam 10, t5-base two-stage retrieval, eight queries vs the oracle;
+  * config C5 composed — 1M x 768 bf16 corpus, beam 30, bf16 mode through encoder, decode and rerank, B = 64;
   * a Lightning-style checkpoint dict ({"state_dict": {"model.…", "encoder.model.…"}}, main.py:121-126) through
     GDRModel / EncoderModel.from_state_dict and through `--infer_ckpt`.
 """
@@ -269,6 +270,84 @@ def test_c3_full_size_two_stage_vs_oracle(dev, base_weights):
             ranked_lists_match([str(x) for x in ref[a][1].tolist()], ref[a][0].numpy(), out["doc_ids"][q][a], TOL)
             np.testing.assert_allclose(out["rerank_values"][q, a].cpu().numpy(), ref[a][0].numpy(), rtol=1e-4, atol=1e-4)
     assert end_to_end >= nq - 2, end_to_end                    # swapped near-ties are the exception
+
+
+def test_c5_composed_bf16_two_stage_on_1m_corpus(dev, base_weights):
+    """BASELINE config C5 composed on one GPU: a 1 000 000 x 768 bf16 corpus (83 334 clusters of 12), a batch of 64 queries,
+    beam 30, the bf16 precision mode end to end — encoder (bf16 linears) -> generate() (bf16, prefix table, trie-constrained
+    so that every decoded id names a cluster) -> device cluster lookup -> in-cluster rerank over the bf16 corpus
+    (gdr_rerank_topk_bf16; main_models.py:1574-1637).  The reference has no bf16 mode, so parity is stated per stage
+    against the oracle applied to the same bf16-rounded operands:
+      stage 1 (3 of the 64 queries): the oracle's emulation of the decode path's rounding points on the GPU's own encoder
+              states; scores within 3e-2; ids compared rank by rank with the tolerance-tie rule — an id may differ from the
+              emulation only inside a group of hypotheses whose scores are closer than the bf16 noise; the count of ids
+              that differ OUTSIDE such groups is asserted to be 0 (conftest.ranked_lists_match raises on the first one);
+      stage 2 (all 64 queries): the oracle rerank on the bf16-rounded corpus rows and the GPU's stage-1 output: values
+              to 1e-4, ids exact outside fp32 tolerance ties."""
+    from gdr_amd import codec, ops
+    from gdr_amd.modeling import GDRModel, GDRRetriever
+    from oracle import beam_ref, codec_ref, retrieval_ref, t5_ref
+    cfg, sd = base_weights
+    N, B, R, V = 1000000, 64, 30, 30
+    names, depth, offsets, members = synth.make_cluster_ids(N, cluster_size=12, V=V)
+    assert depth == 4 and len(names) == 83334
+    Dn = synth.make_corpus(N, cfg.d_model)
+    D16 = ops.to_bf16(torch.from_numpy(Dn).to(dev))
+    del Dn
+    torch.cuda.empty_cache()
+    ids, mask = synth.make_tokens(B, L=40, seed=23)
+    batch = {"source_ids": torch.from_numpy(ids).to(dev), "source_mask": torch.from_numpy(mask).to(dev)}
+    args = types.SimpleNamespace(num_return_sequences=R, output_vocab_size=V, max_output_length=10, length_penalty=0.8,
+                                 kary=V, position=1, score_rate=[0, 0.5, 1, 1.5, 2, 2.5, 3], loss_func="tanh")
+    trie = codec.Trie.from_docids(names, V)
+    model = GDRModel(cfg, sd, dev, trie=trie, prefix_trie=trie, dtype=torch.bfloat16, ragged=True)
+    assert model.prefix_table.n_levels == 5
+    retr = GDRRetriever(model, D16, codec.ClusterIndex(names, offsets, members), args)
+    state = retr._step_launch(batch)
+    out = retr._step_finish(state)
+    look = {n: i for i, n in enumerate(names)}
+    assert all(s in look for row in out["clusters"] for s in row), "constrained beams decode real clusters only"
+    got_scores = np.array(out["inf_result_batch_prob"], np.float64).reshape(B, R)
+    # ---- stage 1 vs the oracle's bf16 emulation, on the GPU's own encoder states
+    nq = 3
+    enc_cpu = state["enc_h"][:nq].cpu()
+    idx = torch.arange(nq).view(-1, 1).repeat(1, R).view(-1)
+    enc_x, mask_x = enc_cpu.index_select(0, idx), torch.from_numpy(mask[:nq]).index_select(0, idx)
+    tree = beam_ref.build_trie([codec_ref.encode_single_newid(s, kary=V) for s in names])
+
+    def step(seq):
+        with t5_ref.bf16_linears():
+            return t5_ref.decode_logits(sd, cfg, seq, enc_x, mask_x, restricted=True)
+
+    rd, rs = beam_ref.beam_search(step, nq, R, cfg.decode_vocab_size, 10, 0.8, R, decode_tree=tree)
+    dec = codec_ref.dec_2d(codec_ref.decode_token(rd.numpy(), output_vocab_size=V, kary=V), R)
+    rs2 = np.array(rs, np.float64).reshape(nq, R)
+    np.testing.assert_allclose(got_scores[:nq], rs2, rtol=3e-2, atol=3e-2)
+    BF16_TOL = 1.5e-2                                          # hypothesis-score noise of two correct bf16 decodes
+    permuted = shared = 0
+    for q in range(nq):
+        permuted += ranked_lists_match(dec[q], rs2[q], out["clusters"][q], BF16_TOL)   # raises on an id differing outside a tie group
+        shared += len(set(dec[q]) & set(out["clusters"][q]))
+    assert shared >= 0.7 * nq * R, (shared, permuted)
+    print(f"C5 stage 1: {shared}/{nq * R} ids shared with the emulation, {permuted} slots permuted inside tolerance-tie groups, "
+          "0 ids differ outside them")
+    # ---- stage 2 on all 64 queries: oracle rerank on the bf16-rounded rows the GPU gathered
+    q_emb = state["enc_h"][:, 0].cpu()
+    cand = [[m for s_ in row for m in range(int(offsets[look[s_]]), int(offsets[look[s_] + 1]))] for row in out["clusters"]]
+    flat = torch.tensor(sorted({m for c in cand for m in c}), dtype=torch.long)
+    rows16 = D16[flat.to(dev)].float().cpu()                   # only the candidate rows leave the GPU
+    remap = {int(m): j for j, m in enumerate(flat.tolist())}
+    differing = 0
+    for b in range(B):
+        mem_local = [remap[m] for m in cand[b]]
+        ref = retrieval_ref.rerank(q_emb[b:b + 1], rows16, [mem_local], [[12] * R], [got_scores[b].astype(np.float32).tolist()],
+                                   args.score_rate, R)[0]
+        for a in range(len(args.score_rate)):
+            ref_ids = [str(int(flat[j])) for j in ref[a][1].tolist()]
+            differing += ranked_lists_match(ref_ids, ref[a][0].numpy(), out["doc_ids"][b][a], TOL)
+            np.testing.assert_allclose(out["rerank_values"][b, a].cpu().numpy(), ref[a][0].numpy(), rtol=1e-4, atol=1e-4)
+    assert differing <= 8, differing
+    assert D16.dtype == torch.bfloat16 and D16.shape == (N, cfg.d_model)
 
 
 def _lightning_ckpt(t5_sd, bert_sd):
