@@ -115,7 +115,7 @@ static size_t beam_layout(const BeamDims& bd, char* base, BeamBufs* bb) {
 }
 
 // ------------------------------------------------------------------------------------------ kernels
-__global__ void beam_init_kernel(BeamBufs bb, BeamDims bd) {
+__global__ void beam_init_kernel(BeamBufs bb, BeamDims bd, int dedup0) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int rows = bd.B * bd.R;
   if (r < rows) {
@@ -123,8 +123,9 @@ __global__ void beam_init_kernel(BeamBufs bb, BeamDims bd) {
     bb.beam_scores[r] = (r % bd.R == 0) ? 0.f : -1e9f;  // generation_utils.py:663-668
     bb.cur_tok[r] = START_ID;
     bb.parent[r] = r;
-    bb.anc[0][(size_t)r * bd.maxlen] = r;
-    bb.kv_rows[r] = r;  // step 0: stride 1, position 0
+    // dedup0: step 0 computes ONE row per query (identical beam rows), filed as row b of the position-0 cache slots
+    bb.anc[0][(size_t)r * bd.maxlen] = dedup0 ? r / bd.R : r;
+    bb.kv_rows[r] = r;  // step 0: stride 1, position 0 (dedup0: the first B entries serve the B computed rows)
     bb.node[0][r] = 0;  // trie root
   }
   if (r < bd.B) {
@@ -300,7 +301,7 @@ __global__ void table_logits_kernel(const float* __restrict__ table, const int64
 
 // Per query: log_softmax of every beam's row (masked columns contribute exp(-1e9 - max) = 0 exactly), add the
 // beam score, take the 2R best of the R*(V+1) unmasked candidates, sorted (generation_utils.py:698,766-775).
-__global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims bd, int pos, int npad, int cur,
+__global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims bd, int pos, int npad, int cur, int bcast,
                                                         float* __restrict__ step_scores,
                                                         int32_t* __restrict__ step_tokens) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [npad]
@@ -310,7 +311,8 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims b
   float* lse_log = lse_max + R;                            // [R]
   float* lg_s = lse_log + R;                               // [R*V1] this query's logits, staged once (coalesced)
   const int ncand = R * V1;
-  for (int e = tid; e < ncand; e += nthr) lg_s[e] = bb.logits[(size_t)b * ncand + e];
+  // bcast (step 0 with one computed row per query): logits holds [B][V1], every beam of the query reads row b
+  for (int e = tid; e < ncand; e += nthr) lg_s[e] = bcast ? bb.logits[(size_t)b * V1 + e % V1] : bb.logits[(size_t)b * ncand + e];
   __syncthreads();
   for (int j = wave; j < R; j += nwaves) {
     const float* lg = lg_s + j * V1;
@@ -671,13 +673,13 @@ static int check_beam_dims(const BeamDims& bd, int max_length) {
 
 // One decode step's beam machinery after bb.logits holds the step's unmasked-column logits.
 static int beam_step(const BeamBufs& bb, const BeamDims& bd, int pos, int cur, float* step_scores,
-                     int32_t* step_tokens, hipStream_t stream) {
+                     int32_t* step_tokens, hipStream_t stream, bool bcast = false) {
   const int rows = bd.B * bd.R;
   const int npad = next_pow2i(bd.R * (bd.V + 1));
   const size_t lds = (size_t)npad * 8 + (size_t)bd.R * 8 + (size_t)bd.R * (bd.V + 1) * 4;
   const size_t tr = (size_t)pos * bd.B * 2 * bd.R;
   hipLaunchKernelGGL(beam_topk_kernel, dim3(bd.B), dim3(npad >= 2048 ? 1024 : 256), lds, stream, bb, bd, pos, npad, cur,
-                     step_scores ? step_scores + tr : nullptr, step_tokens ? step_tokens + tr : nullptr);
+                     bcast ? 1 : 0, step_scores ? step_scores + tr : nullptr, step_tokens ? step_tokens + tr : nullptr);
   GDR_CHECK_LAUNCH("beam_topk_kernel");
   const size_t hyp_lds = ((hyp_lds_bytes(bd.R, bd.maxlen) + 15) & ~(size_t)15) + (size_t)bd.R * 4 + (size_t)bd.R * 16;
   hipLaunchKernelGGL(beam_update_kernel, dim3(bd.B), dim3(256), hyp_lds, stream, bb, bd, pos + 1, cur);
@@ -688,10 +690,10 @@ static int beam_step(const BeamBufs& bb, const BeamDims& bd, int pos, int cur, f
   return GDR_OK;
 }
 
-static int beam_begin(const BeamBufs& bb, const BeamDims& bd, hipStream_t stream) {
+static int beam_begin(const BeamBufs& bb, const BeamDims& bd, hipStream_t stream, bool dedup0 = false) {
   const int rows = bd.B * bd.R;
   if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(beam_topk_kernel), 96 * 1024, "beam")) return rc__;
-  hipLaunchKernelGGL(beam_init_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, bb, bd);
+  hipLaunchKernelGGL(beam_init_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, bb, bd, dedup0 ? 1 : 0);
   GDR_CHECK_LAUNCH("beam_init_kernel");
   return GDR_OK;
 }
@@ -933,7 +935,11 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
     if ((rc = (x))) return rc; \
   } while (0)
 
-  GDR_TRY(beam_begin(bb, bd, stream));
+  static const bool dedup0 = [] {
+    const char* e = getenv("GDR_DECODE_DEDUP0");  // exact A/B knob: 0 = run step 0 on all B*R (identical) beam rows
+    return e ? atoi(e) != 0 : true;
+  }();
+  GDR_TRY(beam_begin(bb, bd, stream, dedup0));
   // stream-K hand-off scratch of the two chains' big linears (gemm_f32.hip) inside their split-K regions — a launch uses one
   // or the other; both flag blocks are zeroed here, on the caller's stream, before the adaptor stream is first forked
   StreamK sk1{skw, reinterpret_cast<int32_t*>(base + g.splitk + STREAMK_PART_BYTES), 0};
@@ -960,7 +966,13 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
                                                             lease.ss ? lease.ss->fork : nullptr, lease.ss ? lease.ss->join : nullptr};
   for (int s = 0; s + 1 < max_length; ++s) {  // position s, cur_len = s + 1 (generation_utils.py:676)
     hipStream_t as = ss.ok ? ss.s : stream;   // adaptor stream
-    GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows, d, dm.vocab_size, xd, stream));
+    // Step 0: the R beam rows of a query hold the same START token and the same encoder states, so their decoder /
+    // adaptor / head outputs are identical rows (generation_utils.py:437-442 expands the encoder states, :663-668 starts
+    // every beam but the first at -1e9): one row per query is computed (row b of the step-0 cache slots; every row's
+    // ancestor at position 0 is b, beam_init_kernel) and beam_topk_kernel reads the query's logits for all of its beams.
+    const int rows_s = (s == 0 && dedup0) ? B : rows;
+    const int R_s = (s == 0 && dedup0) ? 1 : num_beams;
+    GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows_s, d, dm.vocab_size, xd, stream));
     if (ss.ok) {
       if (hipEventRecord(ss.fork, stream) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess) {
         set_error("generate: fork to the adaptor stream failed");
@@ -968,28 +980,28 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       }
     }
     if (!ptab) {
-      GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows, d, dm.vocab_size, xa, as));
+      GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows_s, d, dm.vocab_size, xa, as));
     }
     // ---------------- adaptor: post-LN nn.TransformerDecoder over decode_embeddings(ids) (modeling_t5.py:1615-1633)
     auto ad_layer_plain = [&](int l) -> int {
         const GdrAdaptorLayer& al = w->alayers[l];
         float* cache = acache + l * alayer;
         float* slot = cache + s * aslab;
-        GDR_TRY(LIN2(xa, d, al.in_w, d, slot, 3 * d, rows, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0));
+        GDR_TRY(LIN2(xa, d, al.in_w, d, slot, 3 * d, rows_s, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0));
         AttnArgs at{};
         at.q = slot, at.k = cache + d, at.v = cache + 2 * d, at.out = ctx2;
         at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
         at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
-        at.B = rows, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
+        at.B = rows_s, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
         at.scale = 1.0f / sqrtf((float)ahd);
         at.rel_bias = nullptr, at.bidirectional = 0, at.num_buckets = 0, at.lut = lut_uni;
         at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
         at.kv_rows = bb.kv_rows, at.kv_group = 1;
         GDR_TRY(launch_attention(at, as));
         // tmp = norm2(norm1(out_proj(ctx) + xa) + cross_const); xa = norm3(lin2(relu(lin1(tmp))) + tmp)
-        GDR_TRY(LIN2N(ctx2, d, al.out_w, d, tmp, d, rows, nullptr, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d, ln2(al, tmp)));
-        GDR_TRY(LIN2(tmp, d, al.lin1_w, d, ff2, aff, rows, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
-        GDR_TRY(LIN2N(ff2, aff, al.lin2_w, aff, xa, d, rows, nullptr, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d,
+        GDR_TRY(LIN2N(ctx2, d, al.out_w, d, tmp, d, rows_s, nullptr, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d, ln2(al, tmp)));
+        GDR_TRY(LIN2(tmp, d, al.lin1_w, d, ff2, aff, rows_s, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
+        GDR_TRY(LIN2N(ff2, aff, al.lin2_w, aff, xa, d, rows_s, nullptr, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d,
                       ln(al.ln3_w, al.ln3_b, xa)));
         return GDR_OK;
     };
@@ -997,38 +1009,38 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
     if (ptab) {
       // ---------------- prefix-table mode: rows whose prefix is a table node take everything from the table; the rest
       // are compacted (row count *bb.n_miss lives on the device) and run the same chain + the head GEMM on `as`
-      hipLaunchKernelGGL(prefix_plan_kernel, dim3(1), dim3(1024), 0, as, bb, rows, s + 1, cur, ptab->n_table);
+      hipLaunchKernelGGL(prefix_plan_kernel, dim3(1), dim3(1024), 0, as, bb, rows_s, s + 1, cur, ptab->n_table);
       GDR_CHECK_LAUNCH("prefix_plan_kernel");
-      hipLaunchKernelGGL(prefix_fill_kernel, dim3(rows), dim3(256), 0, as, bb, rows, s + 1, cur, ptab->kv,
+      hipLaunchKernelGGL(prefix_fill_kernel, dim3(rows_s), dim3(256), 0, as, bb, rows_s, s + 1, cur, ptab->kv,
                          (int64_t)ptab->n_table * 3 * d, acache + s * aslab, (int64_t)alayer, w->adaptor_layers, 3 * d);
       GDR_CHECK_LAUNCH("prefix_fill_kernel");
-      hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as, w->dec_embed, bb.cur_tok,
+      hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)((rows_s + 3) / 4)), dim3(256), 0, as, w->dec_embed, bb.cur_tok,
                          bb.miss_rows, nm, d / 4, dm.vocab_size, xa);
       GDR_CHECK_LAUNCH("embed_rows_kernel");
     }
 #define LIN2D(A_, lda_, W_, ldw_, C_, ldc_, N_, K_, epi_, bias_, res_, ldr_) \
-  dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, rows, nm, N_, K_, epi_, bias_, res_, ldr_, skw2, as, &sk2)
+  dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, rows_s, nm, N_, K_, epi_, bias_, res_, ldr_, skw2, as, &sk2)
     auto ad_layer_tab = [&](int l) -> int {
         const GdrAdaptorLayer& al = w->alayers[l];
         float* cache = acache + l * alayer;
         float* slot = cache + s * aslab;
         GDR_TRY(LIN2D(xa, d, al.in_w, d, qkv_c, 3 * d, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0));
-        hipLaunchKernelGGL(scatter_slot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as, qkv_c, bb.miss_rows, nm,
+        hipLaunchKernelGGL(scatter_slot_kernel, dim3((unsigned)((rows_s + 3) / 4)), dim3(256), 0, as, qkv_c, bb.miss_rows, nm,
                            3 * d / 4, slot);
         GDR_CHECK_LAUNCH("scatter_slot_kernel");
         AttnArgs at{};
         at.q = qkv_c, at.k = cache + d, at.v = cache + 2 * d, at.out = ctx2;
         at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
         at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
-        at.B = rows, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
+        at.B = rows_s, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
         at.scale = 1.0f / sqrtf((float)ahd);
         at.rel_bias = nullptr, at.bidirectional = 0, at.num_buckets = 0, at.lut = lut_uni;
         at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
         at.kv_rows = bb.kv_rows_c, at.kv_group = 1, at.b_count_dev = nm;
         GDR_TRY(launch_attention(at, as));
-        GDR_TRY(LIN2N(ctx2, d, al.out_w, d, tmp, d, rows, nm, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d, ln2(al, tmp)));
+        GDR_TRY(LIN2N(ctx2, d, al.out_w, d, tmp, d, rows_s, nm, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d, ln2(al, tmp)));
         GDR_TRY(LIN2D(tmp, d, al.lin1_w, d, ff2, aff, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
-        GDR_TRY(LIN2N(ff2, aff, al.lin2_w, aff, xa, d, rows, nm, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d,
+        GDR_TRY(LIN2N(ff2, aff, al.lin2_w, aff, xa, d, rows_s, nm, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d,
                       ln(al.ln3_w, al.ln3_b, xa)));
         return GDR_OK;
     };
@@ -1038,47 +1050,48 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       float* cache = dcache + l * dlayer;
       float* slot = cache + s * dslab;
       // every later RMS norm rides on the reduction of the residual linear in front of it (dec_linear_norm)
-      if (l == 0) GDR_TRY(launch_rmsnorm(xd, ly.ln_self, nx, rows, d, dm.eps, nullptr, 1, stream));
-      GDR_TRY(LIN(nx, d, ly.wqkv, d, slot, 3 * inner, rows, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
+      if (l == 0) GDR_TRY(launch_rmsnorm(xd, ly.ln_self, nx, rows_s, d, dm.eps, nullptr, 1, stream));
+      GDR_TRY(LIN(nx, d, ly.wqkv, d, slot, 3 * inner, rows_s, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
       AttnArgs at{};
       at.q = slot, at.k = cache + inner, at.v = cache + 2 * inner, at.out = ctx;
       at.ldq = at.ldk = at.ldv = 3 * inner, at.ldo = inner;
       at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
-      at.B = rows, at.H = H, at.dk = dk, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s, at.scale = 1.0f;
+      at.B = rows_s, at.H = H, at.dk = dk, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s, at.scale = 1.0f;
       at.rel_bias = w->self_rel_bias, at.bidirectional = 0, at.num_buckets = dm.rel_buckets, at.lut = lut_uni;
       at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 0;
       at.kv_rows = bb.kv_rows, at.kv_group = 1;
       GDR_TRY(launch_attention(at, stream));
-      GDR_TRY(LINN(ctx, inner, ly.wo, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, rms(ly.ln_cross, nx)));
+      GDR_TRY(LINN(ctx, inner, ly.wo, inner, xd, d, rows_s, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, rms(ly.ln_cross, nx)));
       // cross attention over the encoder states of the row's query
-      // the q projection's split-K slabs go to the attention kernel un-reduced (it sums them while it stages the beam rows'
+      // the q projection's split-K slabs go to the attention kernel un-reduced (it sums them while it stages the beam rows_s'
       // queries): one dependent launch less per layer and step
       SlabRef qsl{nullptr, 1, 0};
       bool q_from_slabs = false;
-      if (slab_q_on && !bf16 && ((rows + 127) / 128) * ((inner + 127) / 128) < 192 && rows <= 1536 && d % 32 == 0 && d / 32 >= 4) {
-        const int rc_ = launch_linear_f32_small(nx, d, ly.wq_c, d, qc, inner, rows, inner, d, 0, 0, 0, nullptr, nullptr, 0, skw,
+      if (slab_q_on && !bf16 && R_s > 1 /* the Lq = 1 kernel of the de-duplicated step 0 takes finished q rows */ &&
+          ((rows_s + 127) / 128) * ((inner + 127) / 128) < 192 && rows_s <= 1536 && d % 32 == 0 && d / 32 >= 4) {
+        const int rc_ = launch_linear_f32_small(nx, d, ly.wq_c, d, qc, inner, rows_s, inner, d, 0, 0, 0, nullptr, nullptr, 0, skw,
                                                 SPLITK_WS_BYTES, stream, nullptr, nullptr, &qsl);
         if (rc_ < 0) return rc_;
         q_from_slabs = rc_ == 0;
       }
-      if (!q_from_slabs) GDR_TRY(LIN(nx, d, ly.wq_c, d, qc, inner, rows, inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
+      if (!q_from_slabs) GDR_TRY(LIN(nx, d, ly.wq_c, d, qc, inner, rows_s, inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
       AttnArgs ca{};
       const float* ckv = crosskv + l * ckv_layer;
-      // the R beam rows of a query are consecutive and share its K/V: one workgroup per (query, head) stages K/V
-      // once and serves all R rows (they all sit at decoder position s)
+      // the R beam rows_s of a query are consecutive and share its K/V: one workgroup per (query, head) stages K/V
+      // once and serves all R rows_s (they all sit at decoder position s)
       ca.q = qc, ca.k = ckv, ca.v = ckv + inner, ca.out = ctx;
       ca.ldq = inner, ca.ldk = ca.ldv = 2 * inner, ca.ldo = inner;
-      ca.q_bstride = num_beams, ca.k_bstride = L, ca.o_bstride = num_beams;
-      ca.B = B, ca.H = H, ca.dk = dk, ca.Lq = num_beams, ca.Lk = L, ca.q_pos0 = s, ca.scale = 1.0f, ca.q_same_pos = 1;
+      ca.q_bstride = R_s, ca.k_bstride = L, ca.o_bstride = R_s;
+      ca.B = B, ca.H = H, ca.dk = dk, ca.Lq = R_s, ca.Lk = L, ca.q_pos0 = s, ca.scale = 1.0f, ca.q_same_pos = 1;
       ca.rel_bias = w->cross_rel_bias, ca.bidirectional = 1, ca.num_buckets = dm.rel_buckets, ca.lut = lut_bi;
       ca.key_mask = enc_mask, ca.mask_bstride = L, ca.causal = 0, ca.causal_neg_inf = 0;
       ca.kv_rows = nullptr, ca.kv_group = 1;
       if (q_from_slabs && qsl.S > 1) ca.q_part = qsl.part, ca.q_S = qsl.S, ca.q_tiles_n = qsl.tiles_n;
       GDR_TRY(launch_attention(ca, stream));
-      GDR_TRY(LINN(ctx, inner, ly.wo_c, inner, xd, d, rows, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, rms(ly.ln_ff, nx)));
-      GDR_TRY(LIN(nx, d, ly.wi, d, ff, dm.d_ff, rows, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0));
+      GDR_TRY(LINN(ctx, inner, ly.wo_c, inner, xd, d, rows_s, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, rms(ly.ln_ff, nx)));
+      GDR_TRY(LIN(nx, d, ly.wi, d, ff, dm.d_ff, rows_s, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0));
       const bool last = l + 1 == dm.num_layers;  // the norm behind the block: the next block's first, or final_layer_norm
-      GDR_TRY(LINN(ff, dm.d_ff, ly.wo_ff, dm.d_ff, xd, d, rows, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, xd, d,
+      GDR_TRY(LINN(ff, dm.d_ff, ly.wo_ff, dm.d_ff, xd, d, rows_s, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, xd, d,
                    rms(last ? w->final_ln : w->layers[l + 1].ln_self, last ? hl : nx)));
       return GDR_OK;
     };
@@ -1088,7 +1101,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       if (l < dm.num_layers) GDR_TRY(dec_layer(l));
       if (l < w->adaptor_layers) GDR_TRY(ptab ? ad_layer_tab(l) : ad_layer_plain(l));
     }
-    if (ptab)  // the head GEMM of the compacted rows belongs to the adaptor chain (it needs nothing from the decoder stack)
+    if (ptab)  // the head GEMM of the compacted rows_s belongs to the adaptor chain (it needs nothing from the decoder stack)
       GDR_TRY(LIN2D(xa, d, w_at(w->head_w, (size_t)s * V1 * d * d, bf16), d, A, (int64_t)V1 * d, V1 * d, d, GDR_EPI_NONE, nullptr,
                     nullptr, 0));
 #undef LIN2D
@@ -1106,18 +1119,18 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
     const float* hw = w_at(w->head_w, (size_t)s * V1 * d * d, bf16);
     const float* he = w->head_e + (size_t)s * V1 * d;
     if (!ptab) {
-      GDR_TRY(LIN(xa, d, hw, d, A, (int64_t)V1 * d, rows, V1 * d, d, GDR_EPI_NONE, nullptr, nullptr, 0));
-      const int64_t items = (int64_t)rows * V1;
-      hipLaunchKernelGGL(head_logits_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, hl, A, he, rows, V1, d,
+      GDR_TRY(LIN(xa, d, hw, d, A, (int64_t)V1 * d, rows_s, V1 * d, d, GDR_EPI_NONE, nullptr, nullptr, 0));
+      const int64_t items = (int64_t)rows_s * V1;
+      hipLaunchKernelGGL(head_logits_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, hl, A, he, rows_s, V1, d,
                          1.0f / sqrtf((float)d), bb.logits);
       GDR_CHECK_LAUNCH("head_logits_kernel");
     } else {
-      const int64_t items = (int64_t)rows * V1;
+      const int64_t items = (int64_t)rows_s * V1;
       hipLaunchKernelGGL(head_logits_table_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, hl, A, he, ptab->W,
-                         bb.node[cur], bb.miss_index, ptab->n_table, rows, V1, d, 1.0f / sqrtf((float)d), bb.logits);
+                         bb.node[cur], bb.miss_index, ptab->n_table, rows_s, V1, d, 1.0f / sqrtf((float)d), bb.logits);
       GDR_CHECK_LAUNCH("head_logits_table_kernel");
     }
-    GDR_TRY(beam_step(bb, bd, s, cur, step_scores, step_tokens, stream));
+    GDR_TRY(beam_step(bb, bd, s, cur, step_scores, step_tokens, stream, s == 0 && dedup0));
     cur ^= 1;
   }
   return beam_end(bb, bd, max_length, cur, out_ids, out_len, out_scores, stream);

@@ -47,7 +47,10 @@ def test_decode_scheduling_switches_do_not_change_generate():
     base = _run()
     exact = _run(GDR_DECODE_SLAB_Q="0")
     assert exact == base, "slab-sourced cross-attention q must be bit-identical to the reduction launch"
-    for env in (dict(GDR_DECODE_FUSE_NORM="0"), dict(GDR_REDUCE_NORM_ROW_MAX="0"), dict(GDR_ATTN_DECODE_ROWS="0")):
+    # GDR_DECODE_DEDUP0=0 runs step 0 on all B*R identical beam rows instead of one row per query: the same numbers from
+    # launches of another shape (other split-K factors), i.e. fp32 summation order only
+    for env in (dict(GDR_DECODE_FUSE_NORM="0"), dict(GDR_REDUCE_NORM_ROW_MAX="0"), dict(GDR_ATTN_DECODE_ROWS="0"),
+                dict(GDR_DECODE_DEDUP0="0")):
         other = _run(**env)
         for key in base:
             a, b = base[key], other[key]
