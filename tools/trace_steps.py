@@ -40,3 +40,30 @@ for r in rs:
 print(f"  {'kernel':44s} {'wgs':>6s} {'n':>5s} {'avg us':>8s} {'total us':>9s}  queue")
 for (k, g), (n, t, qs) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"  {k:44s} {g:6d} {n:5d} {t / n / 1e3:8.2f} {t / 1e3:9.1f}  {','.join(sorted(qs))}")
+# ---- per decode step (delimited by beam_topk_kernel): wall span and busy time per queue
+marks = [i for i, r in enumerate(rs) if "beam_topk_kernel" in r["Kernel_Name"]]
+prev = 0
+print("  step   span us   " + "   ".join(f"q{q} busy" for q in sorted(byq)))
+for si, mi in enumerate(marks):
+    seg = rs[prev:mi + 1]
+    a, b = int(seg[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in seg)
+    busy = {q: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg if r["Queue_Id"] == q) for q in sorted(byq)}
+    print(f"  {si:4d} {(b - a) / 1e3:9.1f}   " + "   ".join(f"{busy[q] / 1e3:8.1f}" for q in sorted(byq)))
+    prev = mi + 1
+# ---- optional: kernel table restricted to a step range (argv[3] = "a-b")
+if len(sys.argv) > 3:
+    a_, b_ = [int(x) for x in sys.argv[3].split("-")]
+    lo_i = marks[a_ - 1] + 1 if a_ > 0 else 0
+    hi_i = marks[b_]
+    sub = rs[lo_i:hi_i + 1]
+    tot2 = collections.defaultdict(lambda: [0, 0, set()])
+    for r in sub:
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("gdr::", "")
+        g = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) // max(int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1), 1)
+        key = (k[:44], g)
+        tot2[key][0] += 1
+        tot2[key][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        tot2[key][2].add(r["Queue_Id"])
+    print(f"steps {a_}..{b_}:")
+    for (k, g), (n, t, qs) in sorted(tot2.items(), key=lambda kv: -kv[1][1])[:24]:
+        print(f"  {k:44s} {g:6d} {n:5d} {t / n / 1e3:8.2f} {t / 1e3:9.1f}  {','.join(sorted(qs))}")
