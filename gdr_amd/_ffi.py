@@ -54,7 +54,7 @@ class GdrTrie(C.Structure):
 
 class GdrPrefixTable(C.Structure):
     _fields_ = [("child", C.c_void_p), ("n_nodes", C.c_int32), ("V", C.c_int32), ("n_table", C.c_int32),
-                ("kv", C.c_void_p), ("W", C.c_void_p), ("n_levels", C.c_int32)]
+                ("kv", C.c_void_p), ("W", C.c_void_p)]
 
 
 class GdrClusterIndex(C.Structure):
@@ -88,7 +88,6 @@ SIGNATURES = {
     "gdr_prof_enable": (_i, [_i]),
     "gdr_prof_collect": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gdr_linear_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
-    "gdr_linear_f32_wsk": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _i64, _vp, _i, _vp, _f, _vp, _vp]),
     "gdr_linear_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "gdr_linear_f32_splitk": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "gdr_l2_normalize": (_i, [_vp, _vp, _i64, _i, _f, _vp]),

@@ -113,11 +113,6 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
                             int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev = nullptr,
                             const NormEpilogue* ne = nullptr,  // with ne: returns 2 if the fused form does not apply
                             SlabRef* slabs = nullptr);         // with slabs (no epilogue allowed): the reduction is left to the caller
-// Wave-split-K linear for decode row counts (gemm_wsk.hip): returns 1 when the shape is not served.
-size_t wsk_lds_bytes(int K, int norm_nt);
-int launch_linear_f32_wsk(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N, int K,
-                          int relu, const float* residual, int64_t ldr, const float* norm_part, int norm_nt, const float* norm_w,
-                          float eps, float* out_part, hipStream_t stream);
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, int out_bf16, hipStream_t stream, const int64_t* m_dev = nullptr);

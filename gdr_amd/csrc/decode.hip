@@ -816,7 +816,7 @@ static const float* w_at(const float* W, size_t elems, bool bf16) {
 
 // ------------------------------------------------------------------------------------------ model workspace
 struct GenWs {
-  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, abf, abf2, npart, total;
+  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, abf, abf2, total;
 };
 
 static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
@@ -847,7 +847,6 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
   const size_t abf_main = rows * ffw > (size_t)bd.B * L * d ? rows * ffw : (size_t)bd.B * L * d;
   g.abf = carve(o, 2 * abf_main);                       // bf16 mode: the rounded activation operand of a linear (main stream)
   g.abf2 = carve(o, 2 * rows * ffw);                    //            ... of the adaptor chain (side stream)
-  g.npart = carve(o, 4 * rows * ((d + 63) / 64));       // row sums of squares by 64-column tile (gemm_wsk.hip: the norm rides on the GEMMs)
   g.total = o;
   return g;
 }
@@ -904,7 +903,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
   float *dcache = F(g.dcache), *acache = F(g.acache), *crosskv = F(g.crosskv), *xd = F(g.xd), *xa = F(g.xa),
         *nx = F(g.nx), *ctx = F(g.ctx), *qc = F(g.qc), *ff = F(g.ff), *tmp = F(g.tmp), *A = F(g.A), *hl = F(g.hl),
-        *skw = F(g.splitk), *ctx2 = F(g.ctx2), *ff2 = F(g.ff2), *skw2 = F(g.splitk2), *qkv_c = F(g.qkv_c), *npart = F(g.npart);
+        *skw = F(g.splitk), *ctx2 = F(g.ctx2), *ff2 = F(g.ff2), *skw2 = F(g.splitk2), *qkv_c = F(g.qkv_c);
   void *abf = base + g.abf, *abf2 = base + g.abf2;
   GDR_CHECK_ARG(!bf16 || (dm.d_model % 8 == 0 && dm.d_ff % 8 == 0 && (dm.num_heads * dm.d_kv) % 8 == 0 && w->adaptor_ff % 8 == 0),
                 "generate(bf16): dims must be multiples of 8");
@@ -959,19 +958,6 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
     const char* e = getenv("GDR_DECODE_SLAB_Q");  // A/B knob: 0 = reduce the cross-attention q projection in its own launch
     return e ? atoi(e) != 0 : true;
   }();
-  // The decoder stack's linears on the wave-split-K kernel (gemm_wsk.hip): no slabs, no reduction launches, the RMS norms
-  // folded into producer epilogue + consumer operand.  fp32 only; shapes it does not serve keep the split-K path below.
-  static const bool wsk_on = [] {
-    const char* e = getenv("GDR_DECODE_WSK");  // A/B knob: 0 = the round-2 chain (64x64 split-K tiles + fused reduce / norm launches)
-    return e ? atoi(e) != 0 : true;
-  }();
-  const int ptab_levels = ptab ? (ptab->n_levels > 0 ? ptab->n_levels : max_length) : 0;
-  static const bool wsk_always = [] {
-    const char* e = getenv("GDR_DECODE_WSK");  // 2 = on every step, also beside a busy adaptor chain
-    return e ? atoi(e) == 2 : false;
-  }();
-  const bool use_wsk = wsk_on && !bf16 && d % 128 == 0 && inner % 128 == 0 && dm.d_ff % 128 == 0 &&
-                       (d / 64) % 2 == 0 && wsk_lds_bytes(d, d / 64) <= 160 * 1024;  // = what launch_linear_f32_wsk serves
   const BucketLut lut_uni = make_bucket_lut(dm.rel_buckets, dm.rel_max_distance);
   const BucketLut lut_bi = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
   int cur = 0;
@@ -1109,66 +1095,10 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
                    rms(last ? w->final_ln : w->layers[l + 1].ln_self, last ? hl : nx)));
       return GDR_OK;
     };
-    // The same block on the wave-split-K linears: 8 launches; xd is the residual stream, npart its row sums of squares
-    auto dec_layer_wsk = [&](int l) -> int {
-      const GdrT5DecLayer& ly = w->layers[l];
-      float* cache = dcache + l * dlayer;
-      float* slot = cache + s * dslab;
-      const int nt = d / 64;
-#define WSK(A_, lda_, W_, ldw_, C_, ldc_, N_, K_, relu_, res_, np_, nw_, op_)                                              \
-  do {                                                                                                                     \
-    const int rc_ = launch_linear_f32_wsk(A_, lda_, W_, ldw_, C_, ldc_, rows_s, N_, K_, relu_, res_, d, np_, nt, nw_, dm.eps, op_, \
-                                          stream);                                                                         \
-    if (rc_ < 0) return rc_;                                                                                               \
-    if (rc_ > 0) {                                                                                                         \
-      set_error("generate: the wave-split-K linear refused a shape it was selected for (N=%d K=%d)", N_, K_);            \
-      return GDR_EINVAL;                                                                                                   \
-    }                                                                                                                      \
-  } while (0)
-      if (l == 0) {
-        GDR_TRY(launch_rmsnorm(xd, ly.ln_self, nx, rows_s, d, dm.eps, nullptr, 1, stream));
-        WSK(nx, d, ly.wqkv, d, slot, 3 * inner, 3 * inner, d, 0, nullptr, nullptr, nullptr, nullptr);
-      } else {
-        WSK(xd, d, ly.wqkv, d, slot, 3 * inner, 3 * inner, d, 0, nullptr, npart, ly.ln_self, nullptr);
-      }
-      AttnArgs at{};
-      at.q = slot, at.k = cache + inner, at.v = cache + 2 * inner, at.out = ctx;
-      at.ldq = at.ldk = at.ldv = 3 * inner, at.ldo = inner;
-      at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
-      at.B = rows_s, at.H = H, at.dk = dk, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s, at.scale = 1.0f;
-      at.rel_bias = w->self_rel_bias, at.bidirectional = 0, at.num_buckets = dm.rel_buckets, at.lut = lut_uni;
-      at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 0;
-      at.kv_rows = bb.kv_rows, at.kv_group = 1;
-      GDR_TRY(launch_attention(at, stream));
-      WSK(ctx, inner, ly.wo, inner, xd, d, d, inner, 0, xd, nullptr, nullptr, npart);
-      WSK(xd, d, ly.wq_c, d, qc, inner, inner, d, 0, nullptr, npart, ly.ln_cross, nullptr);
-      AttnArgs ca{};
-      const float* ckv = crosskv + l * ckv_layer;
-      ca.q = qc, ca.k = ckv, ca.v = ckv + inner, ca.out = ctx;
-      ca.ldq = inner, ca.ldk = ca.ldv = 2 * inner, ca.ldo = inner;
-      ca.q_bstride = R_s, ca.k_bstride = L, ca.o_bstride = R_s;
-      ca.B = B, ca.H = H, ca.dk = dk, ca.Lq = R_s, ca.Lk = L, ca.q_pos0 = s, ca.scale = 1.0f, ca.q_same_pos = 1;
-      ca.rel_bias = w->cross_rel_bias, ca.bidirectional = 1, ca.num_buckets = dm.rel_buckets, ca.lut = lut_bi;
-      ca.key_mask = enc_mask, ca.mask_bstride = L, ca.causal = 0, ca.causal_neg_inf = 0;
-      ca.kv_rows = nullptr, ca.kv_group = 1;
-      GDR_TRY(launch_attention(ca, stream));
-      WSK(ctx, inner, ly.wo_c, inner, xd, d, d, inner, 0, xd, nullptr, nullptr, npart);
-      WSK(xd, d, ly.wi, d, ff, dm.d_ff, dm.d_ff, d, 1, nullptr, npart, ly.ln_ff, nullptr);
-      WSK(ff, dm.d_ff, ly.wo_ff, dm.d_ff, xd, d, d, dm.d_ff, 0, xd, nullptr, nullptr, npart);
-      if (l + 1 == dm.num_layers) GDR_TRY(launch_rmsnorm(xd, w->final_ln, hl, rows_s, d, dm.eps, nullptr, 1, stream));
-#undef WSK
-      return GDR_OK;
-    };
-    // Which form of the decoder block this step takes.  Measured (tools/ab_c3.sh, 64 queries x 10 beams): alone on the
-    // chip the wave-split-K block is ~15 % faster (no slabs, no reduce launches); next to a BUSY adaptor chain it is not —
-    // both chains are then bound by the CUs' operand bandwidth, and its 32x64 tiles move 1.5x the bytes of the 64x64
-    // split-K tiles.  So it serves the steps whose adaptor chain has nothing (or little) to compute: with a prefix table, the
-    // positions the table covers (every step, for ids that end inside the trie); without a table, none.
-    const bool wsk_step = use_wsk && (wsk_always || (ptab != nullptr && s < ptab_levels));
     // The two chains are enqueued layer by layer in turn: a host thread that first enqueued the whole adaptor chain left
     // the main stream idle for as long as those ~55 launches take to issue (measured: a fifth of a 100-beam step).
     for (int l = 0; l < dm.num_layers || l < w->adaptor_layers; ++l) {
-      if (l < dm.num_layers) GDR_TRY(wsk_step ? dec_layer_wsk(l) : dec_layer(l));
+      if (l < dm.num_layers) GDR_TRY(dec_layer(l));
       if (l < w->adaptor_layers) GDR_TRY(ptab ? ad_layer_tab(l) : ad_layer_plain(l));
     }
     if (ptab)  // the head GEMM of the compacted rows_s belongs to the adaptor chain (it needs nothing from the decoder stack)

@@ -44,23 +44,6 @@ def linear(a, w, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None, spl
     return out.view(*a.shape[:-1], N)
 
 
-def linear_wsk(a, w, relu=False, residual=None, part_in=None, norm_w=None, eps=1e-6, want_part=False, out=None):
-    """The decode chain's wave-split-K linear alone — gdr_linear_f32_wsk.  part_in [M,nt] + norm_w [K]: T5LayerNorm(a) folded
-    into the A operand; want_part: also return the row sums of squares of the output by 64-column tile [M, N/64]."""
-    _need_cuda(a, w, residual, part_in, norm_w)
-    a2, w = _f32c(a).view(-1, a.shape[-1]), _f32c(w)
-    M, K, N = a2.shape[0], a2.shape[1], w.shape[0]
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    res2 = _f32c(residual).view(-1, N) if residual is not None else None
-    part = torch.empty((M, N // 64), dtype=torch.float32, device=a.device) if want_part else None
-    pin = _f32c(part_in) if part_in is not None else None
-    check(lib().gdr_linear_f32_wsk(ptr(a2), K, ptr(w), w.shape[1], ptr(out), N, M, N, K, int(bool(relu)), ptr(res2), N, ptr(pin),
-                                   pin.shape[1] if pin is not None else 0, ptr(_f32c(norm_w)) if norm_w is not None else None,
-                                   float(eps), ptr(part), stream_ptr()), "gdr_linear_f32_wsk")
-    return (out, part) if want_part else out
-
-
 def linear_bf16(a, w, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None):
     """out[M,N] fp32 = epilogue(a[M,K] @ w[N,K].T) with bf16 operands (fp32 tensors are rounded on the device first) and
     fp32 accumulate — gdr_linear_bf16, the linear of the C5 precision mode."""
@@ -661,7 +644,7 @@ class PrefixTable:
         torch.cuda.current_stream().synchronize()                        # the scratch tensors above may go now
         self.n_levels, self.n_table, self.level_off = n_levels, n_table, level_off
         self.struct = _ffi.GdrPrefixTable(self.device_trie.child.data_ptr(), self.device_trie.child.shape[0], int(bfs.V),
-                                          n_table, self.kv.data_ptr(), self.W.data_ptr(), int(n_levels))
+                                          n_table, self.kv.data_ptr(), self.W.data_ptr())
 
     def struct_ref(self):
         return C.byref(self.struct)

@@ -82,17 +82,6 @@ int gdr_linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t l
                           int64_t M, int N, int K, int epilogue, const float* bias, const float* residual,
                           int64_t ldr, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The decode chain's linear (M = batch x beams rows; csrc/gemm_wsk.hip) on its own, for tests and measurements:
- * C = epilogue(A' W^T) with 32x64 output tiles whose K dimension is split over the four waves of a workgroup (no partial
- * slabs, no reduction launch).  relu: C = max(.,0); residual (may alias C): C = . + residual.
- * part_in [M, part_in_nt] + norm_w [K]: A' = T5LayerNorm(A) (modeling_t5.py:164-171), the row sums of squares given as
- * part_in_nt partial sums per row (added in order); NULL: A' = A.  part_out [M, N/64] (may be NULL) receives the sums of
- * squares of the stored rows by 64-column tile — the part_in of the next linear.  N % 64 == 0, K % 128 == 0, 16-byte
- * aligned rows; GDR_EINVAL otherwise. */
-int gdr_linear_f32_wsk(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N, int K,
-                       int relu, const float* residual, int64_t ldr, const float* part_in, int part_in_nt, const float* norm_w,
-                       float eps, float* part_out, void* stream);
-
 /* bf16 operands (A [M,K], W [N,K] bf16, round-to-nearest-even of the fp32 tensors), fp32 accumulate, epilogue and output:
  * the linear of the opt-in bf16 precision mode (BASELINE config C5; the reference itself runs precision=32).  K, lda,
  * ldw multiples of 8.  K % 64 == 0 takes the LDS-DMA kernel (gemm_bf16.hip), other K the generic core. */
@@ -397,8 +386,6 @@ typedef struct {
   int32_t n_table;        /* nodes with entries: the first n_table nodes (breadth-first order)                       */
   const float* kv;        /* device [adaptor_layers][n_table][3*d]                                                   */
   const float* W;         /* device [n_table][V+1][d]   (adaptor_linear slice + lm_head rows of the node's position) */
-  int32_t n_levels;       /* trie depths the table covers (nodes of depth < n_levels); 0 = unknown.  A scheduling hint only:
-                             decode steps below it expect an idle adaptor chain (gdr_t5_generate picks its kernel forms by it) */
 } GdrPrefixTable;
 
 size_t gdr_t5_prefix_table_workspace_bytes(const GdrT5DecoderWeights* w, int max_level_nodes);
