@@ -75,7 +75,8 @@ int launch_linear_f32(const float* A, int64_t lda, const float* W, int64_t ldw, 
                       hipStream_t stream);
 int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                          int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
-                         float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream, StreamK* sk = nullptr);
+                         float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream, StreamK* sk = nullptr,
+                         const int64_t* m_dev = nullptr, int64_t prof_rows = -1);
 // Decode-time linear over a device-side row count (*m_dev <= M_max live rows; grids sized for M_max): the same kernel
 // choice as launch_linear_f32_ws makes for M_max — small-tile / split-K forms included, so its results for a row equal
 // what launch_linear_f32_ws(M = M_max) gives that row.

@@ -200,11 +200,18 @@ static RagWs rag_ws(const GdrT5Dims& dm, int B, int L, size_t base) {
   r.total = o;
   return r;
 }
-// The packed form needs the d_kv = 64 attention kernel and a 128x128 tile grid that fills the chip without split-K
-// (the narrowest linear has N = d_model): smaller problems run the padded form.
+// The packed form needs the d_kv = 64 attention kernel.  ragged_packs: a 128x128 tile grid that fills the chip without
+// split-K (the narrowest linear has N = d_model) — the un-split forms, with the pooled-only tail on the CLS rows.
+// ragged_packs_small (r03): smaller batches (C3's 64-query encoder pass).  The padded form runs those on the split-K /
+// stream-K forms of launch_linear_f32_ws, chosen from B*L alone; the packed form takes the SAME forms with the live row
+// count on the device, so kept rows are still bit-identical — only the pooled-only tail is not taken (its un-split
+// kernels would sum in another order than the padded form's split ones).
 static bool ragged_packs(const GdrT5Dims& dm, int B, int L) {
   const int64_t tiles = (((int64_t)B * L + 127) / 128) * ((dm.d_model + 127) / 128);
   return dm.d_kv == 64 && tiles >= 192 && dm.d_model % 32 == 0 && dm.d_ff % 32 == 0 && (dm.num_heads * dm.d_kv) % 32 == 0;
+}
+static bool ragged_packs_small(const GdrT5Dims& dm, int B, int L) {
+  return dm.d_kv == 64 && (int64_t)B * L >= 256 && dm.d_model % 32 == 0 && dm.d_ff % 32 == 0 && (dm.num_heads * dm.d_kv) % 32 == 0;
 }
 }  // namespace gdr
 
@@ -241,7 +248,9 @@ static int ragged_impl(const GdrT5EncoderWeights* w, const int64_t* ids, const i
   if ((rc = launch_pack_plan(mask, B, L, seq_len, seq_off, row_src, rows_dev, stream))) return rc;
   // bf16 precision mode: the packed form exists for the fused producer chain only (every contraction a multiple of 64)
   const bool fused16 = bf16 && d % 64 == 0 && inner % 64 == 0 && dm.d_ff % 64 == 0 && (((uintptr_t)w->layers[0].wqkv) & 15) == 0;
-  if (!ragged_packs(dm, B, L) || (bf16 && !fused16)) {
+  const bool big = ragged_packs(dm, B, L);
+  const bool small = !big && !bf16 && ragged_packs_small(dm, B, L);
+  if ((!big && !small) || (bf16 && !fused16)) {
     // small problem / other head size: the padded forward, then the rows that the packed form would not have computed
     // are zeroed so that the output contract does not depend on which form ran
     float* full = out_hidden ? out_hidden : reinterpret_cast<float*>(base + ws.off_qkv);  // qkv is dead when the final norm runs
@@ -333,8 +342,12 @@ static int ragged_impl(const GdrT5EncoderWeights* w, const int64_t* ids, const i
   float* ff_cls = reinterpret_cast<float*>(base + rw.ff_cls);
   StreamK sk{};
   if ((rc = enc_streamk(base + ws.off_splitk, &sk, stream))) return rc;
+  float* skw = reinterpret_cast<float*>(base + ws.off_splitk);
   auto linear = [&](const float* A, int64_t lda, const float* W, float* C, int64_t ldc, int N, int K, int epi,
                     const float* residual) -> int {
+    if (small)  // the forms the padded forward picks for B*L rows (split-K / stream-K), over the live rows only
+      return launch_linear_f32_ws(A, lda, W, K, C, ldc, M, N, K, epi, nullptr, residual, ldc, skw, ENC_SPLITK_BYTES, stream, &sk,
+                                  rows_dev, live_rows_hint);
     return launch_linear_f32_dev(A, lda, W, K, C, ldc, M, rows_dev, N, K, epi, nullptr, residual, ldc, live_rows_hint, stream,
                                  &sk);
   };
@@ -352,7 +365,7 @@ static int ragged_impl(const GdrT5EncoderWeights* w, const int64_t* ids, const i
   at.kv_rows = nullptr, at.kv_group = 1;
   at.seq_off = seq_off, at.seq_len = seq_len;
 
-  const bool pooled_only = out_hidden == nullptr;
+  const bool pooled_only = out_hidden == nullptr && big;
   for (int i = 0; i < dm.num_layers; ++i) {
     const GdrT5EncLayer& ly = w->layers[i];
     GDR_CHECK_ARG(ly.ln_attn && ly.wqkv && ly.wo && ly.ln_ff && ly.wi && ly.wo_ff, "t5_encoder_ragged: layer %d null weight", i);

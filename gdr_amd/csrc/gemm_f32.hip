@@ -1120,7 +1120,12 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, int tile_base,
                                                             int tiles_n, int64_t M, int N, float* __restrict__ C,
                                                             int64_t ldc, const float* __restrict__ bias,
-                                                            const float* __restrict__ residual, int64_t ldr, int act) {
+                                                            const float* __restrict__ residual, int64_t ldr, int act,
+                                                            const int64_t* __restrict__ m_dev) {
+  if (m_dev) {  // device-side row count: the slabs of tiles past it (in whole row panels, as the GEMM rounds it) were never written
+    const int64_t up = (*m_dev + (BM - 1)) / BM * BM;
+    M = up < M ? up : M;
+  }
   const int local_tile = blockIdx.x >> 4;
   const int e = ((blockIdx.x & 15) << 8) + threadIdx.x;  // float4 index inside the tile: 128 rows x 32 float4
   const int r = e >> 5, c = (e & 31) << 2;
@@ -1191,9 +1196,14 @@ int launch_linear_f32_ws_dev(const float* A, int64_t lda, const float* W, int64_
   return launch_linear_f32_dev(A, lda, W, ldw, C, ldc, M_max, m_dev, N, K, epilogue, bias, residual, ldr, -1, stream, sk);
 }
 
+// m_dev (may be null): the live row count on the device, *m_dev <= M.  Every kernel FORM is chosen from M alone, so a row's
+// result does not depend on how many rows are live (the padded and the packed encoder forms agree bit for bit); tiles past
+// the live rows exit at once and the stream-K forms deal only the live tiles' K-steps.  prof_rows: the live count if the
+// host happens to know it — profiler flop accounting only.
 int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                          int N, int K, int epilogue, const float* bias, const float* residual, int64_t ldr,
-                         float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream, StreamK* sk) {
+                         float* splitk_ws, size_t splitk_ws_bytes, hipStream_t stream, StreamK* sk, const int64_t* m_dev,
+                         int64_t prof_rows) {
   if (M == 0) return GDR_OK;  // empty batch: nothing to do (pointers of empty tensors may be null)
   GDR_CHECK_ARG(A && W && C, "linear: null pointer");
   GDR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
@@ -1209,7 +1219,7 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
   GemmArgs g{};
   g.A = A, g.W = W, g.C = C, g.bias = bias, g.residual = residual;
   g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr;
-  g.M = M, g.N = N, g.K = K;
+  g.M = M, g.N = N, g.K = K, g.m_dev = m_dev;
   g.tiles_n = (N + BN - 1) / BN;
   const int64_t tiles_m = (M + BM - 1) / BM;
   g.has_bias = needs_bias, g.has_residual = needs_res;
@@ -1220,7 +1230,7 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
     set_error("linear: unknown epilogue %d", epilogue);
     return GDR_EINVAL;
   }
-  const double flops = 2.0 * (double)M * (double)N * (double)K;  // profiler: attributed per kernel launch, by tile share
+  const double flops = 2.0 * (double)(m_dev && prof_rows >= 0 ? prof_rows : M) * (double)N * (double)K;  // profiler, by tile share
   const int64_t tiles = tiles_m * g.tiles_n;
   const int nk = K / BK;
   constexpr int64_t SLOTS = 512;                      // 256 CUs x 2 resident workgroups
@@ -1240,7 +1250,7 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
     ProfScope prof_r(PROF_REDUCE, 0.0, stream);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(n_tiles * 16)), dim3(256), 0, stream, splitk_ws, S,
                        (int)first_tile, g.tiles_n, M, N, C, ldc, needs_bias ? bias : nullptr,
-                       needs_res ? residual : nullptr, ldr, g.act);
+                       needs_res ? residual : nullptr, ldr, g.act, m_dev);
     GDR_CHECK_LAUNCH("splitk_reduce_kernel");
     return GDR_OK;
   };
@@ -1248,7 +1258,7 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
     // few rows (decode: M = batch*beams): 64x64 tiles (gemm_small.hip), split along K only as far as still needed.
     // With more rows (a 64-query encoder batch) the 128x128 core with split-K measured 5 % faster.
     const int rc = launch_linear_f32_small(A, lda, W, ldw, C, ldc, M, N, K, needs_bias, needs_res, g.act, bias, residual, ldr,
-                                           splitk_ws, splitk_ws_bytes, stream);
+                                           splitk_ws, splitk_ws_bytes, stream, m_dev);
     if (rc <= 0) return rc;
   }
   if (splitk_ws && K % BK == 0 && tiles < 0x7fffffff / 64) {

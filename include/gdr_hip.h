@@ -141,7 +141,9 @@ int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_t* ids, con
  *   - the live-row count is derived from the mask ON THE DEVICE; kernels read it, the call never synchronises.
  *     live_rows_hint: that count if the host happens to know it, else -1 — read only by the opt-in profiler's flop
  *     accounting (gdr_prof_*), never by the computation.
- * Batches too small to fill the chip without split-K, or d_kv != 64, run the padded form internally (same outputs). */
+ * Batches of fewer than 256 token rows, or d_kv != 64, run the padded form internally (same outputs); below 4 096 token
+ * rows the packed form runs on the split-K / stream-K kernel forms the padded forward picks for the same B*L (kept rows
+ * still bit-identical) and the pooled-only shortcut of the last block is not taken. */
 size_t gdr_t5_encoder_ragged_workspace_bytes(const GdrT5Dims* dims, int B, int L);
 int gdr_t5_encoder_forward_ragged(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L,
                                   float* out_hidden, float* out_pooled, int64_t live_rows_hint, void* workspace,

@@ -39,10 +39,11 @@ def _kept(mask):
     return keep
 
 
-@pytest.mark.parametrize("B,L", [(512, 40), (128, 40), (130, 33), (64, 128)])
+@pytest.mark.parametrize("B,L", [(512, 40), (128, 40), (130, 33), (64, 128), (64, 40), (32, 40), (100, 24), (8, 40)])
 def test_ragged_rows_bit_identical_to_padded_form(dev, base_enc, B, L):
-    """C2's batch (512 x 40, lengths 8..40) and other packable shapes: pooled (both ragged call forms) and every kept
-    hidden row equal the padded form bit for bit; dropped rows come back as zeros."""
+    """C2's batch (512 x 40, lengths 8..40), C3's 64-query encoder pass and other packable shapes — above 4 096 token rows
+    on the un-split kernel forms, below on the split-K / stream-K forms the padded forward picks for the same B*L — :
+    pooled (both ragged call forms) and every kept hidden row equal the padded form bit for bit; dropped rows are zeros."""
     cfg, sd, enc = base_enc
     ids, mask = synth.make_tokens(B, L=L, seed=11 + B, min_len=min(8, L))
     it, mt = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
