@@ -33,15 +33,38 @@ def encode_single_newid(a, b=None, **kw):
     return out + [1]
 
 
+_DIGIT_TABLES = {}
+
+
+def _digit_table(width, V, position, hi):
+    """T[i][t] = str(t - (i*V + 2)) (or str(t - 2)): the printed digit of token t at body position i, for t < hi."""
+    key = (width, V, position, hi)
+    T = _DIGIT_TABLES.get(key)
+    if T is None:
+        T = _DIGIT_TABLES[key] = [[str(t - ((i * V + 2) if position else 2)) for t in range(hi)] for i in range(width)]
+    return T
+
+
 def decode_token(a, b=None, **kw):
     """2-D int array of generated ids -> docid strings (main_models.py:322-346): drop START, cut at the first
     EOS, subtract arange*V+2.  A row without EOS is decoded whole, START included, as the reference does."""
     seqs, kary, V, position = _split_args(a, b, **kw)
     if torch.is_tensor(seqs):
         seqs = seqs.cpu().numpy()
-    result = []
+    arr = np.asarray(seqs)
     sep = "-" if kary else ""
-    for lst in np.asarray(seqs).tolist():        # plain Python ints: str() of numpy scalars dominated this loop
+    rows = arr.tolist()                          # plain Python ints: str() of numpy scalars dominated this loop
+    result = []
+    if arr.ndim == 2 and arr.size and int(arr.min()) >= 0 and int(arr.max()) < 4096:
+        # the strings of every (position, token) pair come from a table built once: 3x faster than str() per digit on the
+        # 640 rows of a C3 batch (the host part of validation_step_i)
+        T = _digit_table(arr.shape[1], V, position, int(arr.max()) + 1 if int(arr.max()) >= 512 else 512)
+        getitem = list.__getitem__
+        for lst in rows:
+            body = lst[1:lst.index(1)] if 1 in lst else lst
+            result.append(sep.join(map(getitem, T, body)))
+        return result
+    for lst in rows:
         body = lst[1:lst.index(1)] if 1 in lst else lst
         if position:
             result.append(sep.join([str(t - (i * V + 2)) for i, t in enumerate(body)]))

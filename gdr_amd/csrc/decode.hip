@@ -780,14 +780,8 @@ static int dec_linear_norm(bool bf16, void* abf, const float* A, int64_t lda, co
     return e ? atoi(e) != 0 : true;
   }();
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  // measured (tools/exp_fuse_rows.py): 1 x 100 beams 8.62 -> 8.36 ms, 16 x 10 beams 9.88 -> 9.55, 64 x 10 beams 18.00 -> 17.60
-  // — once the reduction loads four slabs per round trip (with one slab load in flight at a time the fused form LOST 3 % at
-  // 100 rows).  GDR_DECODE_FUSE_MIN_ROWS raises the row count from which it is used (A/B).
-  static const int fuse_min_rows = [] {
-    const char* e = getenv("GDR_DECODE_FUSE_MIN_ROWS");
-    return e ? atoi(e) : 1;
-  }();
-  if (fuse_on && !bf16 && M >= fuse_min_rows && tiles < 192 && M <= 1536 && K % 32 == 0 && K / 32 >= 4 && ldc == N && ne.ldy == N) {
+  // measured in round 2: 1 x 100 beams 8.62 -> 8.36 ms, 16 x 10 beams 9.88 -> 9.55, 64 x 10 beams 18.00 -> 17.60
+  if (fuse_on && !bf16 && tiles < 192 && M <= 1536 && K % 32 == 0 && K / 32 >= 4 && ldc == N && ne.ldy == N) {
     const bool nb = epi == GDR_EPI_BIAS || epi == GDR_EPI_BIAS_RELU || epi == GDR_EPI_BIAS_RESIDUAL;
     const bool nr = epi == GDR_EPI_RESIDUAL || epi == GDR_EPI_BIAS_RESIDUAL;
     const int act = (epi == GDR_EPI_RELU || epi == GDR_EPI_BIAS_RELU) ? 1 : 0;

@@ -1264,46 +1264,14 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
   if (splitk_ws && K % BK == 0 && tiles < 0x7fffffff / 64) {
     if (tiles < 192 && nk >= 4) {
       // (a) the grid cannot fill the chip (decode: M = batch*beams rows): split every tile along K
-      static const int target = [] {
-        const char* e = getenv("GDR_SPLITK_TARGET");  // tuning knob: desired number of blocks per split launch
-        return e ? atoi(e) : 384;
-      }();
+      constexpr int target = 384;  // desired number of workgroups per split launch
       int S = (int)((target + tiles - 1) / tiles);
       if (S > nk / 2) S = nk / 2;
       if ((size_t)S * tiles * tile_bytes > splitk_ws_bytes) S = (int)(splitk_ws_bytes / (tiles * tile_bytes));
       if (S >= 2) return split_launch(0, tiles, S);
-    } else if (tiles > SLOTS && nk >= 8) {
-      // (b) wave quantisation experiment, OFF by default (GDR_TAIL_SPLIT=1 enables): run the full 512-tile rounds as
-      // usual and the last partial round split along K.  Measured on the bench shapes: the GEMM kernels get 0.4 %
-      // faster, the extra reduce launches cost 1.2 % — a net loss, because a CU left with one resident workgroup in
-      // the last round already runs it at twice the speed (it no longer shares its SIMDs).
-      static const bool tail_on = [] {
-        const char* e = getenv("GDR_TAIL_SPLIT");
-        return e ? atoi(e) != 0 : false;
-      }();
-      const int64_t rem = tiles % SLOTS;
-      if (tail_on && rem > 0 && rem <= (SLOTS * 3) / 4) {
-        int S = (int)((2 * SLOTS) / rem);
-        if (S > 4) S = 4;
-        if (S > nk / 4) S = nk / 4;
-        if ((size_t)S * rem * tile_bytes > splitk_ws_bytes) S = (int)(splitk_ws_bytes / (rem * tile_bytes));
-        if (S >= 2) {
-          {
-            ProfScope prof(PROF_LINEAR, flops * (double)(tiles - rem) / (double)tiles, stream);
-            hipLaunchKernelGGL(gemm_nt_f32_kernel<EPI_LINEAR>, dim3((unsigned)(tiles - rem)), dim3(GEMM_THREADS), 0, stream,
-                               g);
-          }
-          GDR_CHECK_LAUNCH("gemm_nt_f32_kernel");
-          return split_launch(tiles - rem, rem, S);
-        }
-      }
     }
   }
   ProfScope prof(PROF_LINEAR, flops, stream);
-  static const bool persist_on = [] {
-    const char* e = getenv("GDR_GEMM_PERSIST");  // A/B knob: 0 = always one tile per workgroup
-    return e ? atoi(e) != 0 : true;
-  }();
   if (sk && streamk_mid_wanted(tiles) && K % BK == 0 && streamk_fits(M, lda, N, ldw)) {
     g.ksplit = g.tiles_n >= 12 ? 8 : 1;
     if (int rc_ = streamk_poll_error()) return rc_;
@@ -1312,16 +1280,12 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
     GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel(256)");
     return GDR_OK;
   }
-  if (persist_on && tiles > SLOTS && tiles < 0x7fffffff && K % BK == 0) {  // more than one round of tiles: persistent form
+  if (tiles > SLOTS && tiles < 0x7fffffff && K % BK == 0) {  // more than one round of tiles: persistent form
     {
-      static const int gm_env = [] {
-        const char* e = getenv("GDR_GEMM_SUPERTILE");  // row panels per supertile, every shape; unset = by shape
-        return e ? atoi(e) : 0;
-      }();
       // Measured HBM-side fetch per launch (PMC, M = 20480): N=3072 1112 -> 557 MB and N=2304 653 -> 443 MB with 8-panel
       // supertiles, but N=768 552 -> 684 MB (its 6 column tiles already fit one XCD's L2 next to 10 row panels): wide
       // outputs only.  Time is unchanged either way (the kernel is MFMA-bound); this is traffic and energy.
-      g.ksplit = gm_env > 0 ? gm_env : (g.tiles_n >= 12 ? 8 : 1);
+      g.ksplit = g.tiles_n >= 12 ? 8 : 1;
     }
     if (sk && streamk_wanted(tiles, K / BK) && streamk_fits(M, lda, N, ldw)) {
       if (int rc_ = streamk_poll_error()) return rc_;
@@ -1426,25 +1390,13 @@ int launch_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, f
           : epilogue == GDR_EPI_BIAS_GELU                             ? ACT_GELU
                                                                       : ACT_NONE;
   ProfScope prof(PROF_LINEAR, 2.0 * (double)M * (double)N * (double)K, stream);
-  static const bool glds_on = [] {
-    const char* e = getenv("GDR_BF16_GLDS");  // A/B knob: 0 = the generic register-staged core
-    return e ? atoi(e) != 0 : true;
-  }();
-  if (glds_on) {
+  {  // the LDS-DMA kernel (gemm_bf16.hip) serves K % 64 == 0 with 16-byte aligned operands; other shapes the generic core
     const int rc = launch_linear_bf16_glds(A, lda, W, ldw, C, ldc, M, N, K, needs_bias, needs_res, g.act, bias, residual, ldr, 0,
                                            stream, m_dev);
     if (rc <= 0) return rc;
   }
   g.m_dev = m_dev;
   return launch<EPI_LINEAR, true>(g, (M + BM - 1) / BM, stream);
-}
-
-static bool bf16_glds_sim() {
-  static const bool on = [] {
-    const char* e = getenv("GDR_BF16_GLDS_SIM");  // A/B knob: 0 = similarity passes on the generic core
-    return e ? atoi(e) != 0 : true;
-  }();
-  return on;
 }
 
 int launch_sim_gemm(const void* D_, int64_t N, const void* Q_, int B, int d, const SimEpilogue& ep, bool bf16,
@@ -1462,7 +1414,7 @@ int launch_sim_gemm(const void* D_, int64_t N, const void* Q_, int B, int d, con
     int64_t rows = n_sample_tiles * BM;
     if (rows > N) rows = N;
     ProfScope prof(PROF_SIM_SAMPLE, 2.0 * (double)rows * (double)B * (double)d, stream);
-    if (bf16 && bf16_glds_sim()) {
+    if (bf16) {
       const int rc = launch_sim_bf16_glds(D_, N, Q_, B, d, ep, n_sample_tiles, stream);
       if (rc <= 0) return rc;
     }
@@ -1471,7 +1423,7 @@ int launch_sim_gemm(const void* D_, int64_t N, const void* Q_, int B, int d, con
   int64_t rows = (tiles_m - n_sample_tiles) * BM;
   if (rows > N) rows = N;
   ProfScope prof(PROF_SIM_FILTER, 2.0 * (double)rows * (double)B * (double)d, stream);
-  if (bf16 && bf16_glds_sim()) {
+  if (bf16) {
     const int rc = launch_sim_bf16_glds(D_, N, Q_, B, d, ep, tiles_m - n_sample_tiles, stream);
     if (rc <= 0) return rc;
   }

@@ -189,130 +189,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const float* _
   }
 }
 
-// Split-K reduction of a full-row output (N = the model width) fused with what always follows it on the decode path:
-// epilogue (bias, residual, activation) -> C, then a norm of the finished row -> Y.  One wave per row: the row stays in
-// registers between the two.  Same summation order as splitk_reduce_small_kernel (slabs s = 0..S-1, then bias, then
-// residual) and the same lane -> column map and arithmetic as rmsnorm_kernel / layernorm_kernel (layers.hip), so C and Y
-// are bit-identical to the three-launch form.
+// Split-K reduction of a full-row output (N = the model width, <= 1024) fused with what always follows it on the decode
+// path: epilogue (bias, residual, activation) -> C, then a norm of the finished row -> Y.  ONE ROW PER WORKGROUP (thread <->
+// float4 column): every slab load of a row (S <= 8) is in flight at once on M workgroups, the row stays in registers between
+// the reduction and the norm, and the row statistics are combined across the four waves through LDS.  Same summation order
+// as splitk_reduce_small_kernel (slabs s = 0..S-1, then bias, then residual) and the same arithmetic as rmsnorm_kernel /
+// layernorm_kernel (layers.hip).  (A wave-per-row form served round 2's first version; measured slower at every row count
+// of the decode path, 10 .. 640 rows: -2 .. -7 % per generate() for this one — removed.)
 //   kind 1: Y = w1 * x / sqrt(mean(x^2) + eps)                               (T5LayerNorm, modeling_t5.py:164-171)
 //   kind 2: Y = LN(x; w1, b1)                                                (torch.nn.LayerNorm)
 //   kind 3: Y = LN(LN(x; w1, b1) + addv; w2, b2)                             (the adaptor's norm1 -> norm2 with its constant
 //                                                                             single-key cross-attention output in between)
-template <int NV>  // float4 per lane: N = 256 * NV (exact) or less with the tail lanes masked
-__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ partial, int S, int tiles_n, int64_t M,
-                                                                int N, float* __restrict__ C, int64_t ldc,
-                                                                const float* __restrict__ bias,
-                                                                const float* __restrict__ residual, int64_t ldr, int act,
-                                                                const int64_t* __restrict__ m_dev, const NormEpilogue ne) {
-  if (m_dev) M = *m_dev;
-  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= M) return;
-  const int lane = threadIdx.x & 63, n4 = N >> 2;
-  const int tm = (int)(m / SB), r = (int)(m - (int64_t)tm * SB);
-  float4 x[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c4 = lane + 64 * i;  // float4 column index, as in rmsnorm_kernel / layernorm_kernel
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c4 < n4) {
-      const int n = c4 << 2, tn = n / SB, c = n - tn * SB;
-      const float* p = partial + ((int64_t)(tm * tiles_n + tn) * S) * (SB * SB) + r * SB + c;
-      // the slabs are summed in the fixed order s = 0..S-1, but loaded four at a time (plus bias / residual up front):
-      // one memory round trip per four slabs instead of one per slab
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f), q = b;
-      if (bias) b = *reinterpret_cast<const float4*>(bias + n);
-      if (residual) q = *reinterpret_cast<const float4*>(residual + m * ldr + n);
-      v = *reinterpret_cast<const float4*>(p);
-      int s = 1;
-      for (; s + 4 <= S; s += 4) {
-        const float4 t0 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 0) * (SB * SB));
-        const float4 t1 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 1) * (SB * SB));
-        const float4 t2 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 2) * (SB * SB));
-        const float4 t3 = *reinterpret_cast<const float4*>(p + (int64_t)(s + 3) * (SB * SB));
-        v.x += t0.x, v.y += t0.y, v.z += t0.z, v.w += t0.w;
-        v.x += t1.x, v.y += t1.y, v.z += t1.z, v.w += t1.w;
-        v.x += t2.x, v.y += t2.y, v.z += t2.z, v.w += t2.w;
-        v.x += t3.x, v.y += t3.y, v.z += t3.z, v.w += t3.w;
-      }
-      for (; s < S; ++s) {
-        const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)s * (SB * SB));
-        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
-      }
-      if (bias) v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
-      if (residual) v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
-      if (act == 1) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
-      *reinterpret_cast<float4*>(C + m * ldc + n) = v;
-    }
-    x[i] = v;
-  }
-  auto wsum = [](float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-  };
-  float* yr = ne.Y + m * ne.ldy;
-  if (ne.kind == 1) {
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if (lane + 64 * i < n4) ss += x[i].x * x[i].x + x[i].y * x[i].y + x[i].z * x[i].z + x[i].w * x[i].w;
-    const float denom = sqrtf(wsum(ss) / (float)N + ne.eps);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c4 = lane + 64 * i;
-      if (c4 >= n4) continue;
-      const float4 g = reinterpret_cast<const float4*>(ne.w1)[c4], v = x[i];
-      *reinterpret_cast<float4*>(yr + 4 * c4) = make_float4(g.x * (v.x / denom), g.y * (v.y / denom), g.z * (v.z / denom),
-                                                            g.w * (v.w / denom));
-    }
-    return;
-  }
-  const float inv_d = 1.0f / (float)N;
-  auto layer_norm = [&](const float* w, const float* b) {  // x <- LN(x), arithmetic of layernorm_kernel
-    float su = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if (lane + 64 * i < n4) su += x[i].x + x[i].y + x[i].z + x[i].w;
-    const float mean = wsum(su) * inv_d;
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if (lane + 64 * i < n4) {
-        const float a0 = x[i].x - mean, a1 = x[i].y - mean, a2 = x[i].z - mean, a3 = x[i].w - mean;
-        ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
-      }
-    const float rstd = 1.0f / sqrtf(wsum(ss) * inv_d + ne.eps);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c4 = lane + 64 * i;
-      if (c4 >= n4) continue;
-      const float4 g = reinterpret_cast<const float4*>(w)[c4], bb = reinterpret_cast<const float4*>(b)[c4], v = x[i];
-      x[i] = make_float4((v.x - mean) * rstd * g.x + bb.x, (v.y - mean) * rstd * g.y + bb.y, (v.z - mean) * rstd * g.z + bb.z,
-                         (v.w - mean) * rstd * g.w + bb.w);
-    }
-  };
-  layer_norm(ne.w1, ne.b1);
-  if (ne.kind == 3) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c4 = lane + 64 * i;
-      if (c4 >= n4) continue;
-      const float4 t = reinterpret_cast<const float4*>(ne.addv)[c4];
-      x[i].x += t.x, x[i].y += t.y, x[i].z += t.z, x[i].w += t.w;
-    }
-    layer_norm(ne.w2, ne.b2);
-  }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c4 = lane + 64 * i;
-    if (c4 < n4) *reinterpret_cast<float4*>(yr + 4 * c4) = x[i];
-  }
-}
-
-// The same reduction + epilogue + norm with ONE ROW PER WORKGROUP (thread <-> float4 column, N <= 1024), for the row counts
-// of a single decoded query (M = beams): the wave-per-row kernel above puts 100 rows on 25 workgroups and walks the slabs
-// in two or three dependent round trips; here every slab load of a row (S <= 8) is in flight at once on M workgroups, and
-// the row statistics are combined across the four waves through LDS.  Same fixed slab order s = 0..S-1.
 __global__ __launch_bounds__(256) void splitk_reduce_norm_row_kernel(const float* __restrict__ partial, int S, int tiles_n,
                                                                     int64_t M, int N, float* __restrict__ C, int64_t ldc,
                                                                     const float* __restrict__ bias,
@@ -393,11 +280,8 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev,
                             const NormEpilogue* ne, SlabRef* slabs) {
-  static const int target = [] {
-    const char* e = getenv("GDR_SMALL_TARGET");  // tuning knob: workgroups wanted per launch; 0 disables this kernel
-    return e ? atoi(e) : 512;
-  }();
-  if (target <= 0 || K % SBK != 0) return 1;
+  constexpr int target = 512;  // workgroups wanted per launch (measured flat between 256 and 512, worse outside)
+  if (K % SBK != 0) return 1;
   const int64_t tiles_m = (M + SB - 1) / SB;
   const int tiles_n = (N + SB - 1) / SB;
   const int64_t tiles = tiles_m * tiles_n;
@@ -417,7 +301,7 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
   g.ksplit = S, g.kchunk = chunk_steps * SBK;
   g.m_dev = m_dev;
   const double flops = 2.0 * (double)M * (double)N * (double)K;
-  if (ne && (S == 1 || N % 4 != 0 || N > 256 * 4 * 4 || act > 1)) return 2;  // the fused norm needs split slabs of a row it can hold
+  if (ne && (S == 1 || N % 4 != 0 || N > 1024 || act > 1)) return 2;  // the fused norm needs split slabs of a row it can hold
   if (slabs) {
     if (has_bias || has_residual || act || ne) return 1;  // slabs carry raw partial sums only
     slabs->part = nullptr, slabs->S = 1, slabs->tiles_n = tiles_n;
@@ -441,28 +325,11 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
   }
   ProfScope prof_r(PROF_REDUCE, 0.0, stream);
   if (ne) {
-    const unsigned grid = (unsigned)((M + 3) / 4);
     const float* bp = has_bias ? bias : nullptr;
     const float* rp = has_residual ? residual : nullptr;
-    static const int row_max = [] {
-      const char* e = getenv("GDR_REDUCE_NORM_ROW_MAX");  // A/B knob: largest M served by the row-per-workgroup form; 0 = off
-      return e ? atoi(e) : 4096;  // measured better at every row count of the decode path (10 .. 640 rows: -2 .. -7 % per generate())
-    }();
-    if (M <= row_max && N <= 1024) {
-      hipLaunchKernelGGL(splitk_reduce_norm_row_kernel, dim3((unsigned)M), dim3(256), 0, stream, ws, S, tiles_n, M, N, C, ldc, bp, rp,
-                         ldr, act, m_dev, *ne);
-      GDR_CHECK_LAUNCH("splitk_reduce_norm_row_kernel");
-      return 0;
-    }
-    const int nv = (N / 4 + 63) / 64;
-#define GDR_RN(NV_) \
-  hipLaunchKernelGGL(splitk_reduce_norm_kernel<NV_>, dim3(grid), dim3(256), 0, stream, ws, S, tiles_n, M, N, C, ldc, bp, rp, ldr, act, m_dev, *ne)
-    if (nv <= 1) GDR_RN(1);
-    else if (nv == 2) GDR_RN(2);
-    else if (nv == 3) GDR_RN(3);
-    else GDR_RN(4);
-#undef GDR_RN
-    GDR_CHECK_LAUNCH("splitk_reduce_norm_kernel");
+    hipLaunchKernelGGL(splitk_reduce_norm_row_kernel, dim3((unsigned)M), dim3(256), 0, stream, ws, S, tiles_n, M, N, C, ldc, bp, rp,
+                       ldr, act, m_dev, *ne);
+    GDR_CHECK_LAUNCH("splitk_reduce_norm_row_kernel");
     return 0;
   }
   hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((unsigned)(tiles * 4)), dim3(256), 0, stream, ws, S, tiles_n, M, N, C, ldc,

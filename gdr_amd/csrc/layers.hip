@@ -535,162 +535,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 
 
 // ------------------------------------------------------------------------------------------ attention on MFMA
-// Full self-attention (Lq == Lk = L <= 128, dk = 64) on v_mfma_f32_32x32x2_f32, one workgroup per (batch, head),
-// one wave per 32-query tile.  Q, K, V of the head are staged once in LDS (rows zero-padded to a multiple of 32,
-// row stride 68 floats: conflict-free ds_read_b128).
-//   S^T = K · Q^T : docs^W keys take the MFMA row role, queries the column role, so a LANE OWNS ONE QUERY: its 16
-//         accumulators per key tile are that query's scores; row max / sum are lane-local plus one exchange with the
-//         partner half-wave (lane ^ 32).
-//   O^T = V^T · P^T : the probability accumulators ARE the B operand of the next MFMA (register r of lane-half h
-//         is key (r&3)+8(r>>2)+4h; the A operand reads V[that key][d] from LDS) — no LDS round trip for P.
-// Arithmetic is the reference's (scores + bias + mask, fp32 softmax, PV; modeling_t5.py:384-413), fp32 throughout.
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-
-template <int NT>
-__global__ __launch_bounds__(64 * NT) void attention_mfma_kernel(const AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int DK = 64, DS = DK + 4, LP = 32 * NT, NTHR = 64 * NT;
-  // Only the L real rows are staged; fragment reads of padded rows are clamped to row L-1 (finite duplicates): padded
-  // keys are removed by Mk = -inf (their probabilities are exactly 0), padded queries are never stored.
-  const int Lr = a.Lk;
-  float* Qs = smem;
-  float* Ks = Qs + Lr * DS;
-  float* Vs = Ks + Lr * DS;
-  float* RelB = Vs + Lr * DS;   // [2*LP]  bias of relative distance n = i_abs - j, index n + LP - 1 (+ q_pos0 folded in)
-  float* Mk = RelB + 2 * LP;    // [LP]    additive key term: 0, pad mask (-1e9) or -inf for padded rows
-  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-  const int L = a.Lk, tid = threadIdx.x;
-  // Per-key / per-distance additive terms are tabulated once per workgroup: inside the softmax loop every lane would
-  // otherwise issue one LUT load, one mask load and one bias read per score (96 dependent loads per lane).
-  for (int e = tid; e < 2 * LP; e += NTHR) {
-    float v = 0.f;
-    if (a.rel_bias) {
-      int n = e - (LP - 1), bucket = 0;
-      if (a.bidirectional) {
-        if (n < 0) {
-          bucket = a.num_buckets >> 1;
-          n = -n;
-        }
-      } else if (n < 0) {
-        n = 0;
-      }
-      bucket += a.lut.v[n < 127 ? n : 127];
-      v = a.rel_bias[bucket * a.H + h];
-    }
-    RelB[e] = v;
-  }
-  for (int j = tid; j < LP; j += NTHR) {
-    float v = -INFINITY;
-    if (j < L) v = (a.key_mask && a.key_mask[(int64_t)b * a.mask_bstride + j] == 0) ? (a.causal_neg_inf ? -INFINITY : -1e9f) : 0.f;
-    Mk[j] = v;
-  }
-  for (int e = tid; e < L * (DK / 4); e += NTHR) {
-    const int r = e >> 4, c = e & 15;
-    float4 q = *reinterpret_cast<const float4*>(a.q + ((int64_t)b * a.q_bstride + r) * a.ldq + h * DK + 4 * c);
-    const float4 k = *reinterpret_cast<const float4*>(a.k + ((int64_t)b * a.k_bstride + r) * a.ldk + h * DK + 4 * c);
-    const float4 v = *reinterpret_cast<const float4*>(a.v + ((int64_t)b * a.k_bstride + r) * a.ldv + h * DK + 4 * c);
-    q.x *= a.scale, q.y *= a.scale, q.z *= a.scale, q.w *= a.scale;
-    *reinterpret_cast<float4*>(Qs + r * DS + 4 * c) = q;
-    *reinterpret_cast<float4*>(Ks + r * DS + 4 * c) = k;
-    *reinterpret_cast<float4*>(Vs + r * DS + 4 * c) = v;
-  }
-  __syncthreads();
-
-  const int w = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-  f32x16_t st[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
-  // ---- S^T tiles: A = K rows (keys), B = Q rows (queries); k index permuted inside chunks of 8 as in the GEMM core
-  const float* qrow = Qs + min(32 * w + l31, L - 1) * DS + 4 * hh;
-#pragma unroll
-  for (int jj = 0; jj < DK / 8; ++jj) {
-    const float4 qv = *reinterpret_cast<const float4*>(qrow + 8 * jj);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const float4 kv = *reinterpret_cast<const float4*>(Ks + min(32 * t + l31, L - 1) * DS + 4 * hh + 8 * jj);
-      st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qv.x, st[t], 0, 0, 0);
-      st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qv.y, st[t], 0, 0, 0);
-      st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qv.z, st[t], 0, 0, 0);
-      st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qv.w, st[t], 0, 0, 0);
-    }
-  }
-  // ---- bias + mask + softmax over keys (this lane's query column)
-  const int i = 32 * w + l31;  // relative distance n = (q_pos0 + i) - j; q_pos0 = 0 for full self-attention
-  const float masked = a.causal_neg_inf ? -INFINITY : -1e9f;
-  float mx = -INFINITY;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      float add = RelB[i - j + (LP - 1)] + Mk[j];          // (bias + mask) first, as the reference (modeling_t5.py:399-400)
-      if (a.causal && j > i && Mk[j] == 0.f) add += masked;  // one -1e9 per masked key, never two
-      const float s = st[t][r] + add;
-      st[t][r] = s;
-      mx = fmaxf(mx, s);
-    }
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  float sum = 0.f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = __expf(st[t][r] - mx);  // padded keys: exp(-inf) = 0
-      st[t][r] = p;
-      sum += p;
-    }
-  }
-  sum += __shfl_xor(sum, 32);
-  const float inv = 1.0f / sum;
-  // ---- O^T = V^T · P^T, two 32-wide d tiles; then normalise and store rows of this lane's query
-#pragma unroll
-  for (int dt = 0; dt < DK / 32; ++dt) {
-    f32x16_t o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const float vv = Vs[min(j, L - 1) * DS + 32 * dt + l31];
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[t][r], o, 0, 0, 0);
-      }
-    }
-    if (i < L) {
-      float* orow = a.out + ((int64_t)b * a.o_bstride + i) * a.ldo + h * DK + 32 * dt + 4 * hh;
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        float4 ov;
-        ov.x = o[4 * q4 + 0] * inv, ov.y = o[4 * q4 + 1] * inv, ov.z = o[4 * q4 + 2] * inv, ov.w = o[4 * q4 + 3] * inv;
-        if (a.out_bf16)
-          *reinterpret_cast<uint2*>(static_cast<__bf16*>(a.out_bf16) + (orow - a.out) + 8 * q4) = pack_bf16x4(ov.x, ov.y, ov.z, ov.w);
-        else
-          *reinterpret_cast<float4*>(orow + 8 * q4) = ov;
-      }
-    }
-  }
-}
-
-template <int NT>
-static int launch_attention_mfma(const AttnArgs& a, hipStream_t stream) {
-  const size_t lds = sizeof(float) * ((size_t)3 * a.Lk * 68 + 3 * 32 * NT);
-  if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(attention_mfma_kernel<NT>), 160 * 1024, "attention")) return rc__;
-  hipLaunchKernelGGL(attention_mfma_kernel<NT>, dim3((unsigned)(a.B * a.H)), dim3(64 * NT), lds, stream, a);
-  GDR_CHECK_LAUNCH("attention_mfma_kernel");
-  return GDR_OK;
-}
-
-
-// The same attention on v_mfma_f32_16x16x4_f32: 16-query tiles (one wave each) against 16-key tiles.  With 32-wide
-// tiles a T5 query batch of L = 40 computes 64 x 64 scores per head to use 40 x 40 (61 % of the matrix work is
-// padding); 16-wide tiles compute 48 x 48.  Same staging, same arithmetic and the same tricks: S^T = K·Q^T so that a lane
+// Full self-attention (Lq == Lk = L <= 128, dk = 64) on v_mfma_f32_16x16x4_f32: one workgroup per (batch, head), one wave
+// per 16-query tile against 16-key tiles (a T5 query batch of L = 40 computes 48 x 48 scores; the 32x32x2 form this
+// replaced in round 2 computed 64 x 64 — it is gone, rocprof history: 104 -> 66 us per layer at B = 512).  K, V of the
+// head are staged once in LDS (row stride 68 floats: conflict-free ds_read_b128).  S^T = K·Q^T so that a lane
 // holds scores of ONE query (4 lanes share a query: lane>>4 picks 4 of every 16 keys; max / sum need two shuffles), and
 // the probability registers are the B operand of the PV MFMAs as they stand (MFMA step s contracts keys 16t + 4q + s,
-// which is register s of lane-quarter q; the A operand reads V[that key][d] from LDS).
+// which is register s of lane-quarter q; the A operand reads V[that key][d] from LDS).  Arithmetic is the reference's
+// (scores + bias + mask, fp32 softmax, PV; modeling_t5.py:384-413), fp32 throughout.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <int NT>  // 16-key tiles = 16-query tiles = waves per workgroup: ceil(L / 16), 1..8
@@ -878,92 +730,13 @@ static int launch_attention_mfma16(const AttnArgs& a, hipStream_t stream) {
 
 
 // ------------------------------------------------------------------------------------------ attention, Lq == 1
-// Decode-time attention (one query row per batch entry): one WAVE per (row, head), four per workgroup, nothing
-// staged in LDS.  Lane j scores key j (and j+64): its K row is read with 16-byte loads (L2-resident cache / cross
-// K/V), q comes from a wave-uniform (broadcast) load.  Softmax by wave shuffles, PV with lane = d and the
-// probabilities broadcast by shuffle.  Same semantics as attention_kernel (bias, masks, kv_rows, kv_group).
-__global__ __launch_bounds__(256) void attention_decode_kernel(const AttnArgs a) {
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= a.B * a.H) return;
-  const int b = item / a.H, h = item % a.H, lane = threadIdx.x & 63;
-  if (a.b_count_dev && b >= (int)*a.b_count_dev) return;  // only the first *b_count_dev batch entries are live
-  const int dk = a.dk, c4 = dk >> 2, Lk = a.Lk, kb = b / a.kv_group;
-  const float* qr = a.q + (int64_t)b * a.q_bstride * a.ldq + h * dk;
-  const int i_abs = a.q_pos0;
-  const int half = a.num_buckets >> 1;
-  const float masked = a.causal_neg_inf ? -INFINITY : -1e9f;
-  float sc[2], mx = -INFINITY;
-  int64_t vrow[2] = {0, 0};
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int j = lane + 64 * t;
-    float s = -INFINITY;
-    if (j < Lk) {
-      const int64_t rk = a.kv_rows ? (int64_t)a.kv_rows[(int64_t)b * Lk + j] : (int64_t)kb * a.k_bstride + j;
-      vrow[t] = rk;
-      const float4* kr = reinterpret_cast<const float4*>(a.k + rk * a.ldk + h * dk);
-      const float4* q4 = reinterpret_cast<const float4*>(qr);
-      float acc = 0.f;
-      for (int c = 0; c < c4; ++c) {
-        const float4 qq = q4[c], kk = kr[c];
-        acc = fmaf(qq.x * a.scale, kk.x, acc);
-        acc = fmaf(qq.y * a.scale, kk.y, acc);
-        acc = fmaf(qq.z * a.scale, kk.z, acc);
-        acc = fmaf(qq.w * a.scale, kk.w, acc);
-      }
-      float add = 0.f;
-      if (a.rel_bias) {
-        int n = i_abs - j, bucket = 0;
-        if (a.bidirectional) {
-          if (n < 0) {
-            bucket = half;
-            n = -n;
-          }
-        } else if (n < 0) {
-          n = 0;
-        }
-        bucket += a.lut.v[n < 127 ? n : 127];
-        add = a.rel_bias[bucket * a.H + h];
-      }
-      bool allowed = true;
-      if (a.causal) allowed = j <= i_abs;
-      if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)kb * a.mask_bstride + j] != 0);
-      if (!allowed) add += masked;
-      s = acc + add;
-    }
-    sc[t] = s;
-    mx = fmaxf(mx, s);
-  }
-  mx = wave_max(mx);
-  float p[2], sum = 0.f;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    p[t] = (lane + 64 * t < Lk) ? expf(sc[t] - mx) : 0.f;
-    sum += p[t];
-  }
-  sum = wave_sum(sum);
-  const float inv = 1.0f / sum;
-  float* orow = a.out + (int64_t)b * a.o_bstride * a.ldo + h * dk;
-  for (int d0 = 0; d0 < dk; d0 += 64) {  // wave-uniform trip count: the shuffles below need every lane
-    const int d = d0 + lane;
-    const bool live = d < dk;
-    float o = 0.f;
-    for (int j = 0; j < Lk; ++j) {
-      const float pj = __shfl(j < 64 ? p[0] : p[1], j & 63);
-      const int64_t rk = __shfl(j < 64 ? vrow[0] : vrow[1], j & 63);
-      const float vv = live ? a.v[rk * a.ldv + h * dk + d] : 0.f;
-      o = fmaf(pj * inv, vv, o);
-    }
-    if (live) orow[d] = o;
-  }
-}
-
-// The same Lq = 1 attention with COALESCED K / V reads.  In the kernel above a lane owns a key and walks its K row with
-// 16-byte loads: one wave instruction touches 64 different rows (64 cache lines for 1 KB of payload), and the texture
-// path, not the arithmetic, sets the pace (138 us per call at 5 120 rows x 12 heads).  Here LPR consecutive lanes read one
-// row together (a 256-byte row = 16 lanes x 16 B), so an instruction covers 64/LPR rows in full cache lines; the 4-element
-// partial dot products are summed over the LPR lanes of a row group by a butterfly, scores / probabilities pass through
-// a per-wave LDS strip, and P·V accumulates a float4 per lane that is finally summed over the row groups.
+// Decode-time attention (one query row per batch entry): one WAVE per (row, head), four per workgroup, nothing staged in
+// LDS but a score strip; same semantics as attention_kernel (bias, masks, kv_rows, kv_group).  K / V reads are COALESCED:
+// LPR consecutive lanes read one row together (a 256-byte row = 16 lanes x 16 B), so an instruction covers 64/LPR rows in
+// full cache lines (the lane-per-key form of round 1 touched 64 cache lines per instruction and ran at the texture
+// path's pace: 138 -> 93 us per call at 5 120 rows x 12 heads); the 4-element partial dot products are summed over the
+// LPR lanes of a row group by a butterfly, scores / probabilities pass through a per-wave LDS strip, and P·V accumulates
+// a float4 per lane that is finally summed over the row groups.
 template <int LPR>  // lanes per K / V row: 16 (dk <= 64) or 32 (dk <= 128)
 __global__ __launch_bounds__(256) void attention_decode_rows_kernel(const AttnArgs a) {
   constexpr int RPI = 64 / LPR;  // rows per wave instruction
@@ -1064,51 +837,32 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   GDR_CHECK_ARG(!a.q_part || (a.Lq > 1 && a.q_same_pos && a.dk % 4 == 0 && a.q_S >= 1 && (a.H * a.dk) % 4 == 0),
                 "attention: slab-sourced q serves the shared-K/V decode form (generic kernel) only");
   if (a.Lq == 1) {
-    static const bool rows_form = [] {
-      const char* e = getenv("GDR_ATTN_DECODE_ROWS");  // A/B knob: 0 = the lane-per-key kernel
-      return e ? atoi(e) != 0 : true;
-    }();
+    GDR_CHECK_ARG(a.dk <= 128 && a.ldo % 4 == 0, "attention: the Lq = 1 form serves dk <= 128 with ldo %% 4 == 0 (dk=%d ldo=%lld)", a.dk,
+                  (long long)a.ldo);
     const dim3 grid((unsigned)((a.B * a.H + 3) / 4));
-    if (rows_form && a.dk <= 128 && a.ldo % 4 == 0) {
-      if (a.dk <= 64)
-        hipLaunchKernelGGL(attention_decode_rows_kernel<16>, grid, dim3(256), 0, stream, a);
-      else
-        hipLaunchKernelGGL(attention_decode_rows_kernel<32>, grid, dim3(256), 0, stream, a);
-      GDR_CHECK_LAUNCH("attention_decode_rows_kernel");
-      return GDR_OK;
-    }
-    hipLaunchKernelGGL(attention_decode_kernel, grid, dim3(256), 0, stream, a);
-    GDR_CHECK_LAUNCH("attention_decode_kernel");
+    if (a.dk <= 64)
+      hipLaunchKernelGGL(attention_decode_rows_kernel<16>, grid, dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL(attention_decode_rows_kernel<32>, grid, dim3(256), 0, stream, a);
+    GDR_CHECK_LAUNCH("attention_decode_rows_kernel");
     return GDR_OK;
   }
-  const bool packed = a.seq_off != nullptr || a.qkv_bf16;  // both exist in the 16x16x4 MFMA form only
+  const bool packed = a.seq_off != nullptr || a.qkv_bf16;  // both exist in the MFMA form only
   GDR_CHECK_ARG(!a.seq_off || a.seq_len, "attention: seq_off without seq_len");
   GDR_CHECK_ARG(!packed || (a.Lq == a.Lk && a.q_pos0 == 0 && !a.kv_rows && a.kv_group == 1 && !a.q_same_pos &&
                             a.dk == 64 && a.ldo % 4 == 0),
                 "attention: the packed (ragged) form and bf16 q/k/v serve full self-attention with d_kv = 64 only");
   GDR_CHECK_ARG(!a.qkv_bf16 || (a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0), "attention: bf16 q/k/v need row strides %% 8 == 0");
   if (a.Lq == a.Lk && a.q_pos0 == 0 && !a.kv_rows && a.kv_group == 1 && !a.q_same_pos && a.dk == 64 && a.ldo % 4 == 0) {
-    static const bool tiles16 = [] {
-      const char* e = getenv("GDR_ATTN_MFMA16");  // A/B knob: 0 = 32x32x2 tiles
-      return e ? atoi(e) != 0 : true;
-    }();
-    if (tiles16 || packed) {
-      switch ((a.Lk + 15) / 16) {
-        case 1: return launch_attention_mfma16<1>(a, stream);
-        case 2: return launch_attention_mfma16<2>(a, stream);
-        case 3: return launch_attention_mfma16<3>(a, stream);
-        case 4: return launch_attention_mfma16<4>(a, stream);
-        case 5: return launch_attention_mfma16<5>(a, stream);
-        case 6: return launch_attention_mfma16<6>(a, stream);
-        case 7: return launch_attention_mfma16<7>(a, stream);
-        default: return launch_attention_mfma16<8>(a, stream);
-      }
-    }
-    switch ((a.Lk + 31) / 32) {
-      case 1: return launch_attention_mfma<1>(a, stream);
-      case 2: return launch_attention_mfma<2>(a, stream);
-      case 3: return launch_attention_mfma<3>(a, stream);
-      default: return launch_attention_mfma<4>(a, stream);
+    switch ((a.Lk + 15) / 16) {
+      case 1: return launch_attention_mfma16<1>(a, stream);
+      case 2: return launch_attention_mfma16<2>(a, stream);
+      case 3: return launch_attention_mfma16<3>(a, stream);
+      case 4: return launch_attention_mfma16<4>(a, stream);
+      case 5: return launch_attention_mfma16<5>(a, stream);
+      case 6: return launch_attention_mfma16<6>(a, stream);
+      case 7: return launch_attention_mfma16<7>(a, stream);
+      default: return launch_attention_mfma16<8>(a, stream);
     }
   }
   const int dks = a.dk + 4, Lkp = (a.Lk + 3) & ~3;

@@ -1,8 +1,9 @@
 """Scheduling choices of the decode path must not change what generate() returns: the cross-attention that sums the q
 projection's split-K slabs itself (GDR_DECODE_SLAB_Q) is bit-identical to the separate reduction launch; the fused
-reduce + residual + norm forms (GDR_DECODE_FUSE_NORM, GDR_REDUCE_NORM_ROW_MAX) and the row-coalesced Lq = 1 attention
-(GDR_ATTN_DECODE_ROWS) may differ in fp32 summation order only.  The switches are read once per process, so each setting
-runs in its own process.  Semantics of the path: generation_utils.py:656-921, modeling_t5.py:1584-1652."""
+reduce + residual + norm launch (GDR_DECODE_FUSE_NORM) and step 0 on one row per query instead of all B*R identical beam rows
+(GDR_DECODE_DEDUP0) may differ in fp32 summation order only.  Each switch selects code that also runs by default for other
+shapes or modes (the bf16 mode, wide layers), so none keeps a dead kernel alive.  The switches are read once per process, so
+each setting runs in its own process.  Semantics of the path: generation_utils.py:656-921, modeling_t5.py:1584-1652."""
 import json
 import os
 import subprocess
@@ -49,8 +50,7 @@ def test_decode_scheduling_switches_do_not_change_generate():
     assert exact == base, "slab-sourced cross-attention q must be bit-identical to the reduction launch"
     # GDR_DECODE_DEDUP0=0 runs step 0 on all B*R identical beam rows instead of one row per query: the same numbers from
     # launches of another shape (other split-K factors), i.e. fp32 summation order only
-    for env in (dict(GDR_DECODE_FUSE_NORM="0"), dict(GDR_REDUCE_NORM_ROW_MAX="0"), dict(GDR_ATTN_DECODE_ROWS="0"),
-                dict(GDR_DECODE_DEDUP0="0")):
+    for env in (dict(GDR_DECODE_FUSE_NORM="0"), dict(GDR_DECODE_DEDUP0="0")):
         other = _run(**env)
         for key in base:
             a, b = base[key], other[key]
