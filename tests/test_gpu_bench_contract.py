@@ -44,9 +44,14 @@ def test_bench_line_contract_fp32():
     assert lat["bound"] == "hbm" and 0 < lat["frac_of_hbm_peak"] < 1
     for key in ("B64_beam10", "B1_beam100"):
         g = st["generate"][key]
-        assert g["generate_ms"] > g["encoder_ms"] > 0 and 0 < g["frac_of_floor"] < 1
+        assert g["generate_ms"] > g["encoder_ms"] > 0 and 0 < g["frac_of_floor_executed"] <= g["frac_of_floor"] < 1
+        assert g["decode_gflop_executed"] < g["decode_gflop_without_table"]
     assert st["c3_two_stage"]["queries_per_s"] > 0 and st["bf16_mode_c2_step"]["queries_per_s"] > 0
     assert st["prefix_table"]["nodes"] > 1
+    rr = st["rerank"]
+    assert any(k.startswith("B64_cand") for k in rr) and any(k.startswith("B1_cand") for k in rr)
+    assert all(0 < v["frac_of_hbm_peak"] < 1 and v["candidates"] > 0 for v in rr.values())
+    assert st["c3_two_stage"]["after_generate_ms"] < st["c3_two_stage"]["ms"]
     assert st["c3_two_stage_B512"]["queries_per_s"] > st["c3_two_stage"]["queries_per_s"] > 0
     assert 0 < st["doc_tower_bert_base_L128"]["frac_of_f32_mfma_peak"] < 1
 
