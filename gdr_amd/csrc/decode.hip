@@ -299,6 +299,14 @@ __global__ void table_logits_kernel(const float* __restrict__ table, const int64
   logits[item] = table[(((size_t)b * maxlen + pos) * Vd + (size_t)cur_tok[r]) * Vd + tok];
 }
 
+// LDS operations of one wave execute in order: between steps that only exchange data inside a wave this wave-level barrier
+// (plus fences for the compiler) is all the synchronisation needed.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Per query: log_softmax of every beam's row (masked columns contribute exp(-1e9 - max) = 0 exactly), add the
 // beam score, take the 2R best of the R*(V+1) unmasked candidates, sorted (generation_utils.py:698,766-775).
 __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims bd, int pos, int npad, int cur, int bcast,
@@ -353,6 +361,44 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims b
   // wave, LDS only across waves) was built and measured no faster (54 us) — 8 ds_bpermute per shuffle stage cost what the
   // LDS round trip of a stage costs.
   const int epw = npad / nwaves;
+  if (epw >= 2 * R && nwaves > 1) {
+    // Only the 2R best of the npad keys are wanted and a wave's block holds at least that many: every wave sorts its own
+    // block (descending, no workgroup barrier), then blocks are merged pairwise keeping the better half — for A and B
+    // sorted descending, max(A[i], B[epw-1-i]) is a bitonic sequence holding the epw largest of both, which log2(epw)
+    // wave-local stages sort — until block 0 holds the top epw of all.  log2(nwaves) + 1 workgroup barriers where the full
+    // network below takes a barrier pair on each of its 10 wide stages: 49 -> (measured) us per step at 100 beams.
+    unsigned long long* blk = keys + wave * epw;
+    for (int size = 2; size <= epw; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int q = lane; q < (epw >> 1); q += 64) {
+          const int lo = (q / stride) * (stride << 1) + (q % stride), hi = lo + stride;
+          const bool desc = ((lo & size) == 0);
+          const unsigned long long x = blk[lo], y = blk[hi];
+          if ((x < y) == desc) blk[lo] = y, blk[hi] = x;
+        }
+        wave_sync();
+      }
+    }
+    for (int nb = nwaves; nb > 1; nb >>= 1) {
+      __syncthreads();
+      if (wave < (nb >> 1)) {
+        const unsigned long long* other = keys + (wave + (nb >> 1)) * epw;
+        for (int q = lane; q < epw; q += 64) {
+          const unsigned long long x = blk[q], y = other[epw - 1 - q];
+          blk[q] = x > y ? x : y;
+        }
+        wave_sync();
+        for (int stride = epw >> 1; stride > 0; stride >>= 1) {
+          for (int q = lane; q < (epw >> 1); q += 64) {
+            const int lo = (q / stride) * (stride << 1) + (q % stride), hi = lo + stride;
+            const unsigned long long x = blk[lo], y = blk[hi];
+            if (x < y) blk[lo] = y, blk[hi] = x;
+          }
+          wave_sync();
+        }
+      }
+    }
+  } else {
   for (int size = 2; size <= npad; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       if (2 * stride <= epw) {
@@ -384,6 +430,7 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims b
       }
     }
   }
+  }
   __syncthreads();
   for (int i = tid; i < 2 * R; i += nthr) {
     const unsigned long long key = keys[i];
@@ -405,11 +452,6 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims b
 // insertion number and the storage order is free: a delete moves the last entry into the hole.
 // The hypothesis-heap helpers below are executed by ONE wave (the first wave of the block): LDS operations of a wave
 // execute in order, so a wave-level barrier (plus fences for the compiler) is all the synchronisation they need.
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 struct HypLds {
   double* sc;   // [R+1]
   int32_t* ln;  // [R+1]
@@ -450,9 +492,10 @@ __device__ __forceinline__ void hyp_store(const HypLds& H, const BeamBufs& bb, c
 
 // BeamHypotheses.add (generation_utils.py:1070-1084); Python-float arithmetic = double.  Called by all 64 lanes of the
 // query's wave with uniform arguments.
-__device__ void hyp_add(HypLds& H, const BeamDims& bd, const int32_t* toks, int len, double sum_logp, int lane) {
+// `len_pow` = pow(len, length_penalty), computed once by the caller (every add of one launch has the same length).
+__device__ __forceinline__ void hyp_add(HypLds& H, const BeamDims& bd, const int32_t* toks, int len, double sum_logp, int lane, double len_pow) {
   const int ml = bd.maxlen;
-  const double score = sum_logp / pow((double)len, bd.lp);
+  const double score = sum_logp / len_pow;
   if (!(H.n < bd.R || score > H.worst)) return;
   if (lane == 0) H.sc[H.n] = score, H.ln[H.n] = len, H.sq[H.n] = H.next;
   for (int t = lane; t < len; t += 64) H.tk[(size_t)H.n * ml + t] = toks[t];
@@ -547,6 +590,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamBufs bb, BeamDims 
     }
     // pass 2: EOS candidates of rank < min(R, end) enter the heap, in rank order (:811-817)
     bool touched = false;
+    const double len_pow = pow((double)cur_len, bd.lp);
     const int lim = end < R ? end : R;
     for (int base = 0; base < lim; base += 64) {
       const int rank = base + lane;
@@ -554,7 +598,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamBufs bb, BeamDims 
       while (m) {
         const int rk = base + (int)__ffsll((long long)m) - 1;
         m &= m - 1;
-        hyp_add(H, bd, seq_c + (size_t)(b * R + ci[rk] / bd.Vd) * ml, cur_len, (double)cs[rk], lane);
+        hyp_add(H, bd, seq_c + (size_t)(b * R + ci[rk] / bd.Vd) * ml, cur_len, (double)cs[rk], lane, len_pow);
         touched = true;
       }
     }
@@ -563,7 +607,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamBufs bb, BeamDims 
     if (lane == 0) {
       n_sh = n;
       if (H.n >= R) {
-        const double cur_score = (double)cs[0] / pow((double)cur_len, bd.lp);
+        const double cur_score = (double)cs[0] / len_pow;
         if (H.worst >= cur_score) bb.done[b] = 1;
       }
     }
@@ -614,10 +658,15 @@ __global__ __launch_bounds__(64) void beam_finalize_kernel(BeamBufs bb, BeamDims
   hyp_load(H, bsm, bb, bd, b, lane);
   int32_t* order = reinterpret_cast<int32_t*>(bsm + ((hyp_lds_bytes(R, ml) + 15) & ~(size_t)15));  // [nret] entry of rank j
   if (!bb.done[b]) {
-    for (int j = 0; j < R; ++j) {
-      const int row = b * R + j;
-      hyp_add(H, bd, bb.seq[cur] + (size_t)row * ml, final_len, (double)bb.beam_scores[row], lane);
-    }
+    // the R open beams enter the heap one after another (:863-883).  Their rows are staged in LDS first: read one by one
+    // from device memory, every add paid a dependent round trip (172 us at 100 beams, rocprofv3; 100 adds)
+    int32_t* rows_s = order + bd.nret;                         // [R][ml]
+    float* sc_s = reinterpret_cast<float*>(rows_s + R * ml);   // [R]
+    for (int e = lane; e < R * ml; e += 64) rows_s[e] = bb.seq[cur][(size_t)b * R * ml + e];
+    for (int j = lane; j < R; j += 64) sc_s[j] = bb.beam_scores[b * R + j];
+    wave_sync();
+    const double len_pow = pow((double)final_len, bd.lp);
+    for (int j = 0; j < R; ++j) hyp_add(H, bd, rows_s + j * ml, final_len, (double)sc_s[j], lane, len_pow);
   }
   __syncthreads();
   // sorted(beams, key=score) is stable ascending and pop() takes the last: highest score first, among equal scores the
@@ -693,6 +742,7 @@ static int beam_step(const BeamBufs& bb, const BeamDims& bd, int pos, int cur, f
 static int beam_begin(const BeamBufs& bb, const BeamDims& bd, hipStream_t stream, bool dedup0 = false) {
   const int rows = bd.B * bd.R;
   if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(beam_topk_kernel), 96 * 1024, "beam")) return rc__;
+  if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(beam_finalize_kernel), 96 * 1024, "beam")) return rc__;
   hipLaunchKernelGGL(beam_init_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, bb, bd, dedup0 ? 1 : 0);
   GDR_CHECK_LAUNCH("beam_init_kernel");
   return GDR_OK;
@@ -700,7 +750,8 @@ static int beam_begin(const BeamBufs& bb, const BeamDims& bd, hipStream_t stream
 
 static int beam_end(const BeamBufs& bb, const BeamDims& bd, int max_length, int cur, int64_t* out_ids,
                     int32_t* out_len, double* out_scores, hipStream_t stream) {
-  const size_t hyp_lds = ((hyp_lds_bytes(bd.R, bd.maxlen) + 15) & ~(size_t)15) + (size_t)bd.R * 4;
+  const size_t hyp_lds = ((hyp_lds_bytes(bd.R, bd.maxlen) + 15) & ~(size_t)15) + (size_t)bd.R * 4 +
+                         (size_t)bd.R * bd.maxlen * 4 + (size_t)bd.R * 4;  // + the staged beam rows and scores
   hipLaunchKernelGGL(beam_finalize_kernel, dim3(bd.B), dim3(64), hyp_lds, stream, bb, bd, max_length, cur, max_length, out_ids,
                      out_len, out_scores);
   GDR_CHECK_LAUNCH("beam_finalize_kernel");
