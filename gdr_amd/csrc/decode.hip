@@ -763,9 +763,11 @@ static int beam_end(const BeamBufs& bb, const BeamDims& bd, int max_length, int 
 // concurrently, the adaptor on a side stream forked / joined with events (graph-capturable pattern).  Side streams are
 // leased per CALL from a per-device pool (created on first use on the device that is current in the calling thread), so
 // concurrent gdr_t5_generate calls from several host threads or on several devices never share one.
+constexpr int SIDE_MAX_LAYERS = 48;
 struct SideStream {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
+  hipEvent_t ckv[SIDE_MAX_LAYERS] = {};  // "cross-attention K/V of layer l are projected" (gdr_t5_generate, before step 0)
   int dev = -1;
 };
 static std::mutex g_side_mu;
@@ -791,6 +793,11 @@ static SideStream* side_stream_acquire() {
     delete x;  // the caller falls back to running the adaptor chain on the main stream
     return nullptr;
   }
+  for (int l = 0; l < SIDE_MAX_LAYERS; ++l)
+    if (hipEventCreateWithFlags(&x->ckv[l], hipEventDisableTiming) != hipSuccess) {
+      delete x;
+      return nullptr;
+    }
   return x;
 }
 // A lease ends when the call has finished ENQUEUEING: the stream is in-order, so the next lessee's work simply queues
@@ -891,7 +898,7 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
   g.qkv_c = carve(o, 4 * rows * 3 * d);                 // prefix-table mode: (q,k,v) of the compacted rows
   const size_t abf_main = rows * ffw > (size_t)bd.B * L * d ? rows * ffw : (size_t)bd.B * L * d;
   g.abf = carve(o, 2 * abf_main);                       // bf16 mode: the rounded activation operand of a linear (main stream)
-  g.abf2 = carve(o, 2 * rows * ffw);                    //            ... of the adaptor chain (side stream)
+  g.abf2 = carve(o, 2 * abf_main);                      //            ... of the side stream (adaptor chain, cross K/V projections)
   g.total = o;
   return g;
 }
@@ -994,10 +1001,32 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
     set_error("generate: memset of the stream-K flags failed");
     return GDR_EHIP;
   }
-  // cross-attention K/V once per query and layer (modeling_t5.py:365-368 recomputes them per beam row per step)
-  for (int l = 0; l < dm.num_layers; ++l)
-    GDR_TRY(LIN(enc_hidden, d, w->layers[l].wkv_c, d, crosskv + l * ckv_layer, 2 * inner, (int64_t)B * L,
-                              2 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
+  SideLease lease;
+  struct { bool ok; hipStream_t s; hipEvent_t fork, join; } ss{lease.ss != nullptr, lease.ss ? lease.ss->s : nullptr,
+                                                            lease.ss ? lease.ss->fork : nullptr, lease.ss ? lease.ss->join : nullptr};
+  // cross-attention K/V once per query and layer (modeling_t5.py:365-368 recomputes them per beam row per step).  They
+  // depend on the encoder states only: with a side stream they are projected THERE (the adaptor chain's scratch), layer by
+  // layer, while the main stream already runs step 0 — a chain of small latency-bound kernels over one row per query that
+  // leaves most of the chip idle — and layer l's cross-attention of step 0 waits for layer l's event.
+  const bool ckv_side = ss.ok && dm.num_layers <= SIDE_MAX_LAYERS;
+  if (ckv_side) {
+    if (hipEventRecord(ss.fork, stream) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess) {
+      set_error("generate: fork to the side stream failed");
+      return GDR_EHIP;
+    }
+    for (int l = 0; l < dm.num_layers; ++l) {
+      GDR_TRY(dec_linear(bf16, abf2, enc_hidden, d, w->layers[l].wkv_c, d, crosskv + l * ckv_layer, 2 * inner, (int64_t)B * L, nullptr,
+                         2 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0, skw2, ss.s, &sk2));
+      if (hipEventRecord(lease.ss->ckv[l], ss.s) != hipSuccess) {
+        set_error("generate: event record on the side stream failed");
+        return GDR_EHIP;
+      }
+    }
+  } else {
+    for (int l = 0; l < dm.num_layers; ++l)
+      GDR_TRY(LIN(enc_hidden, d, w->layers[l].wkv_c, d, crosskv + l * ckv_layer, 2 * inner, (int64_t)B * L,
+                                2 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
+  }
 
   static const bool slab_q_on = [] {
     const char* e = getenv("GDR_DECODE_SLAB_Q");  // A/B knob: 0 = reduce the cross-attention q projection in its own launch
@@ -1006,9 +1035,6 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   const BucketLut lut_uni = make_bucket_lut(dm.rel_buckets, dm.rel_max_distance);
   const BucketLut lut_bi = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
   int cur = 0;
-  SideLease lease;
-  struct { bool ok; hipStream_t s; hipEvent_t fork, join; } ss{lease.ss != nullptr, lease.ss ? lease.ss->s : nullptr,
-                                                            lease.ss ? lease.ss->fork : nullptr, lease.ss ? lease.ss->join : nullptr};
   for (int s = 0; s + 1 < max_length; ++s) {  // position s, cur_len = s + 1 (generation_utils.py:676)
     hipStream_t as = ss.ok ? ss.s : stream;   // adaptor stream
     // Step 0: the R beam rows of a query hold the same START token and the same encoder states, so their decoder /
@@ -1132,6 +1158,10 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       ca.key_mask = enc_mask, ca.mask_bstride = L, ca.causal = 0, ca.causal_neg_inf = 0;
       ca.kv_rows = nullptr, ca.kv_group = 1;
       if (q_from_slabs && qsl.S > 1) ca.q_part = qsl.part, ca.q_S = qsl.S, ca.q_tiles_n = qsl.tiles_n;
+      if (s == 0 && ckv_side && hipStreamWaitEvent(stream, lease.ss->ckv[l], 0) != hipSuccess) {
+        set_error("generate: wait for the cross K/V of layer %d failed", l);
+        return GDR_EHIP;
+      }
       GDR_TRY(launch_attention(ca, stream));
       GDR_TRY(LINN(ctx, inner, ly.wo_c, inner, xd, d, rows_s, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, rms(ly.ln_ff, nx)));
       GDR_TRY(LIN(nx, d, ly.wi, d, ff, dm.d_ff, rows_s, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0));
