@@ -335,7 +335,8 @@ class T5EncoderHandle:
         ragged=False: gdr_t5_encoder_forward — every row, PAD positions included, exactly as the reference computes them.
         ragged=True : gdr_t5_encoder_forward_ragged — PAD rows are not computed (kept rows bit-identical, PAD rows of the
         returned hidden states are zero); with want_hidden=False only h[:,0] is carried through the last block.
-        live_rows_hint: number of kept token rows if the caller knows it (profiler accounting only)."""
+        live_rows_hint: number of kept token rows if the caller knows it — a tuning input (the launcher chooses between
+        bit-identical kernel forms by the tile count it implies; the profiler prices flops with it), never a result input."""
         _need_cuda(input_ids, attention_mask)
         ids = input_ids.to(torch.int64).contiguous()
         B, L = ids.shape

@@ -139,8 +139,10 @@ int gdr_t5_encoder_forward(const GdrT5EncoderWeights* w, const int64_t* ids, con
  *   - out_pooled (may be NULL; one of the two must be given) = hidden[:,0].  With out_hidden == NULL the last block's
  *     o / wi / wo and the final norm run on the B CLS rows only.
  *   - the live-row count is derived from the mask ON THE DEVICE; kernels read it, the call never synchronises.
- *     live_rows_hint: that count if the host happens to know it, else -1 — read only by the opt-in profiler's flop
- *     accounting (gdr_prof_*), never by the computation.
+ *     live_rows_hint: that count if the host happens to know it, else -1 — a TUNING input: the launcher picks between
+ *     kernel forms that are bit-identical to one another (whole tiles, the stream-K tail, the 256-workgroup launch) by the
+ *     tile count it implies, and the opt-in profiler (gdr_prof_*) prices flops with it; a wrong or absent hint can cost
+ *     speed, never a bit of the result.
  * Batches of fewer than 256 token rows, or d_kv != 64, run the padded form internally (same outputs); below 4 096 token
  * rows the packed form runs on the split-K / stream-K kernel forms the padded forward picks for the same B*L (kept rows
  * still bit-identical) and the pooled-only shortcut of the last block is not taken. */
