@@ -141,6 +141,13 @@ def lib():
             raise GdrError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C gdr_amd/csrc`). gdr_amd has no CPU fallback.")
+        if not os.environ.get("GDR_FFI_NO_TORCH"):
+            # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so): it must be the one already in the process
+            # when this library's dependency on libamdhip64 is resolved.  Loaded the other way round (this library first,
+            # e.g. build() then smoke() in one process) the process ends up with /opt/rocm's runtime under torch's
+            # allocator and streams, and the first hipMemsetAsync on a torch stream fails.  (The host-sanitizer test sets
+            # GDR_FFI_NO_TORCH: it never touches a GPU.)
+            import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)            # AttributeError if the .so lacks a declared symbol

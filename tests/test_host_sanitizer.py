@@ -118,7 +118,7 @@ def test_host_side_is_clean_under_asan_and_ubsan():
     p = subprocess.run(["make", "-C", os.path.join(REPO, "gdr_amd", "csrc"), "asan", "-j8"], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lib = os.path.join(REPO, "gdr_amd", "libgdr_hip_asan.so")
-    env = dict(os.environ, LD_PRELOAD=rt[-1], GDR_HIP_LIB=lib, PYTHONPATH=REPO,
+    env = dict(os.environ, LD_PRELOAD=rt[-1], GDR_HIP_LIB=lib, PYTHONPATH=REPO, GDR_FFI_NO_TORCH="1",
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1:exitcode=97:verify_asan_link_order=0",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     r = subprocess.run([sys.executable, "-c", CHILD, REPO], env=env, capture_output=True, text=True, timeout=600)
