@@ -263,6 +263,35 @@ __global__ __launch_bounds__(256) void prefix_fill_kernel(BeamBufs bb, int rows,
   }
 }
 
+// xd[r] = table[tok[r]] and nx[r] = T5LayerNorm(xd[r]; w) in one launch: the embedding of a decode step and the first norm
+// of the decoder stack (modeling_t5.py:725, :164-171), arithmetic of rmsnorm_kernel (layers.hip).  One wave per row.
+__global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const float* __restrict__ table, const int64_t* __restrict__ tok,
+                                                            int rows, int d4, int vocab, const float* __restrict__ w, float eps,
+                                                            float* __restrict__ xd, float* __restrict__ nx) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  int64_t id = tok[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float4* src = reinterpret_cast<const float4*>(table) + id * d4;
+  float4* xr = reinterpret_cast<float4*>(xd) + (int64_t)row * d4;
+  float ss = 0.f;
+  for (int c = lane; c < d4; c += 64) {
+    const float4 v = src[c];
+    xr[c] = v;
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float denom = sqrtf(ss / (float)(d4 * 4) + eps);
+  float4* yr = reinterpret_cast<float4*>(nx) + (int64_t)row * d4;
+  const float4* wr = reinterpret_cast<const float4*>(w);
+  for (int c = lane; c < d4; c += 64) {
+    const float4 v = src[c], g = wr[c];
+    yr[c] = make_float4(g.x * (v.x / denom), g.y * (v.y / denom), g.z * (v.z / denom), g.w * (v.w / denom));
+  }
+}
+
 // out[i] = table[tok[rows_map[i]]] for i < *n_dev
 __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ tok,
                                                          const int32_t* __restrict__ rows_map,
@@ -536,6 +565,20 @@ __device__ __forceinline__ void hyp_add(HypLds& H, const BeamDims& bd, const int
   }
 }
 
+// The ancestor table of a query's R rows for the position about to be processed (pos = cur_len: the new rows have length
+// cur_len + 1): position p < pos is inherited from the row's parent, position pos is the row itself.  Runs at the end of
+// beam_update_kernel (the parents were written by this workgroup: visible after its barrier) — a launch of its own in round 2.
+__device__ __forceinline__ void anc_update_query(const BeamBufs& bb, const BeamDims& bd, int b, int pos, int cur, int tid) {
+  __syncthreads();
+  const int R = bd.R, ml = bd.maxlen, stride = pos + 1, rows = bd.B * R;
+  for (int e = tid; e < R * stride; e += 256) {
+    const int j = e / stride, p = e - j * stride, r = b * R + j;
+    const int a = p < pos ? bb.anc[cur][(size_t)bb.parent[r] * ml + p] : r;
+    bb.anc[cur ^ 1][(size_t)r * ml + p] = a;
+    bb.kv_rows[(size_t)r * stride + p] = p * rows + a;
+  }
+}
+
 // The host loop of generation_utils.py:783-850, one workgroup of four waves per query.  What that loop decides is fixed
 // by the ranked candidate list alone: the next beams are the first R non-EOS candidates, and the EOS candidates that are
 // offered to the hypothesis heap are those of rank < R that come before the R-th non-EOS one — so the non-EOS ranks are
@@ -560,6 +603,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamBufs bb, BeamDims 
       const int j = e / (cur_len + 1), t = e - j * (cur_len + 1);
       seq_n[(size_t)(b * R + j) * ml + t] = t < cur_len ? seq_c[(size_t)(b * R) * ml + t] : PAD_ID;
     }
+    anc_update_query(bb, bd, b, cur_len, cur, tid);
     return;
   }
   int32_t* sel = reinterpret_cast<int32_t*>(bsm + ((hyp_lds_bytes(R, ml) + 15) & ~(size_t)15));  // [R] chosen candidate ranks
@@ -635,17 +679,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamBufs bb, BeamDims 
     const int beam = flat / bd.Vd, tok = flat % bd.Vd;
     seq_n[(size_t)(b * R + j) * ml + t] = t < cur_len ? seq_c[(size_t)(b * R + beam) * ml + t] : tok;
   }
-}
-
-// Rebuild the ancestor table for the position about to be processed (pos = new row length - 1).
-__global__ void anc_update_kernel(BeamBufs bb, int rows, int maxlen, int pos, int cur) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int stride = pos + 1;
-  if (e >= rows * stride) return;
-  const int r = e / stride, p = e - r * stride;
-  const int a = p < pos ? bb.anc[cur][(size_t)bb.parent[r] * maxlen + p] : r;
-  bb.anc[cur ^ 1][(size_t)r * maxlen + p] = a;
-  bb.kv_rows[(size_t)r * stride + p] = p * rows + a;
+  anc_update_query(bb, bd, b, cur_len, cur, tid);
 }
 
 // :862-919 finalise open beams, pick the nret best per query, lay out tokens / EOS / PAD.  One wave per query.
@@ -723,7 +757,6 @@ static int check_beam_dims(const BeamDims& bd, int max_length) {
 // One decode step's beam machinery after bb.logits holds the step's unmasked-column logits.
 static int beam_step(const BeamBufs& bb, const BeamDims& bd, int pos, int cur, float* step_scores,
                      int32_t* step_tokens, hipStream_t stream, bool bcast = false) {
-  const int rows = bd.B * bd.R;
   const int npad = next_pow2i(bd.R * (bd.V + 1));
   const size_t lds = (size_t)npad * 8 + (size_t)bd.R * 8 + (size_t)bd.R * (bd.V + 1) * 4;
   const size_t tr = (size_t)pos * bd.B * 2 * bd.R;
@@ -733,10 +766,7 @@ static int beam_step(const BeamBufs& bb, const BeamDims& bd, int pos, int cur, f
   const size_t hyp_lds = ((hyp_lds_bytes(bd.R, bd.maxlen) + 15) & ~(size_t)15) + (size_t)bd.R * 4 + (size_t)bd.R * 16;
   hipLaunchKernelGGL(beam_update_kernel, dim3(bd.B), dim3(256), hyp_lds, stream, bb, bd, pos + 1, cur);
   GDR_CHECK_LAUNCH("beam_update_kernel");
-  const int n = rows * (pos + 2);
-  hipLaunchKernelGGL(anc_update_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, bb, rows, bd.maxlen, pos + 1, cur);
-  GDR_CHECK_LAUNCH("anc_update_kernel");
-  return GDR_OK;
+  return GDR_OK;  // the ancestor table of the next position is rebuilt at the end of beam_update_kernel
 }
 
 static int beam_begin(const BeamBufs& bb, const BeamDims& bd, hipStream_t stream, bool dedup0 = false) {
@@ -1043,7 +1073,9 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
     // ancestor at position 0 is b, beam_init_kernel) and beam_topk_kernel reads the query's logits for all of its beams.
     const int rows_s = (s == 0 && dedup0) ? B : rows;
     const int R_s = (s == 0 && dedup0) ? 1 : num_beams;
-    GDR_TRY(launch_embed(w->dec_embed, bb.cur_tok, rows_s, d, dm.vocab_size, xd, stream));
+    hipLaunchKernelGGL(embed_rmsnorm_kernel, dim3((unsigned)((rows_s + 3) / 4)), dim3(256), 0, stream, w->dec_embed, bb.cur_tok, rows_s,
+                       d / 4, dm.vocab_size, w->layers[0].ln_self, dm.eps, xd, nx);
+    GDR_CHECK_LAUNCH("embed_rmsnorm_kernel");
     if (ss.ok) {
       if (hipEventRecord(ss.fork, stream) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess) {
         set_error("generate: fork to the adaptor stream failed");
@@ -1085,10 +1117,14 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       hipLaunchKernelGGL(prefix_fill_kernel, dim3(rows_s), dim3(256), 0, as, bb, rows_s, s + 1, cur, ptab->kv,
                          (int64_t)ptab->n_table * 3 * d, acache + s * aslab, (int64_t)alayer, w->adaptor_layers, 3 * d);
       GDR_CHECK_LAUNCH("prefix_fill_kernel");
-      hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)((rows_s + 3) / 4)), dim3(256), 0, as, w->dec_embed, bb.cur_tok,
-                         bb.miss_rows, nm, d / 4, dm.vocab_size, xa);
-      GDR_CHECK_LAUNCH("embed_rows_kernel");
+      if (s > 0) {  // at step 0 every row sits on the trie's root, a table node (n_table >= 1): nothing is compacted
+        hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)((rows_s + 3) / 4)), dim3(256), 0, as, w->dec_embed, bb.cur_tok,
+                           bb.miss_rows, nm, d / 4, dm.vocab_size, xa);
+        GDR_CHECK_LAUNCH("embed_rows_kernel");
+      }
     }
+    // prefix-table mode, step 0: the adaptor chain and the head GEMM would run over zero rows (34 launches that exit at once)
+    const bool adaptor_idle = ptab != nullptr && s == 0;
 #define LIN2D(A_, lda_, W_, ldw_, C_, ldc_, N_, K_, epi_, bias_, res_, ldr_) \
   dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, rows_s, nm, N_, K_, epi_, bias_, res_, ldr_, skw2, as, &sk2)
     auto ad_layer_tab = [&](int l) -> int {
@@ -1121,7 +1157,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       float* cache = dcache + l * dlayer;
       float* slot = cache + s * dslab;
       // every later RMS norm rides on the reduction of the residual linear in front of it (dec_linear_norm)
-      if (l == 0) GDR_TRY(launch_rmsnorm(xd, ly.ln_self, nx, rows_s, d, dm.eps, nullptr, 1, stream));
+      // (the first block's norm rides on the embedding launch: embed_rmsnorm_kernel)
       GDR_TRY(LIN(nx, d, ly.wqkv, d, slot, 3 * inner, rows_s, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
       AttnArgs at{};
       at.q = slot, at.k = cache + inner, at.v = cache + 2 * inner, at.out = ctx;
@@ -1174,9 +1210,9 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
     // the main stream idle for as long as those ~55 launches take to issue (measured: a fifth of a 100-beam step).
     for (int l = 0; l < dm.num_layers || l < w->adaptor_layers; ++l) {
       if (l < dm.num_layers) GDR_TRY(dec_layer(l));
-      if (l < w->adaptor_layers) GDR_TRY(ptab ? ad_layer_tab(l) : ad_layer_plain(l));
+      if (l < w->adaptor_layers && !adaptor_idle) GDR_TRY(ptab ? ad_layer_tab(l) : ad_layer_plain(l));
     }
-    if (ptab)  // the head GEMM of the compacted rows_s belongs to the adaptor chain (it needs nothing from the decoder stack)
+    if (ptab && !adaptor_idle)  // the head GEMM of the compacted rows belongs to the adaptor chain (it needs nothing from the decoder stack)
       GDR_TRY(LIN2D(xa, d, w_at(w->head_w, (size_t)s * V1 * d * d, bf16), d, A, (int64_t)V1 * d, V1 * d, d, GDR_EPI_NONE, nullptr,
                     nullptr, 0));
 #undef LIN2D
