@@ -139,5 +139,27 @@ with open(f"profiles/{tag}_mfma_busy.md", "w") as o:
     o.write("\nReading: for the fp32 GEMMs MFMA busy x clock / 2.4 GHz is the fraction of the 157.3 TFLOP/s peak that the issue "
             "stream could deliver; what bench.py reports as `roofline.frac` is lower by the tile-edge waste (rows past the live "
             "count are computed and discarded) and by the epilogue / prologue phases in which no MFMA is issued.\n")
+# ---------------------------------------------------------------------------------------------- the decode chain
+copy("generate_steps.txt", f"{tag}_generate_steps.txt")
+m, c = counters("pmc_mfma_generate/*/*counter_collection.csv"), counters("pmc_clk_generate/*/*counter_collection.csv")
+if m:
+    with open(f"profiles/{tag}_generate_mfma_busy.md", "w") as o:
+        o.write(f"# {tag} — MFMA utilisation of the decode chain's GEMM kernels (rocprofv3 --pmc on tools/prof_generate.py: 4 x generate(), "
+                "64 queries x 10 beams, prefix table)\n\nSame counters and formulae as the bench table (`{tag}_mfma_busy.md`): per launch "
+                "averages over all four calls; `grid` = threads.  The 64x64-tile split-K kernel of the decode linears is listed by grid: "
+                "122 880 threads = 480 workgroups (the N = 768 projections split 4 ways, wi un-split, wo split 4 ways), 92 160 = 360 (qkv / "
+                "in_proj), 163 840 = 640 (adaptor lin1).\n\n"
+                "| kernel | grid | launches | avg us | SQ_VALU_MFMA_BUSY_CYCLES | clock GHz | MFMA busy |\n|---|---|---|---|---|---|---|\n".replace("{tag}", tag))
+        for k in sorted(m, key=lambda k: -sum(m[k]["dur_ns"])):
+            if "gemm_nt" not in k[0]:
+                continue
+            dur = avg(m[k]["dur_ns"])
+            gui = avg(c[k]["GRBM_GUI_ACTIVE"]) if k in c else 0.0
+            dur_c = avg(c[k]["dur_ns"]) if k in c else 0.0
+            clk = gui / 8 / dur_c if dur_c else 0.0
+            busy = avg(m[k]["SQ_VALU_MFMA_BUSY_CYCLES"])
+            frac = busy / (1024 * dur * clk) if clk else 0.0
+            o.write(f"| `{short(k[0])[:48]}` | {k[1]} | {len(m[k]['dur_ns'])} | {dur / 1e3:.1f} | {busy:.3e} | {clk:.2f} | {frac:.3f} |\n")
+    print(open(f"profiles/{tag}_generate_mfma_busy.md").read())
 print(open(f"profiles/{tag}_mfma_busy.md").read())
 print(open(f"profiles/{tag}_bench_pmc_hbm.md").read()[-3000:])
