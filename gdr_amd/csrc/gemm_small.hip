@@ -26,7 +26,7 @@ struct SmallGemmArgs {
   const float* residual;
   int64_t lda, ldw, ldc, ldr;
   int64_t M;
-  int N, K, tiles_n;
+  int N, K, tiles_n, tiles_m, order;
   int has_bias, has_residual, act;  // 0 none, 1 relu, 2 gelu
   int ksplit, kchunk;               // kchunk in elements, multiple of 32
   const int64_t* m_dev;             // may be null: live row count on the device (<= M); tiles past it exit at once
@@ -43,8 +43,19 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_f32_small_kernel(const SmallGe
     const unsigned nblk = gridDim.x, q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
-  const int split = bid % (unsigned)g.ksplit;  // the splits of one tile are neighbours (same XCD: shared operand panels)
-  const unsigned tile = bid / (unsigned)g.ksplit;
+  // bid is now contiguous per XCD.  Row tile fastest, then column tile, K split slowest: the n/8 workgroups of an XCD
+  // then touch every row panel of A but only n/(8*tiles_m) column panels of W, all over ONE K range — the footprint that
+  // its L2 pulls through the Infinity Cache is (tiles_m + n/(8*tiles_m)) panels of kchunk instead of all of W over all of K.
+  int split;
+  unsigned tile;
+  if (g.order) {
+    const unsigned tiles = (unsigned)g.tiles_m * (unsigned)g.tiles_n, t = bid % tiles;
+    split = (int)(bid / tiles);
+    tile = (t % (unsigned)g.tiles_m) * (unsigned)g.tiles_n + t / (unsigned)g.tiles_m;
+  } else {
+    split = bid % (unsigned)g.ksplit;
+    tile = bid / (unsigned)g.ksplit;
+  }
   const int64_t m0 = (int64_t)(tile / (unsigned)g.tiles_n) * SB;
   const int n0 = (int)(tile % (unsigned)g.tiles_n) * SB;
   const int64_t Mrows = g.m_dev ? *g.m_dev : g.M;
@@ -300,6 +311,8 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
   g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr, g.M = M, g.N = N, g.K = K, g.tiles_n = tiles_n;
   g.ksplit = S, g.kchunk = chunk_steps * SBK;
   g.m_dev = m_dev;
+  static const int order = [] { const char* e = getenv("GDR_SMALL_ORDER"); return e ? atoi(e) : 1; }();
+  g.tiles_m = (int)tiles_m, g.order = order;
   const double flops = 2.0 * (double)M * (double)N * (double)K;
   if (ne && (S == 1 || N % 4 != 0 || N > 1024 || act > 1)) return 2;  // the fused norm needs split slabs of a row it can hold
   if (slabs) {
