@@ -26,7 +26,7 @@ struct SmallGemmArgs {
   const float* residual;
   int64_t lda, ldw, ldc, ldr;
   int64_t M;
-  int N, K, tiles_n, tiles_m, order;
+  int N, K, tiles_n, tiles_m;
   int has_bias, has_residual, act;  // 0 none, 1 relu, 2 gelu
   int ksplit, kchunk;               // kchunk in elements, multiple of 32
   const int64_t* m_dev;             // may be null: live row count on the device (<= M); tiles past it exit at once
@@ -46,16 +46,11 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_f32_small_kernel(const SmallGe
   // bid is now contiguous per XCD.  Row tile fastest, then column tile, K split slowest: the n/8 workgroups of an XCD
   // then touch every row panel of A but only n/(8*tiles_m) column panels of W, all over ONE K range — the footprint that
   // its L2 pulls through the Infinity Cache is (tiles_m + n/(8*tiles_m)) panels of kchunk instead of all of W over all of K.
-  int split;
-  unsigned tile;
-  if (g.order) {
-    const unsigned tiles = (unsigned)g.tiles_m * (unsigned)g.tiles_n, t = bid % tiles;
-    split = (int)(bid / tiles);
-    tile = (t % (unsigned)g.tiles_m) * (unsigned)g.tiles_n + t / (unsigned)g.tiles_m;
-  } else {
-    split = bid % (unsigned)g.ksplit;
-    tile = bid / (unsigned)g.ksplit;
-  }
+  // (Measured on MI355X: generate() is unchanged to +-0.3 % against the old split-fastest, row-major order — these launches
+  // are not bound by where their operands come from, profiles/r03_small_gemm_tile_order_ab.txt — so this is traffic, not time.)
+  const unsigned tiles = (unsigned)g.tiles_m * (unsigned)g.tiles_n, t = bid % tiles;
+  const int split = (int)(bid / tiles);
+  const unsigned tile = (t % (unsigned)g.tiles_m) * (unsigned)g.tiles_n + t / (unsigned)g.tiles_m;  // slab index stays row-major
   const int64_t m0 = (int64_t)(tile / (unsigned)g.tiles_n) * SB;
   const int n0 = (int)(tile % (unsigned)g.tiles_n) * SB;
   const int64_t Mrows = g.m_dev ? *g.m_dev : g.M;
@@ -311,8 +306,7 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
   g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr, g.M = M, g.N = N, g.K = K, g.tiles_n = tiles_n;
   g.ksplit = S, g.kchunk = chunk_steps * SBK;
   g.m_dev = m_dev;
-  static const int order = [] { const char* e = getenv("GDR_SMALL_ORDER"); return e ? atoi(e) : 1; }();
-  g.tiles_m = (int)tiles_m, g.order = order;
+  g.tiles_m = (int)tiles_m;
   const double flops = 2.0 * (double)M * (double)N * (double)K;
   if (ne && (S == 1 || N % 4 != 0 || N > 1024 || act > 1)) return 2;  // the fused norm needs split slabs of a row it can hold
   if (slabs) {

@@ -10,6 +10,8 @@
 //   halves cover one 128-B line) + 4 ds_read_b128 of the Q fragments (row stride d+4 floats: conflict-free) +
 //   16 v_mfma_f32_32x32x2_f32; the k index inside a group is permuted identically on both operands.
 // Epilogues are those of the GEMM core: store the strided sample / compare with thr[q] and append survivors.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gdr {
@@ -23,6 +25,7 @@ struct StreamArgs {
   int B, d;
   int64_t n_tiles;   // 128-doc tiles of this launch
   SimEpilogue sim;
+  int capl;          // filter pass: survivors a workgroup collects per query in LDS before its ONE append to the query's list
 };
 
 #ifndef STREAM_THREADS
@@ -47,6 +50,18 @@ __global__ __launch_bounds__(STREAM_THREADS) void sim_stream_f32_kernel(const St
   const float thr = (MODE == 2 && l31 < g.B) ? g.sim.thr[l31] : 0.f;
   float* cv = g.sim.cand_val + (int64_t)l31 * g.sim.cap;
   int32_t* ci = g.sim.cand_idx + (int64_t)l31 * g.sim.cap;
+  // Filter pass: survivors go to per-workgroup lists in LDS and reach the query's global list with ONE returning atomic per
+  // (workgroup, query) at the end.  One atomic per (32-doc slice, query) on 32 shared counters was ~4 000 same-address
+  // atomics per counter (~12 ns each, serialised in L2): the pass took 222 us at 32 queries against 174 us at one.  A list that
+  // fills up (capl entries; the expected load is ~1/9 of it) sends the rest of that query's survivors down the direct path;
+  // lfirst[q] = the LDS count at the first reservation that did not fit = the number of entries that are really there.
+  const int capl = MODE == 2 ? g.capl : 0;
+  int* lcnt = reinterpret_cast<int*>(qs + 32 * QS);  // [32]
+  int* lfirst = lcnt + 32;                           // [32]
+  float* lval = reinterpret_cast<float*>(lfirst + 32);  // [32][capl]
+  int* lidx = reinterpret_cast<int*>(lval + 32 * capl);  // [32][capl]
+  if (capl && tid < 32) lcnt[tid] = 0, lfirst[tid] = capl;
+  if (capl) __syncthreads();
 
   const int64_t n_units = g.n_tiles * 4;  // 32-doc slices
   for (int64_t u = (int64_t)blockIdx.x * STREAM_WAVES + wave; u < n_units; u += (int64_t)gridDim.x * STREAM_WAVES) {
@@ -133,22 +148,58 @@ __global__ __launch_bounds__(STREAM_THREADS) void sim_stream_f32_kernel(const St
         }
         const int mine = __popc(keep);
         const int other = __shfl_xor(mine, 32);
+        const int total = mine + other;
         int base = 0;
-        if (h == 0 && mine + other > 0) base = atomicAdd(g.sim.cand_cnt + l31, mine + other);
-        base = __shfl(base, l31);
-        int pos = base + (h ? other : 0);
-        if (mine) {
+        bool local = false;
+        if (capl) {
+          if (h == 0 && total > 0) {
+            base = atomicAdd(lcnt + l31, total);  // LDS
+            local = base + total <= capl;
+            if (!local) atomicMin(lfirst + l31, base);
+          }
+          local = __shfl((int)local, l31) != 0;
+        }
+        if (local) {
+          base = __shfl(base, l31);
+          int pos = l31 * capl + base + (h ? other : 0);
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (keep >> r & 1u) {
-              if (pos < g.sim.cap) {
-                cv[pos] = acc[r];
-                ci[pos] = (int)(m0 + (r & 3) + 8 * (r >> 2) + 4 * h);
-              }
+              lval[pos] = acc[r];
+              lidx[pos] = (int)(m0 + (r & 3) + 8 * (r >> 2) + 4 * h);
               ++pos;
             }
+        } else {
+          if (h == 0 && total > 0) base = atomicAdd(g.sim.cand_cnt + l31, total);
+          base = __shfl(base, l31);
+          int pos = base + (h ? other : 0);
+          if (mine) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (keep >> r & 1u) {
+                if (pos < g.sim.cap) {
+                  cv[pos] = acc[r];
+                  ci[pos] = (int)(m0 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                }
+                ++pos;
+              }
+          }
         }
       }
+    }
+  }
+  if (capl) {  // flush: wave w appends the lists of queries w, w + 8, ...
+    __syncthreads();
+    for (int q = wave; q < g.B; q += STREAM_WAVES) {
+      const int n = min(lcnt[q], lfirst[q]);
+      if (n <= 0) continue;  // wave-uniform
+      int gbase = 0;
+      if (lane == 0) gbase = atomicAdd(g.sim.cand_cnt + q, n);
+      gbase = __shfl(gbase, 0);
+      float* qv = g.sim.cand_val + (int64_t)q * g.sim.cap;
+      int32_t* qi = g.sim.cand_idx + (int64_t)q * g.sim.cap;
+      for (int i = lane; i < n; i += 64)
+        if (gbase + i < g.sim.cap) qv[gbase + i] = lval[q * capl + i], qi[gbase + i] = lidx[q * capl + i];
     }
   }
 }
@@ -230,7 +281,15 @@ int launch_sim_stream(const float* D, int64_t N, const float* Q, int B, int d, c
   const int64_t n_sample_tiles = (tiles_m + ep.tile_stride - 1) / ep.tile_stride;
   g.n_tiles = ep.mode == 1 ? n_sample_tiles : tiles_m - n_sample_tiles;
   if (g.n_tiles <= 0) return GDR_OK;
-  const size_t lds = (size_t)32 * (d + 4) * sizeof(float);
+  size_t lds = (size_t)32 * (d + 4) * sizeof(float);
+  const size_t lds_q = lds;
+  if (ep.mode == 2) {  // per-workgroup survivor lists beside the queries: up to 192 entries per query, what LDS leaves otherwise
+    static const int capl_max = [] { const char* e = getenv("GDR_SIM_LOCAL_LIST"); return e ? atoi(e) : 192; }();
+    int64_t room = ((int64_t)160 * 1024 - (int64_t)lds_q - 256) / (32 * 8);
+    room = room > capl_max ? capl_max : room;
+    g.capl = room >= 16 ? (int)(room & ~7) : 0;
+    if (g.capl) lds += 256 + (size_t)32 * g.capl * 8;
+  }
   for (const void* fn : {reinterpret_cast<const void*>(sim_stream_f32_kernel<1>),
                          reinterpret_cast<const void*>(sim_stream_f32_kernel<2>),
                          reinterpret_cast<const void*>(sim_stream_sample_splitk_kernel)})
@@ -239,7 +298,7 @@ int launch_sim_stream(const float* D, int64_t N, const float* Q, int B, int d, c
   if (blocks > 256) blocks = 256;  // persistent: one workgroup per CU
   const double rows = (double)(g.n_tiles * 128 < N ? g.n_tiles * 128 : N);
   ProfScope prof(ep.mode == 1 ? PROF_SIM_SAMPLE : PROF_SIM_FILTER, 2.0 * rows * B * d, stream);
-  const size_t lds_split = lds + (size_t)STREAM_WAVES * 16 * 64 * sizeof(float);
+  const size_t lds_split = lds_q + (size_t)STREAM_WAVES * 16 * 64 * sizeof(float);
   if (ep.mode == 1 && g.n_tiles * 4 <= 128 * STREAM_WAVES && lds_split <= 160 * 1024)  // fewer slices than half the waves
     hipLaunchKernelGGL(sim_stream_sample_splitk_kernel, dim3((unsigned)(g.n_tiles * 4)), dim3(STREAM_THREADS), lds_split,
                        stream, g);

@@ -63,3 +63,35 @@ def test_decode_scheduling_switches_do_not_change_generate():
             for r in np.nonzero(~same & live)[0]:
                 assert abs(sa[r] - sb[r]) <= 1e-4 * max(1.0, abs(sa[r])), f"{env} {key} row {r}"
             assert same[live].mean() > 0.97, f"{env} {key}: {same[live].mean():.3f} of the live hypotheses identical"
+
+
+SIM_CHILD = r"""
+import json, sys, torch
+sys.path.insert(0, sys.argv[1])
+from gdr_amd import ops, synth
+torch.set_grad_enabled(False)
+dev = torch.device("cuda:0")
+D = torch.from_numpy(synth.make_corpus(200000, 768, seed=5)).to(dev)
+out = {}
+for B in (1, 7, 32):
+    Qn, _ = synth.make_queries(D[:20000].cpu().numpy(), B, seed=40 + B)
+    vals, idx, status = ops.sim_topk(torch.from_numpy(Qn).to(dev), D, 100, exact_on_overflow=False, return_status=True)
+    out[str(B)] = {"idx": idx.cpu().tolist(), "val": [float(x) for x in vals.flatten().cpu()], "status": int(status.max())}
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_latency_mode_filter_lists_local_full_and_direct_agree():
+    """sim_stream_f32_kernel<2> collects a workgroup's survivors per query in LDS and appends them with one atomic per
+    (workgroup, query).  The lists are an unordered set until the select pass sorts them by (score, id), so the result must be
+    bit-identical whether every survivor goes through LDS (default), the LDS lists overflow and the rest is appended directly
+    (16 entries per query: the expected load is above that), or LDS is not used at all (0)."""
+    def run(v):
+        r = subprocess.run([sys.executable, "-c", SIM_CHILD, ROOT], env=dict(os.environ, GDR_SIM_LOCAL_LIST=v),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
+    base = run("192")
+    assert all(v["status"] == 0 for v in base.values())
+    assert run("16") == base
+    assert run("0") == base
