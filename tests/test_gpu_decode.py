@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+from conftest import golden, ranked_lists_match
 from gdr_amd.config import GDRConfig
 from gdr_amd import synth
 
@@ -282,8 +282,10 @@ def test_generate_bf16_mode_vs_oracle_emulation(dev, kind, B, R, use_table):
     (fp32 summation order decides a bf16 ulp), so parity is stated at bf16 tolerance:
       * the first decode step's top-2R scores (same inputs on both sides: the START token) to 5e-3;
       * final hypothesis scores to 3e-2 relative (SURVEY §8d) against the emulation AND against the fp32 oracle;
-      * ids: per query at least 70 % of the returned hypotheses are the emulation's, the best one exactly when its margin
-        to the runner-up exceeds the tolerance."""
+      * ids: compared rank by rank with the tolerance-tie rule (conftest.ranked_lists_match): a hypothesis may differ from the
+        emulation's only inside a group of hypotheses whose scores are closer than the bf16 noise — the number of ids that
+        differ OUTSIDE such groups is asserted to be 0; in addition at least 70 % of the returned hypotheses are the
+        emulation's, the best one exactly when its margin to the runner-up exceeds the tolerance."""
     from gdr_amd import codec, ops
     from oracle import beam_ref, t5_ref
     cfg = GDRConfig.tiny() if kind == "tiny" else GDRConfig.base()
@@ -320,12 +322,16 @@ def test_generate_bf16_mode_vs_oracle_emulation(dev, kind, B, R, use_table):
     np.testing.assert_allclose(sc, fs, rtol=3e-2, atol=3e-2)
     got, ref = dec.cpu().numpy(), rd.numpy()
     W = min(got.shape[1], ref.shape[1])
+    permuted = 0
     for b in range(B):
-        gset = {tuple(r[:W]) for r in got[b * R:(b + 1) * R].tolist()}
-        rset = {tuple(r[:W]) for r in ref[b * R:(b + 1) * R].tolist()}
+        glist = [tuple(r[:W]) for r in got[b * R:(b + 1) * R].tolist()]
+        rlist = [tuple(r[:W]) for r in ref[b * R:(b + 1) * R].tolist()]
+        gset, rset = set(glist), set(rlist)
         assert len(gset & rset) >= 0.7 * R, (b, len(gset & rset))
+        permuted += ranked_lists_match(rlist, rs[b], glist, 1.5e-2)     # raises on an id that differs outside a tie group
         if rs[b, 0] - rs[b, 1] > 3e-2 * (1 + abs(rs[b, 0])):
             assert tuple(got[b * R][:W]) == tuple(ref[b * R][:W])
+    print(f"bf16 generate {kind} R={R} table={use_table}: {permuted} slots permuted inside tolerance-tie groups, 0 ids differ outside them")
 
 
 def test_generate_graph_replay_is_identical(dev):

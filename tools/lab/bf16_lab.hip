@@ -33,6 +33,7 @@ struct SkArgs {
     bid = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + j_;                               \
   }
 
+template <int OUT_BF16 = 0>
 __device__ __forceinline__ void epilogue_tile(const Args& g, f32x4b (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int r16,
                                               int q4) {
 #pragma unroll
@@ -51,11 +52,21 @@ __device__ __forceinline__ void epilogue_tile(const Args& g, f32x4b (&acc)[4][4]
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
       }
-      *reinterpret_cast<float4*>(g.C + m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+      if (OUT_BF16) {
+        union {
+          __bf16 h[4];
+          uint2 u;
+        } o;
+        o.h[0] = (__bf16)v[0], o.h[1] = (__bf16)v[1], o.h[2] = (__bf16)v[2], o.h[3] = (__bf16)v[3];
+        *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(g.C) + m * g.ldc + n) = o.u;
+      } else {
+        *reinterpret_cast<float4*>(g.C + m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+      }
     }
   }
 }
 
+template <int OUT_BF16 = 0>
 __global__ __launch_bounds__(256, 3) void one_tile_kernel(const Args g) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * 128 * 128];
   char* const As = smem;
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(256, 3) void one_tile_kernel(const Args g) {
     }
     __syncthreads();
   }
-  epilogue_tile(g, acc, m0, n0, wm, wn, r16, q4);
+  epilogue_tile<OUT_BF16>(g, acc, m0, n0, wm, wn, r16, q4);
 }
 
 // Persistent + stream-K tail.  WPC = workgroups per CU the launch bound allows.
@@ -689,8 +700,9 @@ int main(int argc, char** argv) {
       Args g{A, W, C0, R, s.K, s.K, s.N, s.N, M, s.N, s.K, s.N / 128, s.res, s.act};
       const int tiles = ((M + 127) / 128) * g.tiles_n;
       const double flop = 2.0 * M * s.N * s.K;
-      const double t0 = time_us([&] { hipLaunchKernelGGL(one_tile_kernel, dim3(tiles), dim3(256), 0, 0, g); }, 50);
-      printf("M=%5d %-3s tiles=%4d  one-tile %7.1f us %6.0f TF/s |", M, s.name, tiles, t0, flop / t0 / 1e6);
+      const double t0 = time_us([&] { hipLaunchKernelGGL(one_tile_kernel<0>, dim3(tiles), dim3(256), 0, 0, g); }, 50);
+      const double t0b = time_us([&] { hipLaunchKernelGGL(one_tile_kernel<1>, dim3(tiles), dim3(256), 0, 0, g); }, 50);
+      printf("M=%5d %-3s tiles=%4d  one-tile %7.1f us %6.0f TF/s (bf16-out %6.1f us) |", M, s.name, tiles, t0, flop / t0 / 1e6, t0b);
       h0.resize((size_t)M * s.N);
       CK(hipMemcpy(h0.data(), C0, h0.size() * 4, hipMemcpyDeviceToHost));
       Args g1 = g;
