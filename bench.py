@@ -192,7 +192,7 @@ def stages(dev, cfg, D, D_dev, a):
     out["similarity_topk_f32"] = sim
     # ---- docid beam decode (generate()) and the two-stage path, t5-base with the GDR head
     sd = synth.make_state_dict(cfg, seed=1234)
-    names, depth, offsets, members = synth.make_cluster_ids(N, cluster_size=12, V=30)
+    names, id_depth, offsets, members = synth.make_cluster_ids(N, cluster_size=12, V=30)
     t0 = time.perf_counter()
     model = GDRModel(cfg, sd, dev, ragged=True, prefix_trie=codec.Trie.from_docids(names, 30))
     torch.cuda.synchronize()
@@ -280,6 +280,33 @@ def stages(dev, cfg, D, D_dev, a):
                     "host post-processes the previous one"}
     out["generate"] = gen
     out["generate"]["mflop_per_row_step"] = {"decoder": mf_dec, "adaptor": mf_adp, "head": mf_head}
+    # ---- the trie-constrained mode (opt-in, generation_utils_previous.py:714-729): every hypothesis is a
+    # docid of the corpus, so every beam has ended two steps after the deepest leaf and the call leaves its step loop there
+    # (`if all(done): break`, generation_utils.py:836-838) — what a trained model does without the constraint, and what the
+    # random weights of the stages above never do (they run all 9 steps)
+    from gdr_amd import _ffi
+    model.trie = tab.device_trie
+    real = codec.ClusterIndex(names, offsets, members)
+    con = {}
+    for B, R in ((64, 10), (1, 100)):
+        ids, mask = synth.make_tokens(B, L=40, seed=11)
+        ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+        g = lambda: model.generate(ids, attention_mask=mask, max_length=10, num_beams=R, length_penalty=0.8,   # noqa: E731
+                                   num_return_sequences=R, output_scores=True, output_encoder_embedding=True)
+        n0 = _ffi.lib().gdr_t5_generate_early_exits()
+        t = timed(g, reps=5, warm=2)
+        t_enc = timed(lambda: model.enc.forward(ids, mask, want_pooled=False, ragged=True), reps=5, warm=1)
+        a_r = types.SimpleNamespace(**{**vars(args), "num_return_sequences": R})
+        retr_c = GDRRetriever(model, D_dev, real, a_r)
+        batch = {"source_ids": ids, "source_mask": mask}
+        t3 = timed(lambda: retr_c.validation_step_i(batch), reps=5, warm=2)
+        con[f"B{B}_beam{R}"] = {"generate_ms": t * 1e3, "decode_ms": (t - t_enc) * 1e3, "two_stage_ms": t3 * 1e3,
+                                "two_stage_queries_per_s": B / t3, "docid_depth": id_depth,
+                                "calls_that_left_the_loop_early": int(_ffi.lib().gdr_t5_generate_early_exits() - n0)}
+    con["note"] = ("beams constrained to the corpus' docid trie (depth %d + EOS): all queries are done after ~%d of the 9 steps; the "
+                   "steps already enqueued skip their linears on the device and the host stops enqueueing" % (id_depth, id_depth + 2))
+    out["generate_trie_constrained"] = con
+    model.trie = None
     del model, retr
     torch.cuda.empty_cache()
     # ---- bf16 precision mode (config C5): encoder linears + corpus in bf16, fp32 accumulate

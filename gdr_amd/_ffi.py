@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDR_HIP_LIB") or os.path.join(_HERE, "libgdr_hip.so")   # override: A/B builds in the lab
 
 GDR_OK, GDR_EINVAL, GDR_ENOSPC, GDR_EHIP = 0, -1, -2, -3
-ABI_VERSION = 3                  # what this binding was written against (gdr_abi_version(), csrc/common.hip)
+ABI_VERSION = 4                  # what this binding was written against (gdr_abi_version(), csrc/common.hip)
 RERANK_POSITIONS = 1
 SIM_EXHAUSTIVE = 1
 SIM_NO_STREAM = 2
@@ -120,6 +120,7 @@ SIGNATURES = {
                              C.POINTER(GdrPrefixTable), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gdr_t5_generate_bf16": (_i, [C.POINTER(GdrT5DecoderWeights), _vp, _vp, _i, _i, _i, _i, C.c_double, _i,
                                   C.POINTER(GdrTrie), C.POINTER(GdrPrefixTable), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gdr_t5_generate_early_exits": (C.c_int64, []),
     "gdr_t5_prefix_table_build_bf16": (_i, [C.POINTER(GdrT5DecoderWeights), _i, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp,
                                             _vp, _sz, _vp]),
     "gdr_t5_prefix_table_workspace_bytes": (_sz, [C.POINTER(GdrT5DecoderWeights), _i]),

@@ -66,6 +66,9 @@ struct StreamK {
   float* part;     // device [512][128*128]: raw accumulators handed from a workgroup to its successor
   int32_t* flag;   // device [512]
   int32_t epoch;   // host-side launch counter
+  // decode only (may be null): a device word that gdr_t5_generate's beam bookkeeping clears when every query of the call is
+  // done (generation_utils.py:836-838 `if all(done): break`); the 64x64-tile linears of the steps still enqueued exit at once
+  const int32_t* live = nullptr;
 };
 constexpr size_t STREAMK_PART_BYTES = (size_t)512 * 128 * 128 * 4;
 constexpr size_t STREAMK_BYTES = STREAMK_PART_BYTES + 4096;
@@ -113,7 +116,8 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev = nullptr,
                             const NormEpilogue* ne = nullptr,  // with ne: returns 2 if the fused form does not apply
-                            SlabRef* slabs = nullptr);         // with slabs (no epilogue allowed): the reduction is left to the caller
+                            SlabRef* slabs = nullptr,          // with slabs (no epilogue allowed): the reduction is left to the caller
+                            const int32_t* live = nullptr);    // StreamK::live
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, int out_bf16, hipStream_t stream, const int64_t* m_dev = nullptr);

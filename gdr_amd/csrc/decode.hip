@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -58,6 +59,10 @@ struct BeamBufs {
   int32_t* hyp_cnt;     // [B]
   double* hyp_worst;    // [B]
   int32_t* done;        // [B]
+  int32_t* n_done;      // [1] queries whose beam search is done (generation_utils.py:827-829)
+  int32_t* live;        // [1] 1 until n_done reaches B: the linears and the miss-row chain of later steps look at it
+  int32_t* all_done_host;  // host-mapped word (may be null): receives `done_epoch` when n_done reaches B
+  int32_t done_epoch;
 };
 
 struct BeamDims {
@@ -110,6 +115,8 @@ static size_t beam_layout(const BeamDims& bd, char* base, BeamBufs* bb) {
   CARVE(hyp_cnt, int32_t, bd.B);
   CARVE(hyp_worst, double, bd.B);
   CARVE(done, int32_t, bd.B);
+  CARVE(n_done, int32_t, 1);
+  CARVE(live, int32_t, 1);
 #undef CARVE
   return o;
 }
@@ -134,6 +141,7 @@ __global__ void beam_init_kernel(BeamBufs bb, BeamDims bd, int dedup0) {
     bb.hyp_worst[r] = 1e9;  // :1062
     bb.done[r] = 0;
   }
+  if (r == 0) *bb.n_done = 0, *bb.live = 1;
 }
 
 __device__ __forceinline__ uint32_t dfkey(float v) {
@@ -238,7 +246,9 @@ __global__ __launch_bounds__(1024) void prefix_plan_kernel(BeamBufs bb, int rows
     if (tid == 1023) carry = before + inc;
     __syncthreads();
   }
-  if (tid == 0) *bb.n_miss = carry;
+  // every query done (beam_update_kernel): the miss rows' adaptor chain and head GEMM of this step run on zero rows; the
+  // index arrays stay as computed, so whoever still reads them (the head lookup of a step nobody consumes) stays in bounds
+  if (tid == 0) *bb.n_miss = *bb.live ? carry : 0;
   (void)stride;
 }
 
@@ -652,7 +662,15 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamBufs bb, BeamDims 
       n_sh = n;
       if (H.n >= R) {
         const double cur_score = (double)cs[0] / len_pow;
-        if (H.worst >= cur_score) bb.done[b] = 1;
+        if (H.worst >= cur_score) {
+          bb.done[b] = 1;  // set once: a done query takes the early return at the top from now on
+          // generation_utils.py:836-838 `if all(done): break` — the host polls this word between steps (generate_impl)
+          if (atomicAdd(bb.n_done, 1) + 1 == bd.B) {
+            *bb.live = 0;  // the steps already enqueued skip their linears (StreamK::live) and their miss-row chain
+            if (bb.all_done_host)
+              __hip_atomic_store(bb.all_done_host, bb.done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
       }
     }
   }
@@ -793,6 +811,27 @@ static int beam_end(const BeamBufs& bb, const BeamDims& bd, int max_length, int 
 // concurrently, the adaptor on a side stream forked / joined with events (graph-capturable pattern).  Side streams are
 // leased per CALL from a per-device pool (created on first use on the device that is current in the calling thread), so
 // concurrent gdr_t5_generate calls from several host threads or on several devices never share one.
+// `if all(done): break` (generation_utils.py:836-838) without a host sync: beam_update_kernel stores the call's epoch into a
+// host-mapped word when the last query becomes done, and the host looks at that word before it enqueues the next step.  The
+// host runs ahead of the GPU by less than a step's worth of launches at decode batch sizes, so a call whose beams all finish
+// at step s enqueues at most a step or two more (which change nothing: done queries only pad, :786-794) instead of all
+// max_length - 1.  Random weights (bench.py) never finish early; a trained model does after the docid's length + 1 steps, and so
+// does every trie-constrained call.  64 words used round-robin by epoch: a stale store from the call 64 epochs ago cannot match.
+static int32_t* done_words() {
+  static int32_t* words = [] {
+    int32_t* h = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h), 64 * sizeof(int32_t), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) !=
+        hipSuccess) {
+      (void)hipGetLastError();
+      return static_cast<int32_t*>(nullptr);
+    }
+    for (int i = 0; i < 64; ++i) h[i] = 0;
+    return h;
+  }();
+  return words;
+}
+static std::atomic<int32_t> g_done_epoch{0};
+static std::atomic<int64_t> g_early_exits{0};
 constexpr int SIDE_MAX_LAYERS = 48;
 struct SideStream {
   hipStream_t s = nullptr;
@@ -875,7 +914,7 @@ static int dec_linear_norm(bool bf16, void* abf, const float* A, int64_t lda, co
     const int act = (epi == GDR_EPI_RELU || epi == GDR_EPI_BIAS_RELU) ? 1 : 0;
     GDR_CHECK_ARG(epi != GDR_EPI_BIAS_GELU && (!nb || bias) && (!nr || res), "decode: bad epilogue for a fused norm");
     const int rc = launch_linear_f32_small(A, lda, W, ldw, C, ldc, M, N, K, nb, nr, act, bias, res, ldr, skw, SPLITK_WS_BYTES, st,
-                                           m_dev, &ne);
+                                           m_dev, &ne, nullptr, sk ? sk->live : nullptr);
     if (rc <= 0) return rc;
   }
   if (int rc = dec_linear(bf16, abf, A, lda, W, ldw, C, ldc, M, m_dev, N, K, epi, bias, res, ldr, skw, st, sk)) return rc;
@@ -1031,6 +1070,21 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
     set_error("generate: memset of the stream-K flags failed");
     return GDR_EHIP;
   }
+  // early exit (see done_words): not while a caller wants the per-step trace — its rows of the steps not run would be undefined
+  static const bool early_on = [] {
+    const char* e = getenv("GDR_DECODE_EARLY_EXIT");  // A/B knob: 0 = always run all max_length - 1 steps
+    return e ? atoi(e) != 0 : true;
+  }();
+  int32_t* done_word = nullptr;
+  int32_t my_epoch = 0;
+  if (early_on && !step_scores && !step_tokens) {
+    if (int32_t* words = done_words()) {
+      my_epoch = g_done_epoch.fetch_add(1) + 1;  // never 0
+      done_word = words + (my_epoch & 63);
+      bb.all_done_host = done_word, bb.done_epoch = my_epoch;  // travels with every beam_update launch
+    }
+    sk1.live = sk2.live = bb.live;  // the device-side half: steps already enqueued when the last query finishes skip their work
+  }
   SideLease lease;
   struct { bool ok; hipStream_t s; hipEvent_t fork, join; } ss{lease.ss != nullptr, lease.ss ? lease.ss->s : nullptr,
                                                             lease.ss ? lease.ss->fork : nullptr, lease.ss ? lease.ss->join : nullptr};
@@ -1066,6 +1120,10 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   const BucketLut lut_bi = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
   int cur = 0;
   for (int s = 0; s + 1 < max_length; ++s) {  // position s, cur_len = s + 1 (generation_utils.py:676)
+    if (done_word && s > 0 && __atomic_load_n(done_word, __ATOMIC_RELAXED) == my_epoch) {  // :836-838 all(done)
+      g_early_exits.fetch_add(1);
+      break;
+    }
     hipStream_t as = ss.ok ? ss.s : stream;   // adaptor stream
     // Step 0: the R beam rows of a query hold the same START token and the same encoder states, so their decoder /
     // adaptor / head outputs are identical rows (generation_utils.py:437-442 expands the encoder states, :663-668 starts
@@ -1177,7 +1235,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       if (slab_q_on && !bf16 && R_s > 1 /* the Lq = 1 kernel of the de-duplicated step 0 takes finished q rows */ &&
           ((rows_s + 127) / 128) * ((inner + 127) / 128) < 192 && rows_s <= 1536 && d % 32 == 0 && d / 32 >= 4) {
         const int rc_ = launch_linear_f32_small(nx, d, ly.wq_c, d, qc, inner, rows_s, inner, d, 0, 0, 0, nullptr, nullptr, 0, skw,
-                                                SPLITK_WS_BYTES, stream, nullptr, nullptr, &qsl);
+                                                SPLITK_WS_BYTES, stream, nullptr, nullptr, &qsl, sk1.live);
         if (rc_ < 0) return rc_;
         q_from_slabs = rc_ == 0;
       }
@@ -1252,6 +1310,8 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
 #undef LIN2N
 }
 }  // namespace gdr
+
+extern "C" int64_t gdr_t5_generate_early_exits(void) { return gdr::g_early_exits.load(); }
 
 extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B,
                                int L, int num_beams, int max_length, double length_penalty,

@@ -1190,7 +1190,7 @@ int launch_linear_f32_ws_dev(const float* A, int64_t lda, const float* W, int64_
                     : epilogue == GDR_EPI_BIAS_GELU                             ? ACT_GELU
                                                                                 : ACT_NONE;
     const int rc = launch_linear_f32_small(A, lda, W, ldw, C, ldc, M_max, N, K, nb, nr, act, bias, residual, ldr, splitk_ws,
-                                           splitk_ws_bytes, stream, m_dev);
+                                           splitk_ws_bytes, stream, m_dev, nullptr, nullptr, sk ? sk->live : nullptr);
     if (rc <= 0) return rc;
   }
   return launch_linear_f32_dev(A, lda, W, ldw, C, ldc, M_max, m_dev, N, K, epilogue, bias, residual, ldr, -1, stream, sk);
@@ -1258,7 +1258,7 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
     // few rows (decode: M = batch*beams): 64x64 tiles (gemm_small.hip), split along K only as far as still needed.
     // With more rows (a 64-query encoder batch) the 128x128 core with split-K measured 5 % faster.
     const int rc = launch_linear_f32_small(A, lda, W, ldw, C, ldc, M, N, K, needs_bias, needs_res, g.act, bias, residual, ldr,
-                                           splitk_ws, splitk_ws_bytes, stream, m_dev);
+                                           splitk_ws, splitk_ws_bytes, stream, m_dev, nullptr, nullptr, sk ? sk->live : nullptr);
     if (rc <= 0) return rc;
   }
   if (splitk_ws && K % BK == 0 && tiles < 0x7fffffff / 64) {

@@ -30,6 +30,7 @@ struct SmallGemmArgs {
   int has_bias, has_residual, act;  // 0 none, 1 relu, 2 gelu
   int ksplit, kchunk;               // kchunk in elements, multiple of 32
   const int64_t* m_dev;             // may be null: live row count on the device (<= M); tiles past it exit at once
+  const int32_t* live;              // may be null: *live == 0 -> the whole launch exits (common.h StreamK::live)
 };
 
 __device__ __forceinline__ float gelu_erf_s(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -111,7 +112,9 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_f32_small_kernel(const SmallGe
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);                  \
     }                                                                                        \
   }
+  const int live_v = g.live ? *g.live : 1;  // scalar load: its latency hides behind the first operand loads
   S_LOAD(p, 0)
+  if (live_v == 0) return;  // uniform; every query of the generate call is done, the step's output is never read
   S_STORE(p, 0)
   S_LOAD(p, 1)
   S_LOAD(q, 2)
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_row_kernel(const float
 int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, float* ws, size_t ws_bytes, hipStream_t stream, const int64_t* m_dev,
-                            const NormEpilogue* ne, SlabRef* slabs) {
+                            const NormEpilogue* ne, SlabRef* slabs, const int32_t* live) {
   constexpr int target = 512;  // workgroups wanted per launch (measured flat between 256 and 512, worse outside)
   if (K % SBK != 0) return 1;
   const int64_t tiles_m = (M + SB - 1) / SB;
@@ -305,7 +308,7 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
   g.A = A, g.W = W, g.bias = bias, g.residual = residual;
   g.lda = lda, g.ldw = ldw, g.ldc = ldc, g.ldr = ldr, g.M = M, g.N = N, g.K = K, g.tiles_n = tiles_n;
   g.ksplit = S, g.kchunk = chunk_steps * SBK;
-  g.m_dev = m_dev;
+  g.m_dev = m_dev, g.live = live;
   g.tiles_m = (int)tiles_m;
   const double flops = 2.0 * (double)M * (double)N * (double)K;
   if (ne && (S == 1 || N % 4 != 0 || N > 1024 || act > 1)) return 2;  // the fused norm needs split slabs of a row it can hold

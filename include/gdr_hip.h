@@ -428,6 +428,15 @@ int gdr_t5_generate_bf16(const GdrT5DecoderWeights* w, const float* enc_hidden, 
                          const GdrTrie* trie, const GdrPrefixTable* prefix_table, int64_t* out_ids, int32_t* out_len,
                          double* out_scores, float* step_scores, int32_t* step_tokens, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* Early exit of the step loop — `if all(done): break`, generation_utils.py:836-838, without a host synchronisation.  When the
+ * last query of a call becomes done (BeamHypotheses.is_done, :827-829) the beam bookkeeping kernel (a) clears a device word
+ * that the 64x64-tile linears and the miss-row chain of every step already enqueued look at — they exit at once — and
+ * (b) stores the call's epoch in host-mapped memory, which the host reads before it enqueues the next step and then stops.
+ * The steps that still run change nothing (done queries only pad, :786-794): outputs are bit-identical to running all
+ * max_length - 1 steps.  Not taken while the per-step trace is requested; under graph capture only (a) applies.  Random
+ * weights never finish early; a trained model does after the docid's length + 1 steps, a trie-constrained call always does.
+ * Returns how many generate calls of this process left their loop on the host side (monitoring / tests). */
+int64_t gdr_t5_generate_early_exits(void);
 int gdr_t5_prefix_table_build_bf16(const GdrT5DecoderWeights* w, int n_levels, const int32_t* level_off,
                                    const int64_t* node_tok, const int32_t* node_anc, float* kv, float* W, void* workspace,
                                    size_t workspace_bytes, void* stream);

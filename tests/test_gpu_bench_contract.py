@@ -52,6 +52,8 @@ def test_bench_line_contract_fp32():
     assert any(k.startswith("B64_cand") for k in rr) and any(k.startswith("B1_cand") for k in rr)
     assert all(0 < v["frac_of_hbm_peak"] < 1 and v["candidates"] > 0 for v in rr.values())
     assert st["c3_two_stage"]["after_generate_ms"] < st["c3_two_stage"]["ms"]
+    con = st["generate_trie_constrained"]["B64_beam10"]        # constrained beams end early: the call must be shorter
+    assert 0 < con["decode_ms"] < st["generate"]["B64_beam10"]["decode_ms"] and con["two_stage_queries_per_s"] > 0
     assert st["c3_two_stage_B512"]["queries_per_s"] > st["c3_two_stage"]["queries_per_s"] > 0
     assert 0 < st["doc_tower_bert_base_L128"]["frac_of_f32_mfma_peak"] < 1
 

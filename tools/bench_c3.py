@@ -28,7 +28,9 @@ N = 320000
 sd = synth.make_state_dict(cfg, seed=1234)
 names, depth, offsets, members = synth.make_cluster_ids(N, cluster_size=12, V=30)
 D_dev = torch.from_numpy(synth.make_corpus(N, cfg.d_model)).to(dev)
-model = GDRModel(cfg, sd, dev, ragged=True, prefix_trie=codec.Trie.from_docids(names, 30))
+_trie = codec.Trie.from_docids(names, 30)
+# TRIE=1: trie-constrained beams (every hypothesis is a corpus docid; all beams end two steps after the deepest leaf)
+model = GDRModel(cfg, sd, dev, ragged=True, prefix_trie=_trie, trie=_trie if os.environ.get("TRIE") == "1" else None)
 out = {}
 shapes = [tuple(int(x) for x in s.split("x")) for s in os.environ.get("SHAPES", "64x10,1x100").split(",")]
 for B, R in shapes:
@@ -65,4 +67,6 @@ for B, R in shapes:
     out[f"B{B}_beam{R}"] = {"generate_ms": t, "encoder_ms": t_enc, "decode_ms": t - t_enc, "two_stage_ms": t3,
                             "two_stage_qps": B / t3 * 1e3, "two_stage_host_candidates_ms": t3h, "stage2_device_ms": t2,
                             "candidates": ncand, "stage2_gather_gbs": ncand * cfg.d_model * 4 / (t2 * 1e-3) / 1e9}
+from gdr_amd import _ffi
+out["early_exits"] = int(_ffi.lib().gdr_t5_generate_early_exits())
 print(json.dumps(out, indent=1))
