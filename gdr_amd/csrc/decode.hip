@@ -977,6 +977,7 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
 extern "C" size_t gdr_t5_generate_workspace_bytes(const GdrT5DecoderWeights* w, int B, int L, int num_beams,
                                                   int max_length) {
   if (!w || B <= 0 || L <= 0 || num_beams <= 0 || max_length < 2) return 0;
+  (void)gdr::done_words();  // pinned host words of the early exit: allocated here, never inside a caller's stream capture
   gdr::BeamDims bd{B, num_beams, w->out_vocab, w->dims.vocab_size, max_length, num_beams, 1.0, nullptr, nullptr, 0};
   return gdr::gen_ws(*w, bd, L).total;
 }
