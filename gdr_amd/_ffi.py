@@ -54,7 +54,7 @@ class GdrTrie(C.Structure):
 
 class GdrPrefixTable(C.Structure):
     _fields_ = [("child", C.c_void_p), ("n_nodes", C.c_int32), ("V", C.c_int32), ("n_table", C.c_int32),
-                ("kv", C.c_void_p), ("W", C.c_void_p)]
+                ("kv", C.c_void_p), ("W", C.c_void_p), ("complete_levels", C.c_int32)]
 
 
 class GdrClusterIndex(C.Structure):

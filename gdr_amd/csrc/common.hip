@@ -118,5 +118,6 @@ extern "C" int gdr_prof_collect(int64_t* launches, double* total_ms, double* tot
 extern "C" const char* gdr_last_error(void) { return gdr::g_err; }
 // 2: gdr_t5_generate takes a GdrPrefixTable; GdrTrie carries V
 // 3: gdr_rerank_topk takes a shard range, flags and a workspace; gdr_rerank_topk_bf16, gdr_cluster_candidates added
-// 4: gdr_t5_generate_early_exits added (gdr_t5_generate leaves its step loop when every query is done)
+// 4: gdr_t5_generate_early_exits added (gdr_t5_generate leaves its step loop when every query is done);
+//    GdrPrefixTable.complete_levels
 extern "C" int gdr_abi_version(void) { return 4; }

@@ -1167,6 +1167,10 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
                       ln(al.ln3_w, al.ln3_b, xa)));
         return GDR_OK;
     };
+    // prefix-table mode, steps at which every possible prefix is a table node (step 0: the root; deeper while the trie's
+    // levels are complete, GdrPrefixTable.complete_levels): the adaptor chain and the head GEMM would run over zero rows
+    // (34 launches per step that exit at once — 0.2 ms of the side queue and, at one query x 100 beams, of the host's time)
+    const bool adaptor_idle = ptab != nullptr && s < (ptab->complete_levels > 1 ? ptab->complete_levels : 1);
     const int64_t* nm = bb.n_miss;
     if (ptab) {
       // ---------------- prefix-table mode: rows whose prefix is a table node take everything from the table; the rest
@@ -1176,14 +1180,12 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       hipLaunchKernelGGL(prefix_fill_kernel, dim3(rows_s), dim3(256), 0, as, bb, rows_s, s + 1, cur, ptab->kv,
                          (int64_t)ptab->n_table * 3 * d, acache + s * aslab, (int64_t)alayer, w->adaptor_layers, 3 * d);
       GDR_CHECK_LAUNCH("prefix_fill_kernel");
-      if (s > 0) {  // at step 0 every row sits on the trie's root, a table node (n_table >= 1): nothing is compacted
+      if (!adaptor_idle) {  // idle steps: every row sits on a table node, nothing is compacted
         hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)((rows_s + 3) / 4)), dim3(256), 0, as, w->dec_embed, bb.cur_tok,
                            bb.miss_rows, nm, d / 4, dm.vocab_size, xa);
         GDR_CHECK_LAUNCH("embed_rows_kernel");
       }
     }
-    // prefix-table mode, step 0: the adaptor chain and the head GEMM would run over zero rows (34 launches that exit at once)
-    const bool adaptor_idle = ptab != nullptr && s == 0;
 #define LIN2D(A_, lda_, W_, ldw_, C_, ldc_, N_, K_, epi_, bias_, res_, ldr_) \
   dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, rows_s, nm, N_, K_, epi_, bias_, res_, ldr_, skw2, as, &sk2)
     auto ad_layer_tab = [&](int l) -> int {

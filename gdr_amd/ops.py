@@ -644,8 +644,13 @@ class PrefixTable:
                     ws.numel(), stream_ptr()), "gdr_t5_prefix_table_build")
         torch.cuda.current_stream().synchronize()                        # the scratch tensors above may go now
         self.n_levels, self.n_table, self.level_off = n_levels, n_table, level_off
+        # levels 0 .. c-1 hold ALL V^s prefixes of their length (and are inside the table): no beam row can miss at those steps
+        c = 1
+        while c < n_levels and int(level_off[c + 1]) - int(level_off[c]) == int(bfs.V) ** c:
+            c += 1
+        self.complete_levels = c
         self.struct = _ffi.GdrPrefixTable(self.device_trie.child.data_ptr(), self.device_trie.child.shape[0], int(bfs.V),
-                                          n_table, self.kv.data_ptr(), self.W.data_ptr())
+                                          n_table, self.kv.data_ptr(), self.W.data_ptr(), c)
 
     def struct_ref(self):
         return C.byref(self.struct)

@@ -390,6 +390,10 @@ typedef struct {
   int32_t n_table;        /* nodes with entries: the first n_table nodes (breadth-first order)                       */
   const float* kv;        /* device [adaptor_layers][n_table][3*d]                                                   */
   const float* W;         /* device [n_table][V+1][d]   (adaptor_linear slice + lm_head rows of the node's position) */
+  int32_t complete_levels; /* c >= 1: every one of the V^s prefixes of length s is a table node for all s < c (level 0 = the
+                            * root always is).  A beam row of decode step s sits on a prefix of length s, so at steps s < c
+                            * no row can miss and gdr_t5_generate does not enqueue the miss-row chain at all (1 = step 0 only;
+                            * a value larger than the truth gives WRONG logits for the rows that do miss)                    */
 } GdrPrefixTable;
 
 size_t gdr_t5_prefix_table_workspace_bytes(const GdrT5DecoderWeights* w, int max_level_nodes);

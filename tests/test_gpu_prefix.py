@@ -81,6 +81,9 @@ def test_generate_tiny_with_prefix_table_vs_oracle(dev, keep_every, constrain):
               output_scores=True)
     plain = GDRModel(cfg, sd, dev, trie=trie if constrain else None)
     tabled = GDRModel(cfg, sd, dev, trie=trie if constrain else None, prefix_trie=trie)
+    # levels whose V^s prefixes are ALL trie nodes: no row can miss at those steps and the miss-row chain is not even enqueued
+    # (GdrPrefixTable.complete_levels) — all three levels of the full trie, root + first digit of the ones with holes
+    assert tabled.prefix_table.complete_levels == (3 if keep_every == 1 else 2)
     (d0, s0), _ = plain.generate(it, **kw)
     (d1, s1), _ = tabled.generate(it, **kw)
     assert torch.equal(d0, d1)
@@ -107,6 +110,7 @@ def test_generate_base_golden_still_exact_with_prefix_table(dev):
     names, _, _, _ = synth.make_cluster_ids(30000, cluster_size=12, V=30)
     model = GDRModel(cfg, sd, dev, prefix_trie=codec.Trie.from_docids(names, 30))
     assert model.prefix_table.n_levels == 4 and model.prefix_table.n_table == 1 + 3 + 84 + 2500
+    assert model.prefix_table.complete_levels == 1                      # only 3 of the 30 first digits exist: step 0 alone is miss-free
     R = int(g["num_beams"])
     ids, mask = torch.from_numpy(g["input_ids"]).to(dev), torch.from_numpy(g["attention_mask"]).to(dev)
     (dec, scores), _ = model.generate(ids, attention_mask=mask, max_length=cfg.max_output_length, num_beams=R,
