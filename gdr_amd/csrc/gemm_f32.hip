@@ -421,6 +421,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
   const int64_t Mrows = live_rows_padded(g);  // ragged batches: a device-side value <= g.M, in whole row panels
   const int tiles_m = (int)((Mrows + BM - 1) / BM);
   const int total_tiles = g.m_dev ? tiles_m * g.tiles_n : total_tiles_host;
+  constexpr int S = 1;  // whole tiles only (the stream-K kernel's macros of the same name also serve (tile, chunk) units)
   // a device-side row count of 0 (prefix-table decode when every beam hits the table): no tile exists to park the load
   // stream on — the prologue below would divide by gm_ = 0 and clamp rows to -1.  Uniform exit before anything is loaded.
   if (total_tiles <= 0) return;
@@ -430,8 +431,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_persistent_kernel
 // tile index -> (row panel, column tile): supertiles of GM row panels x all column tiles, row-panel-fastest inside, so
 // that the 64 tiles an XCD works on at a time are ~8 row panels x 8 column tiles (16 operand panels through its L2)
 // instead of a few row panels x every column tile (N=3072: 27 panels).  GM travels in g.ksplit (unused by this kernel).
-#define P_TILE_MN(tile_, mt_, nt_)                                           \
+#define P_TILE_MN(item_, mt_, nt_)                                           \
   {                                                                          \
+    const int tile_ = S > 1 ? (item_) / S : (item_);                         \
     const int per_ = g.ksplit * g.tiles_n;                                   \
     const int grp_ = (tile_) / per_, loc_ = (tile_) - grp_ * per_;           \
     const int gm_ = min(g.ksplit, tiles_m - grp_ * g.ksplit);                \
@@ -689,6 +691,12 @@ struct StreamKArgs {
   int32_t* flag;
   int32_t epoch;
   int32_t* err;  // host-mapped word (streamk_err_word): a take-over that timed out raises it; may be null
+  // split-K UNITS (S > 1): the work items are (tile, K chunk s) pairs of g.kchunk contraction steps each, in the order
+  // unit = tile * S + s, and a finished unit stores its raw 128x128 partial at slabs[unit] — the slab layout and the k order
+  // inside a chunk are those of gemm_nt_f32_kernel's split-K form, so splitk_reduce_kernel gives the bit-identical result.
+  // Dealing the units by K-step ranges balances launches whose (tile, chunk) count sits between one and two per CU.
+  int S;
+  float* slabs;
 };
 // A take-over spin that runs out (the predecessor workgroup never became resident for seconds — a co-tenant kernel that
 // starves it; the kernel itself assumes its <= 512 workgroups are co-resident, 2 per CU) used to trap, which aborts the
@@ -746,6 +754,7 @@ static bool streamk_wanted(int64_t tiles, int nk) {
   const int64_t rem = tiles % 512;
   return rem != 0 && (512 - rem) * nk > (int64_t)thr * 512;
 }
+template <bool UNITS>  // UNITS: the work items are split-K (tile, chunk) units (StreamKArgs.S > 1), else whole tiles
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(const GemmArgs g, const int total_tiles_host,
                                                                               const StreamKArgs sk) {
   __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDS_STRIDE + 2 * BN * LDS_STRIDE];
@@ -766,18 +775,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
   const int l31 = lane & 31, h = lane >> 5;
   const int a_rd = (wm * 64 + l31) * LDS_STRIDE + 4 * h;
   const int b_rd = (wn * 64 + l31) * LDS_STRIDE + 4 * h;
-  const int nk = g.K / BK;
+  const int S = UNITS ? sk.S : 1;  // a compile-time 1 in the whole-tile kernel: the unit bookkeeping costs it no register
+  const int nk = (S > 1 ? g.kchunk : g.K) / BK;
   const int64_t Mrows = live_rows_padded(g);  // ragged batches: a device-side value <= g.M, in whole row panels
   const int tiles_m = (int)((Mrows + BM - 1) / BM);
-  const int total_tiles = g.m_dev ? tiles_m * g.tiles_n : total_tiles_host;
+  const int total_tiles = g.m_dev ? tiles_m * g.tiles_n * S : total_tiles_host;  // work items: tiles, or (tile, chunk) units
 
   int a_ld[4];  // element offsets from g.A / g.W, 32-bit (the launcher sends operands of >= 2^31 elements to the whole-tile
   int w_ld[4];  // kernel): with 64-bit offsets the segment bookkeeping pushed three spills into the K-step
 // tile index -> (row panel, column tile): supertiles of GM row panels x all column tiles, row-panel-fastest inside, so
 // that the 64 tiles an XCD works on at a time are ~8 row panels x 8 column tiles (16 operand panels through its L2)
 // instead of a few row panels x every column tile (N=3072: 27 panels).  GM travels in g.ksplit (unused by this kernel).
-#define P_TILE_MN(tile_, mt_, nt_)                                           \
+#define P_TILE_MN(item_, mt_, nt_)                                           \
   {                                                                          \
+    const int tile_ = S > 1 ? (item_) / S : (item_);                         \
     const int per_ = g.ksplit * g.tiles_n;                                   \
     const int grp_ = (tile_) / per_, loc_ = (tile_) - grp_ * per_;           \
     const int gm_ = min(g.ksplit, tiles_m - grp_ * g.ksplit);                \
@@ -793,8 +804,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
       ra_ = ra_ < Mrows ? ra_ : Mrows - 1;                                   \
       int rw_ = nt_ * BN + lrow + 32 * p;                                    \
       rw_ = rw_ < g.N ? rw_ : g.N - 1;                                       \
-      a_ld[p] = (int)(ra_ * g.lda + lcol);                                   \
-      w_ld[p] = (int)((int64_t)rw_ * g.ldw + lcol);                          \
+      const int ks_ = S > 1 ? ((tile_) % S) * g.kchunk : 0;                  \
+      a_ld[p] = (int)(ra_ * g.lda + lcol + ks_);                             \
+      w_ld[p] = (int)((int64_t)rw_ * g.ldw + lcol + ks_);                    \
     }                                                                        \
   }
   float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
@@ -992,7 +1004,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_streamk_kernel(co
       P_TILE_MN(tile, mt, nt)
       const int64_t m0 = (int64_t)mt * BM;
       const int n0 = nt * BN;
-      if (m0 + BM <= Mrows && n0 + BN <= g.N) {
+      if (UNITS) {  // a finished (tile, chunk) unit: the raw partial, in gemm_nt_f32_kernel's slab layout
+        float* slab = sk.slabs + (int64_t)tile * (BM * BN) + (wm * 64 + 4 * h) * BN + wn * 64 + l31;  // unit index = tile * S + s already
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              slab[(mi * 32 + (r & 3) + 8 * (r >> 2)) * BN + ni * 32] = acc[mi][ni][r];
+              acc[mi][ni][r] = 0.f;
+            }
+      } else if (m0 + BM <= Mrows && n0 + BN <= g.N) {
         // interior tile: uniform branches only, so that the 64 residual loads go out as one batch and the 64 stores
         // as another (per-element flag tests serialise them behind a vmcnt(0) each)
         const int64_t mrow = m0 + wm * 64 + 4 * h;
@@ -1268,7 +1291,41 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
       int S = (int)((target + tiles - 1) / tiles);
       if (S > nk / 2) S = nk / 2;
       if ((size_t)S * tiles * tile_bytes > splitk_ws_bytes) S = (int)(splitk_ws_bytes / (tiles * tile_bytes));
-      if (S >= 2) return split_launch(0, tiles, S);
+      if (S >= 2) {
+        // A packed batch (device-side row count, live rows known to the host as a hint) whose LIVE (tile, chunk) units number
+        // between one and two per CU: one workgroup per unit leaves every CU waiting for those that got two (a 64-query
+        // encoder pass, N = 768: 78 live tiles x 4 chunks = 312 workgroups on 256 CUs, 94 us for K = 3072).  The stream-K
+        // kernel on 256 workgroups deals the same units by K-step ranges instead — same chunks, same k order inside a chunk,
+        // same slabs, same reduction: bit-identical — and the busiest CU runs ~1.2 units' worth instead of 2.
+        const int chunk_steps = (nk + S - 1) / S;
+        const int S2 = (nk + chunk_steps - 1) / chunk_steps;
+        // Taken for every packed batch of this size class: the live row count is on the device (a host copy would cost a
+        // synchronisation), and the kernel is right for any count — up to 256 live units each gets its own workgroup like
+        // in the one-unit-per-workgroup form, above that they are dealt by ranges.  With the host's hint (the bench) a
+        // launch whose units all fit one per CU keeps the plain form.
+        const int64_t units_hint = m_dev && prof_rows >= 0 ? ((prof_rows + BM - 1) / BM) * g.tiles_n * S2 : -1;
+        const size_t need = STREAMK_BYTES + (size_t)tiles * S2 * tile_bytes;
+        if (sk && m_dev && sk->part == splitk_ws && nk % chunk_steps == 0 && tiles * S2 > 256 && (units_hint < 0 || units_hint > 256) &&
+            need <= splitk_ws_bytes && streamk_fits(M, lda, N, ldw)) {
+          if (int rc_ = streamk_poll_error()) return rc_;
+          float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(splitk_ws) + STREAMK_BYTES);
+          GemmArgs p = g;
+          p.has_bias = 0, p.has_residual = 0, p.act = ACT_NONE;
+          p.ksplit = 1 /* supertile height, unused at these widths */, p.kchunk = chunk_steps * BK, p.tile_base = 0;
+          const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch, streamk_err_word(), S2, slabs};
+          {
+            ProfScope prof(PROF_LINEAR, flops, stream);
+            hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel<true>, dim3(256), dim3(GEMM_THREADS), 0, stream, p, (int)(tiles * S2), ska);
+          }
+          GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel(units)");
+          ProfScope prof_r(PROF_REDUCE, 0.0, stream);
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(tiles * 16)), dim3(256), 0, stream, slabs, S2, 0, g.tiles_n, M, N,
+                             C, ldc, needs_bias ? bias : nullptr, needs_res ? residual : nullptr, ldr, g.act, m_dev);
+          GDR_CHECK_LAUNCH("splitk_reduce_kernel");
+          return GDR_OK;
+        }
+        return split_launch(0, tiles, S);
+      }
     }
   }
   ProfScope prof(PROF_LINEAR, flops, stream);
@@ -1276,7 +1333,7 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
     g.ksplit = g.tiles_n >= 12 ? 8 : 1;
     if (int rc_ = streamk_poll_error()) return rc_;
       const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch, streamk_err_word()};
-    hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3(256), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
+    hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel<false>, dim3(256), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
     GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel(256)");
     return GDR_OK;
   }
@@ -1290,7 +1347,7 @@ int launch_linear_f32_ws(const float* A, int64_t lda, const float* W, int64_t ld
     if (sk && streamk_wanted(tiles, K / BK) && streamk_fits(M, lda, N, ldw)) {
       if (int rc_ = streamk_poll_error()) return rc_;
       const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch, streamk_err_word()};
-      hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3((unsigned)SLOTS), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
+      hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel<false>, dim3((unsigned)SLOTS), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
       GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel");
       return GDR_OK;
     }
@@ -1338,7 +1395,7 @@ int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t l
     g.ksplit = g.tiles_n >= 12 ? 8 : 1;
     if (int rc_ = streamk_poll_error()) return rc_;
       const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch, streamk_err_word()};
-    hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3(256), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
+    hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel<false>, dim3(256), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
     GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel(256, dev rows)");
     return GDR_OK;
   }
@@ -1347,7 +1404,7 @@ int launch_linear_f32_dev(const float* A, int64_t lda, const float* W, int64_t l
     if (sk && streamk_wanted(tiles_live, K / BK) && streamk_fits(M_max, lda, N, ldw)) {
       if (int rc_ = streamk_poll_error()) return rc_;
       const StreamKArgs ska{sk->part, sk->flag, ++sk->epoch, streamk_err_word()};
-      hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel, dim3(512), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
+      hipLaunchKernelGGL(gemm_nt_f32_streamk_kernel<false>, dim3(512), dim3(GEMM_THREADS), 0, stream, g, (int)tiles, ska);
       GDR_CHECK_LAUNCH("gemm_nt_f32_streamk_kernel(dev rows)");
       return GDR_OK;
     }
