@@ -42,8 +42,23 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
   char* const As = smem;
   char* const Bs = smem + 128 * 128;
   unsigned bid = blockIdx.x;
+  const int64_t Mv = (EPI == 0 && g.m_dev) ? *g.m_dev : g.M;
   {
-    const unsigned nblk = gridDim.x, q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
+    // The XCD-aware remap hands every XCD a CONTIGUOUS range of logical tiles.  With a device-side row count the grid is sized
+    // for the padded batch and the tiles past the live rows are the LAST logical ones: remapped over the whole grid they all
+    // belong to the last XCDs, which then idle while the first ones do all the work (C2's packed batch, 60 % live: XCDs 5-7 got
+    // nothing; the bf16 linears ran 25-30 % slower in the encoder than alone).  So the remap runs over the LIVE tile count and
+    // hardware blocks past it exit — the hardware deals consecutive block ids round-robin over the XCDs, so the live ones
+    // are spread evenly.
+    unsigned nblk = gridDim.x;
+    if (EPI == 0 && g.m_dev) {
+      const int64_t live = ((Mv + 127) / 128) * (int64_t)g.tiles_n;
+      if (live < (int64_t)nblk) {
+        if ((int64_t)bid >= live) return;  // uniform
+        nblk = (unsigned)live;
+      }
+    }
+    const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
   int64_t m0, slot_base = 0;
@@ -63,8 +78,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     }
     n0 = dt * 128;
   }
-  const int64_t Mv = (EPI == 0 && g.m_dev) ? *g.m_dev : g.M;
-  if (EPI == 0 && m0 >= Mv) return;  // uniform
+  if (EPI == 0 && m0 >= Mv) return;  // uniform (cannot happen after the live-count remap; kept as the bound it documents)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int r16 = lane & 15, q4 = lane >> 4;

@@ -77,8 +77,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
 
   // ---- block -> tile (XCD-aware, bijective for any grid size) ----
   unsigned bid = blockIdx.x;
+  int64_t Mrows = g.M;
   {
-    const unsigned nblk = gridDim.x, q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
+    // With a device-side row count the grid is sized for the padded batch and the tiles past the live rows are the last
+    // logical ones: the remap (a contiguous logical range per XCD) runs over the LIVE block count, or the last XCDs would get
+    // nothing but tiles that exit (gemm_bf16.hip has the measurement).  Hardware blocks past the live count exit.
+    unsigned nblk = gridDim.x;
+    if (EPI == EPI_LINEAR && g.m_dev) {
+      Mrows = live_rows_padded(g);
+      const int64_t live = (((Mrows + BM - 1) / BM) * (int64_t)g.tiles_n - g.tile_base) * (g.ksplit > 1 ? g.ksplit : 1);
+      if (live < (int64_t)nblk) {
+        if ((int64_t)bid >= live) return;  // uniform
+        nblk = (unsigned)live;
+      }
+    }
+    const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
   int split = 0;
@@ -100,11 +113,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
   }
   const int64_t m0 = mt * BM;
   const int n0 = nt * BN;
-  int64_t Mrows = g.M;
-  if (EPI == EPI_LINEAR && g.m_dev) {
-    Mrows = live_rows_padded(g);
-    if (m0 >= Mrows) return;  // uniform: a tile past the device-side row count
-  }
+  if (EPI == EPI_LINEAR && g.m_dev && m0 >= Mrows) return;  // uniform: a tile past the device-side row count
 
   const int tid = threadIdx.x;
   // ---- staging map: 8 lanes cover one 128-B row segment, 32 rows per pass, 4 passes ----

@@ -40,8 +40,18 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_f32_small_kernel(const SmallGe
   float* const As = smem;
   float* const Bs = smem + 2 * SB * SLD;
   unsigned bid = blockIdx.x;
+  const int64_t Mrows = g.m_dev ? *g.m_dev : g.M;
+  // live row tiles: with a device-side row count the grid is sized for M and the remap below (a contiguous logical range per
+  // XCD) runs over the live workgroups only — otherwise the tiles that exit would all belong to the last XCDs
+  const unsigned tiles_m = g.m_dev ? (unsigned)((Mrows + SB - 1) / SB) : (unsigned)g.tiles_m;
   {
-    const unsigned nblk = gridDim.x, q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
+    unsigned nblk = gridDim.x;
+    const unsigned live = tiles_m * (unsigned)g.tiles_n * (unsigned)g.ksplit;
+    if (live < nblk) {
+      if (bid >= live) return;  // uniform
+      nblk = live;
+    }
+    const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, j = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
   // bid is now contiguous per XCD.  Row tile fastest, then column tile, K split slowest: the n/8 workgroups of an XCD
@@ -49,12 +59,11 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_f32_small_kernel(const SmallGe
   // its L2 pulls through the Infinity Cache is (tiles_m + n/(8*tiles_m)) panels of kchunk instead of all of W over all of K.
   // (Measured on MI355X: generate() is unchanged to +-0.3 % against the old split-fastest, row-major order — these launches
   // are not bound by where their operands come from, profiles/r03_small_gemm_tile_order_ab.txt — so this is traffic, not time.)
-  const unsigned tiles = (unsigned)g.tiles_m * (unsigned)g.tiles_n, t = bid % tiles;
+  const unsigned tiles = tiles_m * (unsigned)g.tiles_n, t = bid % tiles;
   const int split = (int)(bid / tiles);
-  const unsigned tile = (t % (unsigned)g.tiles_m) * (unsigned)g.tiles_n + t / (unsigned)g.tiles_m;  // slab index stays row-major
+  const unsigned tile = (t % tiles_m) * (unsigned)g.tiles_n + t / tiles_m;  // slab index stays row-major
   const int64_t m0 = (int64_t)(tile / (unsigned)g.tiles_n) * SB;
   const int n0 = (int)(tile % (unsigned)g.tiles_n) * SB;
-  const int64_t Mrows = g.m_dev ? *g.m_dev : g.M;
   if (m0 >= Mrows) return;  // uniform
   const int tid = threadIdx.x;
   // staging: 8 lanes cover one 128-B row segment, 32 rows per pass, 2 passes per operand
