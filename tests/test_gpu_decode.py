@@ -259,6 +259,32 @@ def test_generate_leaves_the_step_loop_when_every_query_is_done(dev):
         assert torch.equal(a, b)
 
 
+def test_graph_replay_with_constrained_beams_that_finish_early(dev):
+    """The captured form of a call whose queries are all done before max_length: the capture holds every step, the device
+    word makes the later ones skip their linears at replay time (the host-side exit cannot apply to a graph), and eager and
+    replayed calls return the same hypotheses."""
+    import dataclasses
+    from gdr_amd import codec
+    from gdr_amd.modeling import GDRModel
+    cfg = GDRConfig.tiny()
+    cfg = dataclasses.replace(cfg, max_output_length=10, decode_vocab_size=cfg.output_vocab_size * 10 + 2)
+    sd = synth.make_state_dict(cfg, seed=5)
+    V = cfg.output_vocab_size
+    g = np.random.Generator(np.random.PCG64(9))
+    docids = sorted({"-".join(str(int(x)) for x in g.integers(0, V, size=int(g.integers(2, 4)))) for _ in range(60)})
+    trie = codec.Trie.from_docids(docids, V)
+    eager, graphed = GDRModel(cfg, sd, dev, trie=trie, prefix_trie=trie), GDRModel(cfg, sd, dev, trie=trie, prefix_trie=trie, graph=True)
+    for seed in (1, 2):
+        ids, mask = synth.make_tokens(4, L=9, vocab_hi=cfg.vocab_size, seed=seed, min_len=2)
+        it, mt = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+        kw = dict(attention_mask=mt, max_length=cfg.max_output_length, num_beams=5, length_penalty=0.8, num_return_sequences=5,
+                  output_scores=True)
+        (d0, s0), _ = eager.generate(it, **kw)
+        (d1, s1), _ = graphed.generate(it, **kw)
+        (d2, s2), _ = graphed.generate(it, **kw)
+        assert torch.equal(d0, d1) and torch.equal(d1, d2) and s0 == s1 == s2
+
+
 def test_two_stage_with_reencode_vs_oracle(dev):
     """Stage-2 re-encode path (main_models.py:1445-1455): candidate docs embedded on the fly by the
     doc tower, then reranked — vs the oracle composition bert_ref + rerank."""
