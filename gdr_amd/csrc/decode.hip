@@ -884,14 +884,24 @@ struct SideLease {
 // One linear of the decode path.  fp32: the split-K / small-tile launcher (device-side row count when m_dev is given).
 // bf16 precision mode (BASELINE config C5): W points to bf16 data, the activation operand is rounded to bf16 into `abf`
 // (RNE) and the GEMM accumulates in fp32; bias / residual / output stay fp32.
+// bf16 mode: the norm that produced a linear's fp32 operand also left it rounded to bf16 (`buf`), so the linear needs no cast
+// launch of its own — `src` says which fp32 buffer the image belongs to; anything else is cast as before.  One per chain
+// (stream); whoever rewrites a normed buffer by other means resets `src`.
+struct Bf16Image {
+  const float* src = nullptr;
+  void* buf = nullptr;
+};
+
 static int dec_linear(bool bf16, void* abf, const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
                       int64_t M, const int64_t* m_dev, int N, int K, int epi, const float* bias, const float* res, int64_t ldr,
-                      float* skw, hipStream_t st, StreamK* sk = nullptr) {
+                      float* skw, hipStream_t st, StreamK* sk = nullptr, const Bf16Image* img = nullptr) {
   if (!bf16)
     return m_dev ? launch_linear_f32_ws_dev(A, lda, W, ldw, C, ldc, M, m_dev, N, K, epi, bias, res, ldr, skw, SPLITK_WS_BYTES, st, sk)
                  : launch_linear_f32_ws(A, lda, W, ldw, C, ldc, M, N, K, epi, bias, res, ldr, skw, SPLITK_WS_BYTES, st, sk);
   if (M == 0) return GDR_OK;
   GDR_CHECK_ARG(lda == K && K % 8 == 0, "decode(bf16): the activation operand must be dense with K %% 8 == 0");
+  if (img && img->buf && img->src == A)  // the producing norm already wrote this operand's bf16 image
+    return launch_linear_bf16(img->buf, K, W, ldw, C, ldc, M, N, K, epi, bias, res, ldr, st, m_dev);
   if (int rc = launch_cast_f32_bf16(A, abf, M * (int64_t)K, st)) return rc;
   return launch_linear_bf16(abf, K, W, ldw, C, ldc, M, N, K, epi, bias, res, ldr, st, m_dev);
 }
@@ -900,7 +910,8 @@ static int dec_linear(bool bf16, void* abf, const float* A, int64_t lda, const f
 // finished row (one launch instead of two or three); otherwise the linear and the norm kernels run one after another.
 static int dec_linear_norm(bool bf16, void* abf, const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
                            int64_t M, const int64_t* m_dev, int N, int K, int epi, const float* bias, const float* res,
-                           int64_t ldr, float* skw, hipStream_t st, const NormEpilogue& ne, StreamK* sk = nullptr) {
+                           int64_t ldr, float* skw, hipStream_t st, const NormEpilogue& ne, StreamK* sk = nullptr,
+                           Bf16Image* img = nullptr) {
   if (M == 0) return GDR_OK;
   static const bool fuse_on = [] {
     const char* e = getenv("GDR_DECODE_FUSE_NORM");  // A/B knob: 0 = always separate launches
@@ -917,17 +928,21 @@ static int dec_linear_norm(bool bf16, void* abf, const float* A, int64_t lda, co
                                            m_dev, &ne, nullptr, sk ? sk->live : nullptr);
     if (rc <= 0) return rc;
   }
-  if (int rc = dec_linear(bf16, abf, A, lda, W, ldw, C, ldc, M, m_dev, N, K, epi, bias, res, ldr, skw, st, sk)) return rc;
+  if (int rc = dec_linear(bf16, abf, A, lda, W, ldw, C, ldc, M, m_dev, N, K, epi, bias, res, ldr, skw, st, sk, img)) return rc;
+  // bf16 mode: the last norm of this call also leaves its output rounded to bf16 for the linear that reads it next
+  void* y16 = (bf16 && img && img->buf && ne.ldy == N) ? img->buf : nullptr;
+  if (img) img->src = y16 ? ne.Y : nullptr;
   if (ne.kind == 1)
-    return m_dev ? launch_rmsnorm_dev(C, ne.w1, ne.Y, m_dev, M, N, ne.eps, st) : launch_rmsnorm(C, ne.w1, ne.Y, M, N, ne.eps, nullptr, 1, st);
+    return m_dev ? launch_rmsnorm_dev(C, ne.w1, ne.Y, m_dev, M, N, ne.eps, st, y16)
+                 : launch_rmsnorm(C, ne.w1, ne.Y, M, N, ne.eps, nullptr, 1, st, y16);
   // LayerNorm(s): the second one reads the first one's output through Y
   float* y1 = ne.kind == 3 ? C : ne.Y;  // kind 3: norm1 may overwrite C (the pre-norm rows are not needed again)
-  if (int rc = m_dev ? launch_layernorm_dev(C, ne.w1, ne.b1, y1, m_dev, M, N, ne.eps, nullptr, st)
-                     : launch_layernorm(C, ne.w1, ne.b1, y1, M, N, ne.eps, nullptr, st))
+  if (int rc = m_dev ? launch_layernorm_dev(C, ne.w1, ne.b1, y1, m_dev, M, N, ne.eps, nullptr, st, ne.kind == 3 ? nullptr : y16)
+                     : launch_layernorm(C, ne.w1, ne.b1, y1, M, N, ne.eps, nullptr, st, ne.kind == 3 ? nullptr : y16))
     return rc;
   if (ne.kind == 3)
-    return m_dev ? launch_layernorm_dev(y1, ne.w2, ne.b2, ne.Y, m_dev, M, N, ne.eps, ne.addv, st)
-                 : launch_layernorm(y1, ne.w2, ne.b2, ne.Y, M, N, ne.eps, ne.addv, st);
+    return m_dev ? launch_layernorm_dev(y1, ne.w2, ne.b2, ne.Y, m_dev, M, N, ne.eps, ne.addv, st, y16)
+                 : launch_layernorm(y1, ne.w2, ne.b2, ne.Y, M, N, ne.eps, ne.addv, st, y16);
   return GDR_OK;
 }
 // element offset into a linear weight (fp32 or bf16 storage)
@@ -937,7 +952,7 @@ static const float* w_at(const float* W, size_t elems, bool bf16) {
 
 // ------------------------------------------------------------------------------------------ model workspace
 struct GenWs {
-  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, abf, abf2, total;
+  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, abf, abf2, img1, img2, total;
 };
 
 static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
@@ -968,6 +983,8 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
   const size_t abf_main = rows * ffw > (size_t)bd.B * L * d ? rows * ffw : (size_t)bd.B * L * d;
   g.abf = carve(o, 2 * abf_main);                       // bf16 mode: the rounded activation operand of a linear (main stream)
   g.abf2 = carve(o, 2 * abf_main);                      //            ... of the side stream (adaptor chain, cross K/V projections)
+  g.img1 = carve(o, 2 * rows * d);                      // bf16 mode: the bf16 image of the last normed rows of either chain (Bf16Image)
+  g.img2 = carve(o, 2 * rows * d);
   g.total = o;
   return g;
 }
@@ -1027,6 +1044,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
         *nx = F(g.nx), *ctx = F(g.ctx), *qc = F(g.qc), *ff = F(g.ff), *tmp = F(g.tmp), *A = F(g.A), *hl = F(g.hl),
         *skw = F(g.splitk), *ctx2 = F(g.ctx2), *ff2 = F(g.ff2), *skw2 = F(g.splitk2), *qkv_c = F(g.qkv_c);
   void *abf = base + g.abf, *abf2 = base + g.abf2;
+  Bf16Image img1{nullptr, bf16 ? base + g.img1 : nullptr}, img2{nullptr, bf16 ? base + g.img2 : nullptr};
   GDR_CHECK_ARG(!bf16 || (dm.d_model % 8 == 0 && dm.d_ff % 8 == 0 && (dm.num_heads * dm.d_kv) % 8 == 0 && w->adaptor_ff % 8 == 0),
                 "generate(bf16): dims must be multiples of 8");
   const int d = dm.d_model, H = dm.num_heads, dk = dm.d_kv, inner = H * dk;
@@ -1038,13 +1056,13 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   const size_t ckv_layer = (size_t)B * L * 2 * inner;
 
 #define LIN(A_, lda_, W_, ldw_, C_, ldc_, M_, N_, K_, epi_, bias_, res_, ldr_) \
-  dec_linear(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream, &sk1)
+  dec_linear(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream, &sk1, &img1)
 #define LIN2(A_, lda_, W_, ldw_, C_, ldc_, M_, N_, K_, epi_, bias_, res_, ldr_) \
-  dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw2, as, &sk2)
+  dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw2, as, &sk2, &img2)
 #define LINN(A_, lda_, W_, ldw_, C_, ldc_, M_, N_, K_, epi_, bias_, res_, ldr_, ne_) \
-  dec_linear_norm(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream, ne_, &sk1)
+  dec_linear_norm(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream, ne_, &sk1, &img1)
 #define LIN2N(A_, lda_, W_, ldw_, C_, ldc_, M_, md_, N_, K_, epi_, bias_, res_, ldr_, ne_) \
-  dec_linear_norm(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, M_, md_, N_, K_, epi_, bias_, res_, ldr_, skw2, as, ne_, &sk2)
+  dec_linear_norm(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, M_, md_, N_, K_, epi_, bias_, res_, ldr_, skw2, as, ne_, &sk2, &img2)
   auto rms = [&](const float* wgt, float* y) { return NormEpilogue{1, wgt, nullptr, nullptr, nullptr, nullptr, dm.eps, y, (int64_t)dm.d_model}; };
   auto ln = [&](const float* w1, const float* b1, float* y) {
     return NormEpilogue{2, w1, b1, nullptr, nullptr, nullptr, w->adaptor_eps, y, (int64_t)dm.d_model};
@@ -1126,6 +1144,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       break;
     }
     hipStream_t as = ss.ok ? ss.s : stream;   // adaptor stream
+    img1.src = img2.src = nullptr;            // the embedding kernels below rewrite nx / xa without a bf16 image
     // Step 0: the R beam rows of a query hold the same START token and the same encoder states, so their decoder /
     // adaptor / head outputs are identical rows (generation_utils.py:437-442 expands the encoder states, :663-668 starts
     // every beam but the first at -1e9): one row per query is computed (row b of the step-0 cache slots; every row's
@@ -1187,7 +1206,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       }
     }
 #define LIN2D(A_, lda_, W_, ldw_, C_, ldc_, N_, K_, epi_, bias_, res_, ldr_) \
-  dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, rows_s, nm, N_, K_, epi_, bias_, res_, ldr_, skw2, as, &sk2)
+  dec_linear(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, rows_s, nm, N_, K_, epi_, bias_, res_, ldr_, skw2, as, &sk2, &img2)
     auto ad_layer_tab = [&](int l) -> int {
         const GdrAdaptorLayer& al = w->alayers[l];
         float* cache = acache + l * alayer;

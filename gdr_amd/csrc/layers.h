@@ -69,13 +69,14 @@ int launch_scatter_rows(const float* src, const int32_t* row_src, const int64_t*
                         float* dst, hipStream_t stream);
 // y = x / sqrt(mean(x^2) + eps) * w     (T5LayerNorm, modeling_t5.py:164-171); optional second output
 // `pooled` receives rows r with r % pool_every == 0 (CLS pool h[:,0]) when non-null.
+// y16 (optional, everywhere below): the same output once more, rounded to bf16 (RNE) — the operand of a bf16-mode linear
 int launch_rmsnorm(const float* x, const float* w, float* y, int64_t rows, int d, float eps, float* pooled,
-                   int pool_every, hipStream_t stream);
+                   int pool_every, hipStream_t stream, void* y16 = nullptr);
 // x[b, j, :] = 0 for j >= seq_len[b]  (x is [B, L, d])
 int launch_zero_dead_rows(float* x, const int32_t* seq_len, int B, int L, int d, hipStream_t stream);
 // same over the first *rows_dev rows (a device-side count; the grid is sized for max_rows)
 int launch_rmsnorm_dev(const float* x, const float* w, float* y, const int64_t* rows_dev, int64_t max_rows, int d, float eps,
-                       hipStream_t stream);
+                       hipStream_t stream, void* y16 = nullptr);
 // same, output rounded to bf16 (RNE): the activation operand of a bf16-mode linear
 int launch_rmsnorm_bf16(const float* x, const float* w, void* y_bf16, int64_t rows, int d, float eps, hipStream_t stream);
 int launch_rmsnorm_bf16_dev(const float* x, const float* w, void* y_bf16, const int64_t* rows_dev, int64_t max_rows, int d,
@@ -83,8 +84,8 @@ int launch_rmsnorm_bf16_dev(const float* x, const float* w, void* y_bf16, const 
 // y = (x - mean) / sqrt(var + eps) * w + b   (torch.nn.LayerNorm; BERT / nn.TransformerDecoderLayer)
 // optional addv [d]: y = LN(x + addv)  (the adaptor's constant single-key cross-attention output)
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int d, float eps,
-                     const float* addv, hipStream_t stream);
+                     const float* addv, hipStream_t stream, void* y16 = nullptr);
 int launch_layernorm_dev(const float* x, const float* w, const float* b, float* y, const int64_t* rows_dev, int64_t max_rows,
-                         int d, float eps, const float* addv, hipStream_t stream);
+                         int d, float eps, const float* addv, hipStream_t stream, void* y16 = nullptr);
 
 }  // namespace gdr

@@ -228,7 +228,7 @@ template <bool BF16OUT>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       float* __restrict__ y, int64_t rows, int d4, float eps,
                                                       float* __restrict__ pooled, int pool_every,
-                                                      const int64_t* __restrict__ rows_dev) {
+                                                      const int64_t* __restrict__ rows_dev, uint2* __restrict__ y16 = nullptr) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (rows_dev) rows = *rows_dev;
   if (row >= rows) return;
@@ -254,26 +254,27 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     } else {
       yr[c] = o;
       if (pr) pr[c] = o;
+      if (y16) (y16 + row * d4)[c] = pack_bf16x4(o.x, o.y, o.z, o.w);  // the same values, rounded: a bf16 linear's operand
     }
   }
 }
 
 int launch_rmsnorm(const float* x, const float* w, float* y, int64_t rows, int d, float eps, float* pooled,
-                   int pool_every, hipStream_t stream) {
+                   int pool_every, hipStream_t stream, void* y16) {
   GDR_CHECK_ARG(d % 4 == 0, "rmsnorm: d %% 4 != 0");
   if (rows == 0) return GDR_OK;
   hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, y, rows, d / 4, eps,
-                     pooled, pool_every > 0 ? pool_every : 1, (const int64_t*)nullptr);
+                     pooled, pool_every > 0 ? pool_every : 1, (const int64_t*)nullptr, static_cast<uint2*>(y16));
   GDR_CHECK_LAUNCH("rmsnorm_kernel");
   return GDR_OK;
 }
 
 int launch_rmsnorm_dev(const float* x, const float* w, float* y, const int64_t* rows_dev, int64_t max_rows, int d, float eps,
-                       hipStream_t stream) {
+                       hipStream_t stream, void* y16) {
   GDR_CHECK_ARG(d % 4 == 0, "rmsnorm: d %% 4 != 0");
   if (max_rows == 0) return GDR_OK;
   hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((unsigned)((max_rows + 3) / 4)), dim3(256), 0, stream, x, w, y, max_rows,
-                     d / 4, eps, (float*)nullptr, 1, rows_dev);
+                     d / 4, eps, (float*)nullptr, 1, rows_dev, static_cast<uint2*>(y16));
   GDR_CHECK_LAUNCH("rmsnorm_kernel(dev rows)");
   return GDR_OK;
 }
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ b, float* __restrict__ y,
                                                         int64_t rows, int d4, float eps,
                                                         const float* __restrict__ addv,
-                                                        const int64_t* __restrict__ rows_dev) {
+                                                        const int64_t* __restrict__ rows_dev, uint2* __restrict__ y16) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (rows_dev) rows = *rows_dev;
   if (row >= rows) return;
@@ -352,25 +353,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     o.x = (v.x - mean) * rstd * g.x + bb.x, o.y = (v.y - mean) * rstd * g.y + bb.y;
     o.z = (v.z - mean) * rstd * g.z + bb.z, o.w = (v.w - mean) * rstd * g.w + bb.w;
     yr[c] = o;
+    if (y16) (y16 + row * d4)[c] = pack_bf16x4(o.x, o.y, o.z, o.w);
   }
 }
 
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int d, float eps,
-                     const float* addv, hipStream_t stream) {
+                     const float* addv, hipStream_t stream, void* y16) {
   GDR_CHECK_ARG(d % 4 == 0, "layernorm: d %% 4 != 0");
   if (rows == 0) return GDR_OK;
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, b, y, rows, d / 4,
-                     eps, addv, (const int64_t*)nullptr);
+                     eps, addv, (const int64_t*)nullptr, static_cast<uint2*>(y16));
   GDR_CHECK_LAUNCH("layernorm_kernel");
   return GDR_OK;
 }
 
 int launch_layernorm_dev(const float* x, const float* w, const float* b, float* y, const int64_t* rows_dev, int64_t max_rows,
-                         int d, float eps, const float* addv, hipStream_t stream) {
+                         int d, float eps, const float* addv, hipStream_t stream, void* y16) {
   GDR_CHECK_ARG(d % 4 == 0, "layernorm: d %% 4 != 0");
   if (max_rows == 0) return GDR_OK;
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((max_rows + 3) / 4)), dim3(256), 0, stream, x, w, b, y, max_rows, d / 4,
-                     eps, addv, rows_dev);
+                     eps, addv, rows_dev, static_cast<uint2*>(y16));
   GDR_CHECK_LAUNCH("layernorm_kernel(dev rows)");
   return GDR_OK;
 }
