@@ -14,6 +14,16 @@ queries, which it merges (gdr_amd/dist.py); the exchange runs on a side stream u
 The encoder runs in its ragged form by default (PAD token rows are not computed, the last block runs on the CLS rows
 only; pooled output bit-identical to the padded form — tests/test_gpu_ragged.py); --encoder padded computes all rows.
 
+`python bench.py --gpus N` needs no launcher typed by hand: with no RANK in the environment the command (which has not
+touched a GPU) starts the N ranks as fresh child processes of `python -m torch.distributed.run` (gdr_amd/launch.py), relays
+rank 0's JSON line and exits non-zero if any rank does; under torch.distributed.run it is a rank.
+
+--workload c3 / c5 measure the TWO-STAGE path (BASELINE configs C3 / C5) in the same JSON contract: a step = one batch of
+queries per GPU through GDRRetriever.validation_step_i — encoder -> docid beam decode -> device cluster lookup -> in-cluster
+rerank over 7 alphas -> host formatting; at N > 1 the corpus is row-sharded and stage 2 is dist.ShardedIndex.rerank_own
+(one all-gather of queries + candidate blocks, per-shard scoring, one all-to-all, merge).  c3: 320k x 768 fp32, beam 10,
+64 queries per GPU; c5: 1M x 768 bf16 corpus, beam 30, bf16 linear operands, 512 queries per GPU (4 096 at 8 GPUs).
+
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the fp32 MFMA GEMM that serves every
 encoder linear: algorithmic flops per launch / average launch duration, both measured live over the timed
 region with hipEvent pairs recorded by the library on the launch stream (gdr_prof_*).  `cpu_baseline` is the
@@ -45,8 +55,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="queries per GPU per step")
-    ap.add_argument("--corpus", type=int, default=320000)
+    ap.add_argument("--workload", choices=["c2", "c3", "c5"], default="c2",
+                    help="c2 (default, the headline): encoder + Q.D^T top-100; c3 / c5: the two-stage GDR path (beam decode "
+                         "-> in-cluster rerank), c5 with the 1M-row bf16 corpus, beam 30 and bf16 linear operands")
+    ap.add_argument("--batch", type=int, default=None, help="queries per GPU per step (default: 512 for c2 / c5, 64 for c3)")
+    ap.add_argument("--corpus", type=int, default=None, help="corpus rows (default: 320000; c5: 1000000)")
+    ap.add_argument("--beams", type=int, default=None, help="c3 / c5: num_beams = num_return_sequences (default 10 / 30)")
+    ap.add_argument("--depth", type=int, default=2, help="c3 / c5: batches in flight (GDRRetriever.validation_steps)")
+    ap.add_argument("--constrained", action="store_true",
+                    help="c3 / c5: constrain the beams to the corpus' docid trie (generation_utils_previous.py:714-729) — every "
+                         "hypothesis names a real cluster and the call leaves its step loop early, as a trained model does")
+    ap.add_argument("--launcher", action="store_true",
+                    help="start the rank processes through torch.distributed.run even for --gpus 1 (a 1-rank RCCL group)")
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = the reference's precision (the headline); bf16 = config C5's precision mode: bf16 linear "
@@ -61,7 +81,16 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the `stages` object (other stages of the path, N = 1)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.batch is None:
+        a.batch = 64 if a.workload == "c3" else 512
+    if a.corpus is None:
+        a.corpus = 1000000 if a.workload == "c5" else 320000
+    if a.beams is None:
+        a.beams = 30 if a.workload == "c5" else 10
+    if a.workload == "c5":
+        a.dtype = "bf16"
+    return a
 
 
 def host_threads():
@@ -107,14 +136,50 @@ def cpu_baseline(sd, cfg, ids, mask, D, k, budget_s=25.0):
             break
         n = min(n * 2, ids.shape[0])
     ts = [t]
-    for _ in range(2):
+    for _ in range(4):
         t0 = time.perf_counter()
         run(n)
         ts.append(time.perf_counter() - t0)
-    med = sorted(ts)[1]
+    med = sorted(ts)[2]
     return {"value": n / med, "unit": "queries/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
             "sample": f"{n} of the step's queries through the whole path (encoder fp32 + Q.D^T top-{k} over "
-                      f"all {D.shape[0]} docs), torch-CPU oracle, warm-up + median of 3 ({med:.2f} s each)"}
+                      f"all {D.shape[0]} docs), torch-CPU oracle, warm-up + median of 5 ({med:.2f} s each)"}
+
+
+def cpu_baseline_two_stage(sd, cfg, ids, mask, D, lookup, R, alphas, n=2, reps=1, budget_s=40.0):
+    """The two-stage path on the host cores in the REFERENCE's formulation (generation_utils.py:412-413,520-521 time exactly
+    this split; call site main_models.py:1380-1397): oracle generate() with use_cache=False semantics (every position
+    recomputed every step) and the full 302-column adaptor head (restricted_head=False), then decode_token -> candidate lookup
+    -> the oracle rerank over all alphas.  n queries per call (a bounded sample), `reps` timed calls after none (the first
+    call is the measurement when the budget is short: a 100-beam query is ~1.6 TFLOP of head GEMM).
+    lookup: cluster string -> list of doc ids (codec.ClusterIndex)."""
+    from oracle import beam_ref, codec_ref, retrieval_ref
+    torch.set_num_threads(host_threads())
+    ids_t, mask_t, Dt = torch.from_numpy(ids[:n]), torch.from_numpy(mask[:n]), torch.from_numpy(np.asarray(D, np.float32))
+
+    def run():
+        t0 = time.perf_counter()
+        (dec, scores), enc_x = beam_ref.generate(sd, cfg, ids_t, mask_t, R, length_penalty=0.8, restricted_head=False)
+        t1 = time.perf_counter()
+        names = codec_ref.dec_2d(codec_ref.decode_token(dec.numpy(), cfg.output_vocab_size, cfg.output_vocab_size), R)
+        mem = [[m for s_ in row for m in lookup[s_]] for row in names]
+        num = [[len(lookup[s_]) for s_ in row] for row in names]
+        ran[0] = all(len(m) >= R for m in mem)                 # topk(R) raises on fewer candidates (main_models.py:1625)
+        if ran[0]:
+            retrieval_ref.rerank(enc_x[::R][:, 0], Dt, mem, num, np.asarray(scores, np.float32).reshape(n, R).tolist(), alphas, R)
+        return t1 - t0, time.perf_counter() - t0
+
+    ts, ran = [], [False]
+    for _ in range(max(1, reps)):
+        ts.append(run())
+        if sum(t[1] for t in ts) > budget_s:
+            break
+    gen_s, tot_s = sorted(ts, key=lambda t: t[1])[len(ts) // 2]
+    return {"value": n / tot_s, "unit": "queries/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
+            "generate_s": gen_s, "total_s": tot_s, "rerank_ran": bool(ran[0]),
+            "sample": f"{n} quer{'y' if n == 1 else 'ies'} x {R} beams through the whole two-stage path in the reference's formulation "
+                      f"(use_cache=False recompute, full 302-column head, then in-cluster rerank over {len(alphas)} alphas), "
+                      f"torch-CPU oracle, median of {len(ts)} call(s) ({tot_s:.1f} s each, generate {gen_s:.1f} s)"}
 
 
 def recall_at(idx, gold, ks=(1, 10, 100)):
@@ -209,9 +274,14 @@ def stages(dev, cfg, D, D_dev, a):
     mf_head = 2 * V1 * d * d / 1e6                                                       # 36.6
     args = types.SimpleNamespace(num_return_sequences=10, output_vocab_size=30, max_output_length=10, length_penalty=0.8,
                                  kary=30, position=1, score_rate=[0, 0.5, 1, 1.5, 2, 2.5, 3], loss_func="tanh")
-    gen = {}
-    for B, R in ((64, 10), (1, 100), (512, 10)):       # C3 at infer.sh's eval batch, one query x 100 beams, C2's batch
+    gen, cpu_two = {}, {}
+    ids_np, mask_np = {}, {}
+    # C3 at infer.sh's eval batch, one query x 100 beams, C2's batch, and the batch sweep that shows where the decode chain stops
+    # being launch-bound (a reduced --corpus, as the contract test runs, skips the sweep)
+    sweep = ((64, 10), (1, 100), (512, 10)) + (((128, 10), (256, 10), (1024, 10), (2048, 10)) if N >= 300000 else ())
+    for B, R in sweep:
         ids, mask = synth.make_tokens(B, L=40, seed=11)
+        ids_np[(B, R)], mask_np[(B, R)] = ids, mask
         ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
         steps = 9
         g = lambda: model.generate(ids, attention_mask=mask, max_length=10, num_beams=R, length_penalty=0.8,   # noqa: E731
@@ -271,13 +341,24 @@ def stages(dev, cfg, D, D_dev, a):
                     "bandwidth-bound, at these sizes"}
         nb, depth = (16, 4) if B == 1 else (8, 2) if B <= 64 else (4, 2)   # a stream of batches, `depth` in flight (GDRRetriever.validation_steps)
         tp = timed(lambda: list(retr.validation_steps(iter([batch] * nb), depth=depth)), reps=3, warm=1) / nb
-        out["c3_two_stage_infer_sh" if B == 1 else "c3_two_stage" if B == 64 else f"c3_two_stage_B{B}"] = {
+        skey = "c3_two_stage_infer_sh" if B == 1 else "c3_two_stage" if B == 64 else f"c3_two_stage_B{B}"
+        if not a.no_cpu_baseline and B in (1, 64):
+            # the CPU path beside this stage (SURVEY §8d "per config"): the oracle in the reference's formulation
+            nq = 1 if B == 1 else 2
+            cpu_two[skey] = cpu_baseline_two_stage(sd, cfg, ids_np[(B, R)], mask_np[(B, R)], D, look, R, a_r.score_rate, n=nq,
+                                                   reps=1 if B == 1 else 3)
+        out[skey] = {
             "batch": B, "beams": R, "ms": t3 * 1e3, "queries_per_s": B / t3, "pipelined_depth": depth,
             "pipelined_ms_per_batch": tp * 1e3, "pipelined_queries_per_s": B / tp,
             "generate_ms": t * 1e3, "after_generate_ms": (t3 - t) * 1e3,
             "note": "encoder -> beam decode -> device cluster lookup -> in-cluster rerank over 7 alphas -> host formatting; `ms` = one batch start to finish, "
                     "`pipelined_*` = a stream of batches with `pipelined_depth` in flight on separate HIP streams while the "
                     "host post-processes the previous one"}
+    for skey, cb in cpu_two.items():
+        out[skey]["cpu_baseline"] = cb
+    best = max((v for kname, v in out.items() if kname.startswith("c3_two_stage")), key=lambda v: v["pipelined_queries_per_s"])
+    out["c3_best_sustained"] = {"batch": best["batch"], "beams": best["beams"], "queries_per_s": best["pipelined_queries_per_s"],
+                                "frac_of_floor_executed": gen[f"B{best['batch']}_beam{best['beams']}"]["frac_of_floor_executed"]}
     out["generate"] = gen
     out["generate"]["mflop_per_row_step"] = {"decoder": mf_dec, "adaptor": mf_adp, "head": mf_head}
     # ---- the trie-constrained mode (opt-in, generation_utils_previous.py:714-729): every hypothesis is a
@@ -352,16 +433,37 @@ def stages(dev, cfg, D, D_dev, a):
     return out
 
 
-def main():
-    a = parse()
+def fence(dist):
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def launch_self(a):
+    """`python bench.py --gpus N` with no RANK in the environment: this process (no GPU call made) starts the N ranks as fresh
+    children under torch.distributed.run, lets rank 0's JSON line through to stdout (everything else the ranks print goes to
+    stderr) and exits with the launcher's code."""
+    from gdr_amd import launch
+    tail = [x for x in sys.argv[1:] if x != "--launcher"]
+
+    def relay(line):
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        (sys.stdout if line.startswith("{") else sys.stderr).flush()
+
+    rc, _ = launch.spawn_ranks(a.gpus, tail, script=os.path.abspath(__file__), relay=relay)
+    raise SystemExit(rc)
+
+
+def init_ranks(a):
+    """(rank, world, device, dist) of this process; under torch.distributed.run the RCCL group is set up (and warmed: RCCL
+    connects lazily) before anything is timed."""
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         a.gpus = world
-    import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run
@@ -369,14 +471,135 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
         _t = torch.ones(1, device=dev)
-        dist.all_reduce(_t)                  # communicator set-up (RCCL connects lazily) stays out of the timed region
-        torch.cuda.synchronize()             # even with --warmup 0
+        dist.all_reduce(_t)                  # communicator set-up stays out of the timed region even with --warmup 0
+        torch.cuda.synchronize()
     torch.set_grad_enabled(False)
+    return rank, world, dev, dist
+
+
+def two_stage_main(a):
+    """--workload c3 / c5: the two-stage GDR path (main_models.py:1337-1642) per GPU, stage 2 over the row-sharded corpus."""
+    import types
+    rank, world, dev, dist = init_ranks(a)
+    from gdr_amd import codec, ops, synth, _ffi
+    from gdr_amd.config import GDRConfig
+    from gdr_amd.dist import ShardedIndex, shard_bounds
+    from gdr_amd.modeling import GDRModel, GDRRetriever
+
+    cfg = GDRConfig.base()
+    bf16 = a.dtype == "bf16"
+    R, B = a.beams, a.batch
+    sd = synth.make_state_dict(cfg, seed=1234)
+    names, id_depth, offsets, members = synth.make_cluster_ids(a.corpus, cluster_size=12, V=30)
+    trie = codec.Trie.from_docids(names, 30)
+    model = GDRModel(cfg, sd, dev, ragged=True, prefix_trie=trie, trie=trie if a.constrained else None,
+                     dtype=torch.bfloat16 if bf16 else torch.float32)
+    lo, hi = shard_bounds(a.corpus, world, rank, cluster_size=12)
+    D = synth.make_corpus(a.corpus, cfg.d_model)
+    D_dev = torch.from_numpy(D[lo:hi]).to(dev)
+    if bf16:
+        D_dev = ops.to_bf16(D_dev)
+    ids_all, mask_all = synth.make_tokens(B * world, L=40, seed=11)
+    ids = torch.from_numpy(ids_all[rank * B:(rank + 1) * B]).to(dev)
+    mask = torch.from_numpy(mask_all[rank * B:(rank + 1) * B]).to(dev)
+    args = types.SimpleNamespace(num_return_sequences=R, output_vocab_size=30, max_output_length=10, length_penalty=0.8,
+                                 kary=30, position=1, score_rate=[0, 0.5, 1, 1.5, 2, 2.5, 3], loss_func="tanh")
+    if a.constrained:
+        look = codec.ClusterIndex(names, offsets, members)
+    else:
+        # random weights decode full-length rows that name no cluster: every string this rank's batch decodes gets a real
+        # 12-doc cluster, so stage 2 sees C3's candidate counts (R x 12 per query).  The index may differ per rank — the
+        # exchange carries doc ids, only the block width (R x largest cluster) must agree
+        (dec, _), _ = model.generate(ids, attention_mask=mask, max_length=10, num_beams=R, length_penalty=0.8,
+                                     num_return_sequences=R, output_scores=True)
+        strs = sorted(set(codec.decode_token(args, dec.cpu().numpy())))[:len(names)]
+        look = codec.ClusterIndex(strs + names[len(strs):], offsets, members)
+    sharded = ShardedIndex(D_dev, lo) if (world > 1 or dist.is_initialized()) else None
+    retr = GDRRetriever(model, None if sharded is not None else D_dev, look, args, sharded=sharded)
+    batch = {"source_ids": ids, "source_mask": mask}
+
+    def run(n):
+        outs = list(retr.validation_steps(iter([batch] * n), depth=max(1, a.depth)))
+        return outs[-1] if outs else None
+
+    if a.warmup:
+        run(a.warmup)
+    fence(dist)
+    t0 = time.perf_counter()
+    last = run(a.steps)
+    fence(dist)
+    dt = time.perf_counter() - t0
+    if dist.is_initialized():
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the dominant kernel class (every linear: encoder, decoder, adaptor, head) from a PROFILED replay of the same steps right
+    # after the timed region — ~1 100 launches per step, each bracketed by two hipEvents, would slow a launch-bound chain if
+    # they were recorded inside it
+    lib = _ffi.lib()
+    n_prof = min(a.steps, 3)
+    _ffi.check(lib.gdr_prof_enable(4000 * n_prof * max(1, a.depth)), "gdr_prof_enable")
+    run(n_prof)
+    torch.cuda.synchronize()
+    n_l, ms_l, w_l = (C.c_int64 * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
+    lost = lib.gdr_prof_collect(n_l, ms_l, w_l)
+    if lost < 0:
+        _ffi.check(lost, "gdr_prof_collect")
+    n_cand = int(sum(len(look[s_]) for s_ in last["clusters"][0])) if last is not None else 0
+    if rank == 0:
+        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else F32_MFMA_PEAK_TFLOPS
+        lin_tf = w_l[0] / (ms_l[0] * 1e-3) / 1e12 if ms_l[0] > 0 else 0.0
+        tag = a.workload.upper() + ("/constrained" if a.constrained else "") + ("/sharded" if sharded is not None else "")
+        result = {
+            "metric": "queries/sec on NQ-320k (768-d)" if a.workload == "c3" else "queries/sec on a 1Mx768 corpus (TriviaQA-scale)",
+            "value": B * world * a.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{tag}: two-stage GDR, {B} q/GPU, beam {R}, {a.corpus}x{cfg.d_model} {'bf16' if bf16 else 'fp32'} corpus",
+                       "note": "a step = one batch per GPU through validation_step_i: ragged t5-base encoder -> docid beam decode "
+                               f"(beam {R}, 9 steps, prefix table) -> device cluster lookup -> in-cluster rerank over 7 alphas "
+                               f"(top-{R}) -> host formatting; {max(1, a.depth)} batches in flight"
+                               + ("; beams constrained to the corpus' docid trie" if a.constrained else
+                                  "; unconstrained beams of random weights run all 9 steps, every decoded string is mapped to a real 12-doc cluster")
+                               + (f"; corpus row-sharded {world} ways, stage 2 = one all-gather of queries + candidate blocks, per-shard "
+                                  "scoring, one all-to-all of the packed lists, merge" if sharded is not None else ""),
+                       "batch_per_gpu": B, "global_batch": B * world, "beams": R, "seq_len": 40, "corpus_rows": a.corpus,
+                       "dim": cfg.d_model, "k": R, "alphas": 7, "candidates_per_query": n_cand, "pipeline_depth": max(1, a.depth),
+                       "corpus_resident_in_hbm": True, "docid_depth": id_depth},
+            "roofline": {"bound": "mfma",
+                         "kernel": ("every linear of the step (encoder, decoder, adaptor, head): gdr::gemm_nt_bf16_glds_kernel" if bf16 else
+                                    "every linear of the step (encoder, decoder, adaptor, head): gdr::gemm_nt_f32_small_kernel (64x64 "
+                                    "tiles, the decode rows) + gdr::gemm_nt_f32 persistent / stream-K (encoder)"),
+                         "achieved": lin_tf, "peak": peak, "unit": "TFLOP/s", "frac": lin_tf / peak, "traffic": None,
+                         "launches_per_step": int(n_l[0]) / n_prof, "avg_launch_ms": ms_l[0] / max(1, int(n_l[0])),
+                         "linear_ms_per_step": ms_l[0] / n_prof, "source": f"profiled replay of {n_prof} step(s) after the timed region "
+                         "(hipEvent pairs on the launch streams; summed durations of two overlapping chains can exceed the step's wall time)",
+                         "events_lost": int(lost)},
+            "kernels": {"attention_ms_per_step": ms_l[3] / n_prof, "rerank_dot_ms_per_step": ms_l[6] / n_prof,
+                        "rerank_select_ms_per_step": ms_l[5] / n_prof, "splitk_reduce_ms_per_step": ms_l[7] / n_prof},
+            "cpu_baseline": None, "recall": None, "stages": None,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_two_stage(sd, cfg, ids_all, mask_all, D, look, R, args.score_rate,
+                                                            n=1 if R > 10 else 2, reps=1 if R > 10 else 3)
+        print(json.dumps(result))
+        sys.stdout.flush()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if (a.gpus > 1 or a.launcher) and "RANK" not in os.environ:
+        launch_self(a)
+    if a.workload != "c2":
+        return two_stage_main(a)
+    rank, world, dev, dist = init_ranks(a)
 
     from gdr_amd import ops, synth, _ffi
     from gdr_amd.config import GDRConfig
     from gdr_amd.dist import ShardedIndex, shard_bounds
-
     cfg = GDRConfig.base()
     sd = synth.make_state_dict(cfg, seed=1234, with_decoder=False)
     bf16 = a.dtype == "bf16"
@@ -411,19 +634,13 @@ def main():
         pending[0] = None
         return out
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(a.warmup):
         step()
     drain()
     lib = _ffi.lib()
     launches_per_step = 13 * cfg.num_layers + 16        # per layer: 4 linears x (main + tail + reduce) + attention
     _ffi.check(lib.gdr_prof_enable(launches_per_step * a.steps + 16), "gdr_prof_enable")
-    fence()
+    fence(dist)
     t0 = time.perf_counter()
     out = None
     for _ in range(a.steps):
@@ -431,7 +648,7 @@ def main():
         out = r if r is not None else out
     r = drain()                                          # the last batch's exchange completes inside the timed region
     out = r if r is not None else out
-    fence()
+    fence(dist)
     dt = time.perf_counter() - t0
     n_l, ms_l, w_l = (C.c_int64 * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
     _ffi.check(lib.gdr_prof_collect(n_l, ms_l, w_l), "gdr_prof_collect")
@@ -469,8 +686,9 @@ def main():
             "metric": "queries/sec on NQ-320k (768-d)", "value": total_q / dt, "unit": "queries/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": ("C2" if world == 1 else "C4-layout") +
-                       f": t5-base encoder on {a.batch} queries/GPU (L=40) + fused Q.D^T top-{a.k} over a "
+            "config": {"workload": ("C2" if world == 1 else "C4-layout") + ("/ragged" if ragged else "/padded") + ("/bf16" if bf16 else "") +
+                       f": t5-base encoder {a.batch} q/GPU + Q.D^T top-{a.k}, {a.corpus}x{cfg.d_model} corpus",
+                       "note": f"t5-base encoder on {a.batch} queries/GPU (L=40) + fused Q.D^T top-{a.k} over a "
                        f"{a.corpus}x{cfg.d_model} {'bf16' if bf16 else 'fp32'} corpus" +
                        (" [C5 precision mode: bf16 linear operands, fp32 accumulate]" if bf16 else "") +
                        (f" [ragged encoder: the {live_rows} non-PAD token rows of {a.batch * 40} are computed, last block "
@@ -492,6 +710,8 @@ def main():
                                        "included in launches / flops / time)" if ragged else ")")),
                          "achieved": lin["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": lin["tflops"] / peak,
                          "traffic": None if bf16 else traffic,
+                         "traffic_source": None if (bf16 or traffic is None) else "profiles/traffic.json (static: rocprofv3 --pmc FETCH_SIZE / "
+                                           "WRITE_SIZE passes of this command, see profiles/r04_bench_pmc_hbm.md; not re-measured in this run)",
                          "launches": lin["launches"], "avg_launch_ms": lin["avg_ms"],
                          "algorithmic_gflop_per_launch": lin["gflop_per_launch"], "share_of_step": lin["share_of_step"]},
             "kernels": {"sim_sample_gemm": smp, "sim_filter_gemm": flt, "attention": att, "splitk_reduce": red},

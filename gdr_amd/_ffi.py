@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDR_HIP_LIB") or os.path.join(_HERE, "libgdr_hip.so")   # override: A/B builds in the lab
 
 GDR_OK, GDR_EINVAL, GDR_ENOSPC, GDR_EHIP = 0, -1, -2, -3
-ABI_VERSION = 4                  # what this binding was written against (gdr_abi_version(), csrc/common.hip)
+ABI_VERSION = 5                  # what this binding was written against (gdr_abi_version(), csrc/common.hip)
 RERANK_POSITIONS = 1
 SIM_EXHAUSTIVE = 1
 SIM_NO_STREAM = 2
@@ -110,6 +110,9 @@ SIGNATURES = {
                              _vp, _sz, _vp]),
     "gdr_rerank_topk_bf16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, C.c_int32, C.c_int32,
                                   _i, _vp, _sz, _vp]),
+    "gdr_rerank_wire_pack": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "gdr_rerank_wire_unpack": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gdr_rerank_positions_to_ids": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "gdr_cluster_key_hash": (C.c_uint64, [C.POINTER(C.c_int32), _i]),
     "gdr_cluster_candidates": (_i, [C.POINTER(GdrClusterIndex), _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "gdr_t5_relative_bucket_table": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),

@@ -333,7 +333,71 @@ __global__ __launch_bounds__(256) void cluster_candidates_kernel(GdrClusterIndex
   }
 }
 
+// ---- the sharded GDR mode's exchange row (gdr_hip.h gdr_rerank_wire_pack): {q | beam scores | offsets | ids} as int32 ----
+template <bool PACK>
+__global__ __launch_bounds__(256) void rerank_wire_kernel(int32_t* __restrict__ wire, int32_t* __restrict__ q,
+                                                          int32_t* __restrict__ beam, int32_t* __restrict__ offs,
+                                                          int32_t* __restrict__ ids, int d, int R, int stride) {
+  const int b = blockIdx.x, W = d + 2 * R + 1 + stride;
+  int32_t* row = wire + (int64_t)b * W;
+  for (int i = threadIdx.x; i < W; i += 256) {
+    int32_t* p;
+    if (i < d) p = q + (int64_t)b * d + i;
+    else if (i < d + R) p = beam + (int64_t)b * R + (i - d);
+    else if (i < d + 2 * R + 1) p = offs + (int64_t)b * (R + 1) + (i - d - R);
+    else p = ids + (int64_t)b * stride + (i - d - 2 * R - 1);
+    if (PACK) row[i] = *p;
+    else *p = row[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void rerank_pos_to_id_kernel(const int32_t* __restrict__ pos, const int32_t* __restrict__ ids,
+                                                               int64_t n, int per_query, int stride, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t p = pos[i];
+  out[i] = (p >= 0 && p < stride) ? ids[(i / per_query) * stride + p] : -1;
+}
+
 }  // namespace gdr
+
+extern "C" int gdr_rerank_wire_pack(const float* q, const float* beam_scores, const int32_t* cand_offsets,
+                                    const int32_t* cand_ids, int B, int d, int R, int cand_stride, int32_t* wire,
+                                    void* stream_) {
+  using namespace gdr;
+  GDR_CHECK_ARG(q && beam_scores && cand_offsets && cand_ids && wire, "rerank_wire_pack: null pointer");
+  GDR_CHECK_ARG(B > 0 && d > 0 && R > 0 && cand_stride > 0, "rerank_wire_pack: bad shape B=%d d=%d R=%d stride=%d", B, d, R, cand_stride);
+  hipLaunchKernelGGL(rerank_wire_kernel<true>, dim3((unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream_), wire,
+                     reinterpret_cast<int32_t*>(const_cast<float*>(q)), reinterpret_cast<int32_t*>(const_cast<float*>(beam_scores)),
+                     const_cast<int32_t*>(cand_offsets), const_cast<int32_t*>(cand_ids), d, R, cand_stride);
+  GDR_CHECK_LAUNCH("rerank_wire_kernel<pack>");
+  return GDR_OK;
+}
+
+extern "C" int gdr_rerank_wire_unpack(const int32_t* wire, int B, int d, int R, int cand_stride, float* q, float* beam_scores,
+                                      int32_t* cand_offsets, int32_t* cand_ids, void* stream_) {
+  using namespace gdr;
+  GDR_CHECK_ARG(q && beam_scores && cand_offsets && cand_ids && wire, "rerank_wire_unpack: null pointer");
+  GDR_CHECK_ARG(B > 0 && d > 0 && R > 0 && cand_stride > 0, "rerank_wire_unpack: bad shape B=%d d=%d R=%d stride=%d", B, d, R, cand_stride);
+  hipLaunchKernelGGL(rerank_wire_kernel<false>, dim3((unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     const_cast<int32_t*>(wire), reinterpret_cast<int32_t*>(q), reinterpret_cast<int32_t*>(beam_scores), cand_offsets,
+                     cand_ids, d, R, cand_stride);
+  GDR_CHECK_LAUNCH("rerank_wire_kernel<unpack>");
+  return GDR_OK;
+}
+
+extern "C" int gdr_rerank_positions_to_ids(const int32_t* pos, const int32_t* cand_ids, int B, int per_query, int cand_stride,
+                                           int32_t* out_ids, void* stream_) {
+  using namespace gdr;
+  GDR_CHECK_ARG(pos && cand_ids && out_ids, "rerank_positions_to_ids: null pointer");
+  GDR_CHECK_ARG(B > 0 && per_query > 0 && cand_stride > 0, "rerank_positions_to_ids: bad shape B=%d per_query=%d stride=%d", B,
+                per_query, cand_stride);
+  const int64_t n = (int64_t)B * per_query;
+  hipLaunchKernelGGL(rerank_pos_to_id_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), pos,
+                     cand_ids, n, per_query, cand_stride, out_ids);
+  GDR_CHECK_LAUNCH("rerank_pos_to_id_kernel");
+  return GDR_OK;
+}
 
 extern "C" size_t gdr_rerank_workspace_bytes(int B, int max_cand) {
   if (B <= 0 || max_cand <= 0) return 0;

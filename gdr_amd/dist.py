@@ -58,12 +58,19 @@ class _Pending:
 
 
 class ShardedIndex:
-    def __init__(self, D_shard, lo, group=None, local_topk=None, pack=None, merge_packed=None, exact=True, local_rerank=None):
+    def __init__(self, D_shard, lo, group=None, local_topk=None, pack=None, merge_packed=None, exact=True, local_rerank=None,
+                 wire=None):
         """local_topk(Q, D, k, idx_offset) -> (values [B,k], ids int32 [B,k], status int32 [B]);
         pack(values, ids, status) -> int64 [B,k+1];  merge_packed(pairs [G,B,k+1]) -> (values, ids, status);
         local_rerank(q, D, cand_offsets [B,R+1], cand_ids [B,stride], beam_scores, alphas, k, lo, hi, func, positions)
-        -> (values [B,A,k], int32 [B,A,k]) — ops.rerank_topk in the per-query block layout."""
+        -> (values [B,A,k], int32 [B,A,k]) — ops.rerank_topk in the per-query block layout;
+        wire = (wire_pack(q, beam, offs, ids) -> int32 [B,W], wire_unpack(rows, d, R, stride) -> (q, beam, offs, ids),
+        positions_to_ids(pos [B,...], ids [B,stride]) -> int32 ids) — ops.rerank_wire_pack / _unpack / rerank_positions_to_ids."""
         self.D, self.lo, self.group = D_shard, int(lo), group
+        if wire is None:
+            from . import ops as _wops
+            wire = (_wops.rerank_wire_pack, _wops.rerank_wire_unpack, _wops.rerank_positions_to_ids)
+        self.wire_pack, self.wire_unpack, self.positions_to_ids = wire
         if local_topk is None or pack is None or merge_packed is None:
             from . import ops
             ws = ops.Workspace(D_shard.device)
@@ -74,8 +81,8 @@ class ShardedIndex:
         if local_rerank is None:
             from . import ops as _ops
             local_rerank = (lambda q, D, offs, ids, beam, alphas, k, lo, hi, func, positions: _ops.rerank_topk(
-                q, D, offs, ids, beam, alphas, k, func=func, max_cand=ids.shape[1], doc_range=(lo, hi), positions=positions,
-                cand_stride=ids.shape[1]))
+                q, D, offs, ids, beam, alphas, k, func=func, max_cand=_ops.block_max_cand(offs, beam.shape[1], ids.shape[1]),
+                doc_range=(lo, hi), positions=positions, cand_stride=ids.shape[1]))
         self.local_topk, self.pack, self.merge_packed, self.local_rerank = local_topk, pack, merge_packed, local_rerank
         self.distributed = dist.is_initialized()      # a 1-rank group still runs the collectives (exercises RCCL)
         self.world = dist.get_world_size(group) if self.distributed else 1
@@ -161,22 +168,15 @@ class ShardedIndex:
         A = len(alphas)
         if not self.distributed:
             return self.local_rerank(q_local, self.D, cand_offsets, cand_ids, beam_scores, alphas, k, self.lo, hi, func, False)
-        i32 = torch.int32
-        mine = torch.cat([q_local.contiguous().view(i32).view(Bl, d), beam_scores.contiguous().view(i32).view(Bl, R),
-                          cand_offsets.to(i32).view(Bl, R + 1), cand_ids.to(i32).view(Bl, stride)], dim=1).contiguous()
-        W = mine.shape[1]
-        allb = torch.empty((self.world * Bl, W), dtype=i32, device=mine.device)
+        mine = self.wire_pack(q_local, beam_scores, cand_offsets.view(Bl, R + 1), cand_ids.view(Bl, stride))   # [Bl, W] int32
+        allb = torch.empty((self.world * Bl, mine.shape[1]), dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(allb, mine, group=self.group)
         B = self.world * Bl
-        q_all = allb[:, :d].contiguous().view(torch.float32)
-        beam_all = allb[:, d:d + R].contiguous().view(torch.float32)
-        offs_all = allb[:, d + R:d + 2 * R + 1].contiguous()
-        ids_all = allb[:, d + 2 * R + 1:].contiguous()
+        q_all, beam_all, offs_all, ids_all = self.wire_unpack(allb, d, R, stride)
         v, pos = self.local_rerank(q_all, self.D, offs_all, ids_all, beam_all, alphas, k, self.lo, hi, func, True)
         send = self.pack(v.reshape(B * A, k), pos.reshape(B * A, k), None)          # [B*A, k+1]; block g = rank g's queries
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)
         mv, mp, _st = self.merge_packed(recv.view(self.world, Bl * A, k + 1))
-        mp = mp.view(Bl, A * k).long()
-        ids = torch.where(mp >= 0, cand_ids.view(Bl, stride).long().gather(1, mp.clamp(min=0)), mp)
-        return mv.view(Bl, A, k), ids.view(Bl, A, k).to(i32)
+        ids = self.positions_to_ids(mp.view(Bl, A * k), cand_ids.view(Bl, stride))  # position in MY query's block -> doc id
+        return mv.view(Bl, A, k), ids.view(Bl, A, k)

@@ -2,6 +2,12 @@
 
     python -m gdr_amd.main --mode eval --decode_embedding 2 --num_return_sequences 10 --kary 30 ...   (infer.sh flags)
 
+`--n_gpu N` (N > 1) with `--mode eval` fans out over N GPUs of the node: the command starts N fresh rank processes of itself
+(gdr_amd/launch.py; the reference's analogues are Lightning's DDP spawn behind `--n_gpu`, main.py:57-70, and the per-GPU
+launch of Data_process/NQ_dataset/bert/bert_NQ.sh:5-12), every rank decodes its own share of the query batches, the corpus is
+row-sharded over the ranks and stage 2 runs as dist.ShardedIndex.rerank_own (BASELINE config C5's layout) — the TSVs and
+metrics equal the one-GPU run's.
+
 `--mode eval` runs the inference hot path on the MI355X: T5 encoder -> docid beam decode -> (with doc embeddings)
 in-cluster dense rerank, writes the res1 TSV `query\\tpred\\tgt\\trank` (main.py:244-247) and prints recall@k / MRR100
 (main_metrics.py:194-267).  `--mode calculate` recomputes the metrics of an existing TSV.  `--mode train` is out of
@@ -26,7 +32,7 @@ if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     __package__ = "gdr_amd"
 
-from . import codec, synth                      # noqa: E402
+from . import codec, launch, synth              # noqa: E402
 from .config import GDRConfig                   # noqa: E402
 
 # (flag, type, default[, choices]) — names, types and defaults of main.py:262-396
@@ -151,6 +157,14 @@ def inference(args):
         print("[gdr_amd] --infer_ckpt is empty: using seeded synthetic weights (no trained checkpoint ships with the "
               "reference)")
         sd = synth.make_state_dict(cfg, seed=1234)
+    world, rank, sharded_index = 1, 0, None
+    if launch.under_launcher():                              # a rank of `--n_gpu N` (or of torch.distributed.run typed by hand)
+        import torch.distributed as dist
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        args.device = f"cuda:{local_rank}"
+        dist.init_process_group("nccl", device_id=torch.device(args.device))
+        world, rank = dist.get_world_size(), dist.get_rank()
     dev = torch.device(args.device)
     data = _load_inputs(args, cfg)
     if args.constrain_tree and args.kary != args.output_vocab_size:
@@ -162,27 +176,56 @@ def inference(args):
                      prefix_trie=trie if args.prefix_table else None, ragged=True)
     R = args.num_return_sequences
     two_stage = bool(args.is_train_encoder) and data["doc_embed"] is not None
-    retr = GDRRetriever(model, torch.from_numpy(np.ascontiguousarray(data["doc_embed"], dtype=np.float32)).to(dev),
-                        data["index"], args) if two_stage else None
+    retr = None
+    if two_stage and world > 1:
+        # config C5's layout: rank r keeps rows [lo, hi) of the corpus (whole clusters when they are contiguous row blocks,
+        # as the synthetic corpus' are; any row split is correct — a candidate is scored by the rank that holds its row)
+        from .dist import ShardedIndex, shard_bounds
+        N_rows = data["doc_embed"].shape[0]
+        lo_r, hi_r = shard_bounds(N_rows, world, rank, cluster_size=12 if not args.data_npz else 1)
+        shard = torch.from_numpy(np.ascontiguousarray(data["doc_embed"][lo_r:hi_r], dtype=np.float32)).to(dev)
+        sharded_index = ShardedIndex(shard, lo_r)
+        retr = GDRRetriever(model, None, data["index"], args, sharded=sharded_index)
+    elif two_stage:
+        retr = GDRRetriever(model, torch.from_numpy(np.ascontiguousarray(data["doc_embed"], dtype=np.float32)).to(dev),
+                            data["index"], args)
     n = data["source_ids"].shape[0] if args.n_test < 0 else min(args.n_test, data["source_ids"].shape[0])
     texts = data.get("texts") or ["q%d" % i for i in range(data["source_ids"].shape[0])]
     inf_result_cache, outputs = [], []
-    spans = [(lo, min(n, lo + args.eval_batch_size)) for lo in range(0, n, args.eval_batch_size)]
+    all_spans = [(lo, min(n, lo + args.eval_batch_size)) for lo in range(0, n, args.eval_batch_size)]
+    # N ranks: span i goes to rank i % N.  The sharded stage 2 is a fixed-size collective, so every rank runs the same number
+    # of steps with the same batch size: the last span is padded with its last query, and ranks that ran out of spans repeat
+    # the last one — padding rows and repeated steps are dropped below
+    n_steps = (len(all_spans) + world - 1) // world
+    spans = [all_spans[min(i * world + rank, len(all_spans) - 1)] for i in range(n_steps)]
+    real = [i * world + rank < len(all_spans) for i in range(n_steps)]
+    full = args.eval_batch_size if world > 1 else 0
+
+    def take(arr, lo, hi):
+        sel = list(range(lo, hi)) + [hi - 1] * max(0, full - (hi - lo))
+        return [arr[j] for j in sel] if isinstance(arr, list) else arr[sel]
 
     def batches():
         for lo, hi in spans:
-            yield {"source_ids": torch.from_numpy(data["source_ids"][lo:hi]).to(dev),
-                   "source_mask": torch.from_numpy(data["source_mask"][lo:hi]).to(dev), "texts": texts[lo:hi],
-                   "gt": data["gt_cluster"][lo:hi], "oldid": data["gt_doc"][lo:hi]}
+            yield {"source_ids": torch.from_numpy(take(data["source_ids"], lo, hi)).to(dev),
+                   "source_mask": torch.from_numpy(take(data["source_mask"], lo, hi)).to(dev), "texts": take(texts, lo, hi),
+                   "gt": take(data["gt_cluster"], lo, hi), "oldid": take(data["gt_doc"], lo, hi)}
+
+    def trimmed(out, lo, hi):                                    # drop the padding rows of a short last batch
+        m = hi - lo
+        return {"inf_result_batch": out["inf_result_batch"][:m], "inf_result_batch_prob": out["inf_result_batch_prob"][:m * R],
+                "inf_index_batch": out["inf_index_batch"][:m]}
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if two_stage:
-        for out in retr.validation_steps(batches(), depth=max(1, args.pipeline_depth)):
-            outputs.append(out)
-            inf_result_cache.extend(out["inf_result_batch"])
+        for i, out in enumerate(retr.validation_steps(batches(), depth=max(1, args.pipeline_depth))):
+            if real[i]:
+                outputs.append(trimmed(out, *spans[i]))
     else:
-        for (lo, hi), b in zip(spans, batches()):
+        for (lo, hi), b, is_real in zip(spans, batches(), real):
+            if not is_real:
+                continue
             outs, _ = model.generate(b["source_ids"], attention_mask=b["source_mask"], use_cache=False,
                                      max_length=args.max_output_length, num_beams=R, length_penalty=args.length_penalty,
                                      num_return_sequences=R, early_stopping=False, decode_embedding=args.decode_embedding,
@@ -192,11 +235,32 @@ def inference(args):
                 inf_result_cache.append([texts[lo + j], ",".join(pred), data["gt_cluster"][lo + j], 1])
     torch.cuda.synchronize()
     t_model = time.perf_counter() - t0
+    if world > 1 or launch.under_launcher():
+        # rank 0 writes the TSVs: collect every rank's step outputs (plain Python rows) in span order
+        import torch.distributed as dist
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object((outputs, inf_result_cache), gathered, dst=0)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return None, None
+        per_rank_out = [g[0] for g in gathered]
+        if two_stage:
+            outputs = [per_rank_out[i % world][i // world] for i in range(len(all_spans))]
+        else:
+            per = [g[1] for g in gathered]                       # rows of span i: rank i % world, its (i // world)-th block
+            inf_result_cache, cursor = [], [0] * world
+            for i, (lo, hi) in enumerate(all_spans):
+                r_ = i % world
+                inf_result_cache.extend(per[r_][cursor[r_]:cursor[r_] + (hi - lo)])
+                cursor[r_] += hi - lo
+    if two_stage:
+        inf_result_cache = [row for out in outputs for row in out["inf_result_batch"]]
     # main.py:243-247: sort by (query, rank), keep rank 1, write the TSV
     res1 = sorted((r for r in inf_result_cache if r[3] == 1), key=lambda r: (r[0], r[3]))
     os.makedirs(os.path.dirname(args.res1_save_path) or ".", exist_ok=True)
     codec.write_res1(args.res1_save_path, res1)
-    print(f"[gdr_amd] {n} queries, beam {R}: {n / max(t_model, 1e-9):.1f} queries/s (model time only)")
+    print(f"[gdr_amd] {n} queries, beam {R}, {world} GPU(s): {n / max(t_model, 1e-9):.1f} queries/s (model time only)")
     recall_value = codec.recall(args)
     mrr_value = codec.MRR100(args)
     if two_stage:
@@ -245,7 +309,24 @@ def main(argv=None):
         raise SystemExit("gdr_amd implements GDR's inference hot path only; --mode train is out of scope (SURVEY §2.2)")
     if args.mode == "eval":
         args.recall_num = [1, 5, 10, 20, 50, 100]
-        return inference(args)
+        if args.n_gpu > 1 and not launch.under_launcher():
+            # one command, N GPUs: this process (which has not touched a GPU) starts the N ranks as children and relays
+            # their output; rank 0 writes the TSVs and prints the metrics
+            import json
+            tail = list(sys.argv[1:] if argv is None else argv)
+            if "--res1_save_path" not in tail:
+                tail += ["--res1_save_path", args.res1_save_path]
+            rc, text = launch.spawn_ranks(args.n_gpu, tail, module="gdr_amd.main")
+            if rc:
+                raise SystemExit(rc)
+            res = [ln for ln in text.splitlines() if ln.startswith("GDR_RESULT ")]
+            r = json.loads(res[-1][len("GDR_RESULT "):]) if res else {}
+            return r.get("recall"), r.get("mrr100")
+        rec, mrr = inference(args)
+        if launch.under_launcher() and rec is not None:
+            import json
+            print("GDR_RESULT " + json.dumps({"recall": rec, "mrr100": mrr}))
+        return rec, mrr
     return calculate(args)
 
 

@@ -270,13 +270,23 @@ class GDRRetriever:
     per cluster -> top-k, for every alpha in score_rate."""
 
     def __init__(self, model: GDRModel, doc_embed, cluster_index: codec.ClusterIndex, args, doc_tower=None,
-                 doc_tokens=None, device_candidates=True):
+                 doc_tokens=None, device_candidates=True, sharded=None):
         """doc_embed: fp32 (or, in the C5 precision mode, bf16) [N, d] resident on the GPU (the reference's `self.doc_embed`).
         doc_tower + doc_tokens=(input_ids int64[N,Lp], attention_mask) enable the stage-2 re-encode path of
         main_models.py:1445-1455 (`epoch > train_encoder_epoch`): candidate docs are embedded on the fly by the
-        BERT/DPR tower instead of being looked up (tokenisation itself is out of scope: tokens come pre-computed)."""
+        BERT/DPR tower instead of being looked up (tokenisation itself is out of scope: tokens come pre-computed).
+        sharded: a dist.ShardedIndex — BASELINE config C5's layout of this path (SURVEY §8e "for GDR mode, whole clusters"):
+        the corpus is row-sharded over the ranks of one node (`doc_embed` may then be None: the rank's rows are
+        `sharded.D`), every rank encodes and beam-decodes ITS OWN queries (generate() is data-parallel, as the reference's
+        per-GPU launch is: Data_process/NQ_dataset/bert/bert_NQ.sh:5-12), and stage 2 is `sharded.rerank_own` — one
+        all-gather of the queries + candidate blocks, per-shard scoring, one all-to-all, merge: the lists are bit-identical
+        to the unsharded rerank.  Every rank must call validation_step_i the same number of times with the same batch size
+        (the collectives are fixed-size); `cluster_index` is the index of the WHOLE corpus on every rank."""
         self.model, self.args, self.index = model, args, cluster_index
-        self.doc_embed = doc_embed
+        self.doc_embed = doc_embed if doc_embed is not None or sharded is None else sharded.D
+        self.sharded = sharded
+        if sharded is not None and not device_candidates:
+            raise _ffi.GdrError("GDRRetriever(sharded=...) exchanges the device candidate blocks: device_candidates must stay on")
         self.encoder = doc_tower if doc_tower is not None else EncoderModel()
         self.doc_tokens = doc_tokens
         # device_candidates: decoded rows -> clusters -> candidate CSR on the GPU (gdr_cluster_candidates); False keeps the
@@ -340,7 +350,8 @@ class GDRRetriever:
         enc_h, ids, lens, scores = self.model._generate_launch(batch["source_ids"], mask, R, a.max_output_length,
                                                                a.length_penalty, R)
         for t in (enc_h, ids, lens, scores):                 # produced on this stream, possibly consumed after a switch
-            t.record_stream(torch.cuda.current_stream(t.device))
+            if t.is_cuda:
+                t.record_stream(torch.cuda.current_stream(t.device))
         return {"batch": batch, "enc_h": enc_h, "ids": ids, "lens": lens, "scores": scores}
 
     def _device_index(self):
@@ -367,7 +378,7 @@ class GDRRetriever:
             # decode_token -> id_mapping -> candidate lists -> rerank, all enqueued before anything is read back
             # (main_models.py:1398,1441-1443,1574-1637): the host only formats strings afterwards
             _cl, offs, dev_ids, stride = dci.candidates(state["ids"], B, R)
-            max_cand = stride
+            max_cand = ops.block_max_cand(offs, R, stride)
             beam_scores = state["scores"].to(torch.float32).view(B, R)          # fp64 -> fp32 as torch.tensor(list) rounds
         outs = scores = None
         if dci is None:
@@ -377,7 +388,12 @@ class GDRRetriever:
             offs = offs.to(query_embeds.device)
             beam_scores = torch.tensor(scores, dtype=torch.float32, device=query_embeds.device).view(B, R)
             dev_ids = ids.to(query_embeds.device)
-        if reencode:
+        if self.sharded is not None:
+            if dci is None or reencode:
+                raise _ffi.GdrError("the sharded two-stage path needs the device cluster index (--kary > 0) and has no "
+                                    "re-encode form (the doc tower's tokens are not sharded)")
+            vals, idx = self.sharded.rerank_own(query_embeds, offs, dev_ids, beam_scores, alphas, R, func=func)
+        elif reencode:
             if self.doc_tokens is None or getattr(self.encoder, "bert", None) is None:
                 raise _ffi.GdrError("re-encode needs doc_tower= and doc_tokens=")
             if stride:                                   # block layout: the live ids of every query, query-major

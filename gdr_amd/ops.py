@@ -219,6 +219,65 @@ def rerank_topk(q, D, cand_offsets, cand_ids, beam_scores, alphas, k, func="tanh
     return ov, oi
 
 
+def rerank_wire_pack(q, beam_scores, cand_offsets, cand_ids):
+    """(q fp32[B,d], beam fp32[B,R], offsets int32[B,R+1], ids int32[B,stride]) -> int32[B, d+2R+1+stride], the exchange row
+    of the sharded in-cluster rerank — gdr_rerank_wire_pack."""
+    _need_cuda(q, beam_scores, cand_offsets, cand_ids)
+    q, beam_scores = _f32c(q), _f32c(beam_scores)
+    cand_offsets, cand_ids = cand_offsets.to(torch.int32).contiguous(), cand_ids.to(torch.int32).contiguous()
+    (B, d), R, stride = q.shape, beam_scores.shape[1], cand_ids.shape[1]
+    wire = torch.empty((B, d + 2 * R + 1 + stride), dtype=torch.int32, device=q.device)
+    check(lib().gdr_rerank_wire_pack(ptr(q), ptr(beam_scores), ptr(cand_offsets), ptr(cand_ids), B, d, R, stride, ptr(wire),
+                                     stream_ptr()), "gdr_rerank_wire_pack")
+    return wire
+
+
+def rerank_wire_unpack(wire, d, R, stride):
+    """int32[B, d+2R+1+stride] -> (q fp32[B,d], beam fp32[B,R], offsets int32[B,R+1], ids int32[B,stride]) — gdr_rerank_wire_unpack."""
+    _need_cuda(wire)
+    wire = wire.contiguous()
+    B = wire.shape[0]
+    if wire.dtype != torch.int32 or wire.shape[1] != d + 2 * R + 1 + stride:
+        raise _ffi.GdrError(f"rerank_wire_unpack: wire {tuple(wire.shape)} {wire.dtype} does not match d={d} R={R} stride={stride}")
+    q = torch.empty((B, d), dtype=torch.float32, device=wire.device)
+    beam = torch.empty((B, R), dtype=torch.float32, device=wire.device)
+    offs = torch.empty((B, R + 1), dtype=torch.int32, device=wire.device)
+    ids = torch.empty((B, stride), dtype=torch.int32, device=wire.device)
+    check(lib().gdr_rerank_wire_unpack(ptr(wire), B, d, R, stride, ptr(q), ptr(beam), ptr(offs), ptr(ids), stream_ptr()),
+          "gdr_rerank_wire_unpack")
+    return q, beam, offs, ids
+
+
+def rerank_positions_to_ids(pos, cand_ids):
+    """pos int32[B, ...] candidate positions (merged GDR_RERANK_POSITIONS lists; < 0 = padding) -> doc ids int32 of the same
+    shape through cand_ids int32[B, stride] — gdr_rerank_positions_to_ids."""
+    _need_cuda(pos, cand_ids)
+    pos, cand_ids = pos.to(torch.int32).contiguous(), cand_ids.to(torch.int32).contiguous()
+    B, stride = cand_ids.shape
+    out = torch.empty_like(pos)
+    check(lib().gdr_rerank_positions_to_ids(ptr(pos), ptr(cand_ids), B, pos.numel() // B, stride, ptr(out), stream_ptr()),
+          "gdr_rerank_positions_to_ids")
+    return out
+
+
+RERANK_MAX_CAND = 8192          # csrc/rerank.hip RR_MAX_CAND: the LDS sort of one (alpha, query) list
+
+
+def block_max_cand(cand_offsets, R, stride):
+    """The `max_cand` to hand gdr_rerank_topk for candidate blocks of width `stride` = num beams x LARGEST cluster of the
+    corpus.  While that worst case fits the kernel's cap it is used as is — nothing synchronises.  One outlier cluster
+    (more than 81 docs at 100 beams) must not make every step fail when the clusters actually decoded are small: beyond
+    the cap the bound comes from the data (one read-back of the per-query counts, this case only), and only a query that
+    REALLY has more than 8192 candidates is refused (as the host CSR path refuses it)."""
+    if stride <= RERANK_MAX_CAND:
+        return max(int(stride), 1)
+    real = int(cand_offsets.view(-1, R + 1)[:, R].max().item())
+    if real > RERANK_MAX_CAND:
+        raise _ffi.GdrError(f"rerank: a query decoded {real} candidate docs; the in-cluster rerank ranks at most "
+                            f"{RERANK_MAX_CAND} per query")
+    return max(real, 1)
+
+
 class DeviceClusterIndex:
     """codec.ClusterIndex resident on the GPU (include/gdr_hip.h GdrClusterIndex): the clusters' token bodies in an
     exact-match hash table + the member CSR, so that gdr_cluster_candidates turns generate()'s output rows into the rerank's

@@ -272,6 +272,21 @@ uint64_t gdr_cluster_key_hash(const int32_t* tokens_host, int len);   /* host ro
 int gdr_cluster_candidates(const GdrClusterIndex* ci, const int64_t* out_ids, int B, int R, int max_length,
                            int32_t* cluster_of, int32_t* cand_offsets, int32_t* cand_ids, int cand_stride, void* stream);
 
+/* The exchange row of the SHARDED in-cluster rerank (gdr_amd/dist.py ShardedIndex.rerank_own; the arithmetic being sharded
+ * is main_models.py:1434-1462,1574-1637, the per-GPU layout follows Data_process/NQ_dataset/bert/bert_NQ.sh:5-12): per query
+ * ONE int32 row  wire[b] = { q fp32[d] | beam_scores fp32[R] | cand_offsets int32[R+1] | cand_ids int32[cand_stride] },
+ * so that every rank's queries + candidate blocks travel in ONE fixed-size all-gather.  gdr_rerank_wire_pack builds
+ * wire[B][d + 2R + 1 + cand_stride]; gdr_rerank_wire_unpack splits the gathered rows back into the four contiguous arrays
+ * gdr_rerank_topk reads; gdr_rerank_positions_to_ids maps the merged candidate POSITIONS (GDR_RERANK_POSITIONS lists after
+ * gdr_topk_merge_packed) of query b = i / per_query back to doc ids through the query's own candidate block
+ * (position < 0, the "fewer than k candidates" padding, stays -1). */
+int gdr_rerank_wire_pack(const float* q, const float* beam_scores, const int32_t* cand_offsets, const int32_t* cand_ids,
+                         int B, int d, int R, int cand_stride, int32_t* wire, void* stream);
+int gdr_rerank_wire_unpack(const int32_t* wire, int B, int d, int R, int cand_stride, float* q, float* beam_scores,
+                           int32_t* cand_offsets, int32_t* cand_ids, void* stream);
+int gdr_rerank_positions_to_ids(const int32_t* pos, const int32_t* cand_ids, int B, int per_query, int cand_stride,
+                                int32_t* out_ids, void* stream);
+
 /* T5 relative-position buckets (transformers/modeling_t5.py:242-288) for relative_position =
  * key_pos - query_pos, written to a HOST int32[qlen*klen] table; the attention kernels use the same
  * host routine, so tests pin it bit-exact against the reference. */

@@ -37,7 +37,9 @@ def test_bench_line_contract_fp32():
     rec = j["recall"]
     assert rec["gpu"] == rec["cpu_oracle"], "Recall@{1,10,100} parity with the CPU oracle"
     assert rec["rows_violating_tie_rule"] == 0 and rec["topk_ids_identical_rows"] + 8 >= rec["rows"]
-    assert j["config"]["encoder_rows"] == "ragged" and "ragged encoder" in j["config"]["workload"]
+    assert j["config"]["encoder_rows"] == "ragged" and j["config"]["workload"].startswith("C2/ragged")
+    assert len(j["config"]["workload"]) <= 100 and "ragged encoder" in j["config"]["note"]
+    assert "static" in r["traffic_source"] or r["traffic"] is None
     assert c["cpu_model"]
     st = j["stages"]                                   # the other stages of the path, measured after the timed region
     lat = st["similarity_topk_f32"]["B32"]
@@ -47,6 +49,11 @@ def test_bench_line_contract_fp32():
         assert g["generate_ms"] > g["encoder_ms"] > 0 and 0 < g["frac_of_floor_executed"] <= g["frac_of_floor"] < 1
         assert g["decode_gflop_executed"] < g["decode_gflop_without_table"]
     assert st["c3_two_stage"]["queries_per_s"] > 0 and st["bf16_mode_c2_step"]["queries_per_s"] > 0
+    for key in ("c3_two_stage", "c3_two_stage_infer_sh"):          # the CPU path beside the GDR stages (SURVEY §8d "per config")
+        cb = st[key]["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and 0 < cb["value"] < st[key]["queries_per_s"] and cb["sample"]
+        assert 0 < cb["generate_s"] <= cb["total_s"]
+    assert st["c3_best_sustained"]["queries_per_s"] >= st["c3_two_stage"]["pipelined_queries_per_s"]
     assert st["prefix_table"]["nodes"] > 1
     rr = st["rerank"]
     assert any(k.startswith("B64_cand") for k in rr) and any(k.startswith("B1_cand") for k in rr)
@@ -67,6 +74,25 @@ def test_bench_padded_encoder_form_gives_the_same_recall():
 def test_bench_line_contract_bf16_mode():
     j = _run("--dtype", "bf16", "--no-cpu-baseline", "--no-stages")
     assert j["dtype"] == "bf16" and j["cpu_baseline"] is None and j["roofline"]["peak"] == 2500.0
+
+
+def test_bench_two_stage_workloads_and_the_self_launch():
+    """--workload c3 / c5 (BASELINE configs C3 / C5: the two-stage GDR path) print the same JSON contract; `--launcher` makes
+    bench.py start its rank(s) itself through torch.distributed.run (what `--gpus N` does for N > 1): the step then runs the
+    SHARDED stage 2 (ShardedIndex.rerank_own) over a 1-rank RCCL group."""
+    j = _run("--workload", "c3", "--gpus", "1", "--launcher", "--batch", "8", "--no-cpu-baseline")
+    assert j["config"]["workload"].startswith("C3/sharded") and len(j["config"]["workload"]) <= 100
+    assert j["n_gpus"] == 1 and j["dtype"] == "f32" and j["config"]["beams"] == 10 and j["config"]["candidates_per_query"] == 120
+    assert j["value"] > 0 and abs(j["value"] - 8 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    r = j["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["launches_per_step"] > 100 and r["events_lost"] == 0
+    k = _run("--workload", "c5", "--batch", "8")
+    assert k["config"]["workload"].startswith("C5:") and k["dtype"] == "bf16" and k["config"]["beams"] == 30
+    assert k["roofline"]["peak"] == 2500.0 and k["value"] > 0
+    c = k["cpu_baseline"]
+    assert c["kind"] == "port" and 0 < c["value"] < k["value"] and 0 < c["generate_s"] <= c["total_s"]
+    u = _run("--workload", "c3", "--batch", "8", "--no-cpu-baseline", "--constrained")
+    assert u["config"]["workload"].startswith("C3/constrained:") and u["value"] > 0
 
 
 def test_bench_under_torchrun_one_rank_rccl():

@@ -113,6 +113,31 @@ def test_main_eval_entry_point_vs_oracle_composition(tmp_path, base_weights, R, 
     assert "stage 2 (in-cluster rerank)" in out
 
 
+def test_main_eval_sharded_two_stage_under_one_rank_rccl_equals_unsharded(tmp_path):
+    """The sharded two-stage path as ONE path, started by the product's own launcher (gdr_amd/launch.py — what
+    `main.py --n_gpu N` and `bench.py --gpus N` call): a 1-rank RCCL group under torch.distributed.run runs
+    GDRRetriever(sharded=ShardedIndex) — generate -> gdr_cluster_candidates -> rerank_own (wire pack, all-gather, per-shard
+    GDR_RERANK_POSITIONS lists, all-to-all, gdr_topk_merge_packed, positions -> ids) — through the entry point, with a short
+    last batch (padding rows dropped), and writes the same res1 and doc-level TSVs, byte for byte, as the plain one-process
+    run (main_models.py:1434-1462,1574-1637; Data_process/NQ_dataset/bert/bert_NQ.sh:5-12 for the per-GPU launch)."""
+    from gdr_amd import launch
+    a, b = str(tmp_path / "a.tsv"), str(tmp_path / "b.tsv")
+    argv = INFER_SH + ["--infer_ckpt", "", "--num_return_sequences", "10", "--eval_batch_size", "4", "--corpus_rows", "30000",
+                       "--n_queries", "10", "--constrain_tree", "1"]
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cwd = os.getcwd()
+    os.chdir(REPO)
+    try:
+        rc, text = launch.spawn_ranks(1, argv + ["--res1_save_path", a], module="gdr_amd.main", env=env, relay=False, timeout=1500)
+    finally:
+        os.chdir(cwd)
+    assert rc == 0, text[-4000:]
+    assert "GDR_RESULT " in text and "1 GPU(s)" in text
+    _run_main(argv + ["--res1_save_path", b])
+    assert open(a).read() == open(b).read() and len(_read_tsv(a)) == 10
+    assert open(a + ".docs.tsv").read() == open(b + ".docs.tsv").read() and len(_read_tsv(a + ".docs.tsv")) == 70
+
+
 def test_main_eval_missing_checkpoint_is_an_error(tmp_path):
     """A non-empty --infer_ckpt that does not exist must fail (the reference's torch.load raises, main.py:121), not fall
     back to random weights."""
@@ -348,6 +373,34 @@ def test_c5_composed_bf16_two_stage_on_1m_corpus(dev, base_weights):
             np.testing.assert_allclose(out["rerank_values"][b, a].cpu().numpy(), ref[a][0].numpy(), rtol=1e-4, atol=1e-4)
     assert differing <= 8, differing
     assert D16.dtype == torch.bfloat16 and D16.shape == (N, cfg.d_model)
+    # ---- C5's OWN layout (BASELINE.json: "8xMI355X"; SURVEY §8e "for GDR mode, whole clusters"): the 1M-row bf16 corpus in
+    # 8 cluster-aligned row shards, looped on this GPU: per shard the GDR_RERANK_POSITIONS lists of ALL 64 queries over the
+    # rows [lo, hi) only -> wire form -> gdr_topk_merge_packed -> positions back to doc ids == the unsharded lists, bit for bit
+    from gdr_amd.dist import shard_bounds
+    A = len(args.score_rate)
+    dci = retr._device_index()
+    _cl, offs, cids, stride = dci.candidates(state["ids"], B, R)
+    q_dev = state["enc_h"][:, 0].contiguous()
+    beam32 = state["scores"].to(torch.float32).view(B, R)
+    uv, ui = ops.rerank_topk(q_dev, D16, offs, cids, beam32, args.score_rate, R, max_cand=stride, cand_stride=stride)
+    assert torch.equal(uv, out["rerank_values"])
+    assert [[[str(x) for x in ui[b, a].tolist()] for a in range(A)] for b in range(B)] == out["doc_ids"]
+    lists, rows_seen = [], 0
+    for g in range(8):
+        lo, hi = shard_bounds(N, 8, g, cluster_size=12)
+        rows_seen += hi - lo
+        v, pos = ops.rerank_topk(q_dev, D16[lo:hi], offs, cids, beam32, args.score_rate, R, max_cand=stride, cand_stride=stride,
+                                 doc_range=(lo, hi), positions=True)
+        lists.append(ops.topk_pack(v.view(B * A, R), pos.view(B * A, R)))
+    assert rows_seen == N
+    mv, mp = ops.topk_merge_packed(torch.stack(lists))
+    mids = ops.rerank_positions_to_ids(mp.view(B, A * R), cids).view(B, A, R)
+    assert torch.equal(mv.view(B, A, R), uv) and torch.equal(mids, ui), "8 shards merged != unsharded on the 1M bf16 corpus"
+    # the exchange row of the sharded path: pack -> unpack is the identity
+    w = ops.rerank_wire_pack(q_dev, beam32, offs, cids)
+    q2, b2, o2, i2 = ops.rerank_wire_unpack(w, cfg.d_model, R, stride)
+    live = torch.arange(stride, device=dev)[None, :] < offs[:, R:R + 1]
+    assert torch.equal(q2, q_dev) and torch.equal(b2, beam32) and torch.equal(o2, offs) and torch.equal(i2[live], cids[live])
 
 
 def _lightning_ckpt(t5_sd, bert_sd):

@@ -1,6 +1,7 @@
 """CPU-only checks of the boundary and host logic: the C-ABI library loads and exports every symbol that
 include/gdr_hip.h declares; host routines inside it (no GPU work) match the reference's golden vectors."""
 import os
+import sys
 import re
 
 import numpy as np
@@ -274,6 +275,25 @@ def _cpu_rerank(q, D, offs, ids, beam, alphas, k, lo, hi, func, positions):
     return torch.from_numpy(vals), torch.from_numpy(out)
 
 
+def _cpu_wire():
+    """CPU stand-ins of ops.rerank_wire_pack / rerank_wire_unpack / rerank_positions_to_ids (test infrastructure)."""
+    import torch
+    i32 = torch.int32
+
+    def pack(q, beam, offs, ids):
+        return torch.cat([q.contiguous().view(i32), beam.contiguous().view(i32), offs.to(i32), ids.to(i32)], 1).contiguous()
+
+    def unpack(rows, d, R, stride):
+        return (rows[:, :d].contiguous().view(torch.float32), rows[:, d:d + R].contiguous().view(torch.float32),
+                rows[:, d + R:d + 2 * R + 1].contiguous(), rows[:, d + 2 * R + 1:].contiguous())
+
+    def pos2id(pos, ids):
+        p = pos.long()
+        return torch.where(p >= 0, ids.long().gather(1, p.clamp(min=0)), p).to(i32)
+
+    return pack, unpack, pos2id
+
+
 def _gloo_rerank_worker(rank, world, port, tmp):
     import os
     import numpy as np
@@ -333,7 +353,7 @@ def _gloo_rerank_worker(rank, world, port, tmp):
                     torch.zeros(Bq, dtype=torch.int32))
 
         index = ShardedIndex(torch.from_numpy(D[lo:hi]), lo, local_topk=lambda *a: None, pack=pack, merge_packed=merge_packed,
-                             local_rerank=_cpu_rerank)
+                             local_rerank=_cpu_rerank, wire=_cpu_wire())
         blk = slice(rank * Bl, (rank + 1) * Bl)
         T = lambda a: torch.from_numpy(np.ascontiguousarray(a))          # noqa: E731
         v, i = index.rerank_own(T(Q[blk]), T(offs[blk]), T(ids[blk]), T(beam[blk]), alphas, k)
@@ -361,6 +381,188 @@ def test_sharded_gdr_rerank_gloo(tmp_path, world):
     rows = [np.load(tmp_path / f"rr{r}.npy").tolist() for r in range(world)]
     assert all(r[:3] == [1, 1, 1] for r in rows), rows
     assert len({r[3] for r in rows}) > 1 and all(r[4] > 0 for r in rows), rows
+
+
+class _CpuDci:
+    """CPU stand-in of ops.DeviceClusterIndex.candidates (the gdr_cluster_candidates kernel): the host string path."""
+
+    def __init__(self, index, args, max_cluster):
+        self.index, self.args, self.max_cluster = index, args, max_cluster
+
+    def candidates(self, out_ids, B, R):
+        import torch
+        from gdr_amd import codec
+        stride = R * self.max_cluster
+        dec = codec.dec_2d(codec.decode_token(self.args, out_ids.numpy()), R)
+        offs = np.zeros((B, R + 1), np.int32)
+        ids = np.full((B, stride), -7, np.int32)
+        for b in range(B):
+            pos = 0
+            for j in range(R):
+                mem = np.asarray(self.index[dec[b][j]], np.int32)
+                ids[b, pos:pos + mem.size] = mem
+                pos += mem.size
+                offs[b, j + 1] = pos
+        return None, torch.from_numpy(offs), torch.from_numpy(ids), stride
+
+
+def _gloo_retriever_worker(rank, world, port, tmp):
+    import os
+    import types
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gdr_amd import codec, synth
+        from gdr_amd.dist import ShardedIndex, shard_bounds
+        from gdr_amd.modeling import GDRRetriever
+        V, depth, csz, d, R, Bl, L, ml = 5, 3, 7, 32, 4, 3, 6, 6
+        n_cl = V ** depth
+        N = n_cl * csz - 3                                   # the last cluster is short
+        names = ["-".join(str(x) for x in synth.cluster_digits(c, depth, V)) for c in range(n_cl)]
+        offsets = np.minimum(np.arange(n_cl + 1) * csz, N).astype(np.int32)
+        index = codec.ClusterIndex(names, offsets, np.arange(N, dtype=np.int32))
+        D = synth.make_corpus(N, d, cluster_size=csz, seed=4)
+        args = types.SimpleNamespace(num_return_sequences=R, output_vocab_size=V, max_output_length=ml, length_penalty=0.8,
+                                     kary=V, position=1, score_rate=[0, 0.5, 2], loss_func="tanh")
+        rng = np.random.Generator(np.random.PCG64(1000 + rank))    # every rank decodes ITS OWN queries
+
+        class FakeModel:                                          # stand-in of GDRModel._generate_launch (encoder + beam decode)
+            device = torch.device("cpu")
+
+            def _generate_launch(self, input_ids, mask, num_beams, max_length, length_penalty, nret):
+                B = input_ids.shape[0]
+                enc_h = torch.from_numpy(rng.standard_normal((B, L, d)).astype(np.float32) * 0.3)
+                ids = np.zeros((B * nret, max_length), np.int64)
+                for r in range(B * nret):
+                    if r % 5 == 4:                                # a row that names no cluster: depth too short
+                        toks = codec.encode_single_newid(args, "1-2")
+                    else:
+                        toks = codec.encode_single_newid(args, names[int(rng.integers(0, n_cl))])
+                    ids[r, 1:1 + len(toks)] = toks
+                lens = torch.full((B * nret,), depth + 1, dtype=torch.int32)
+                scores = torch.from_numpy(-np.sort(rng.random(B * nret))).double()
+                return enc_h, torch.from_numpy(ids), lens, scores
+
+        lo, hi = shard_bounds(N, world, rank, cluster_size=csz)
+        pack, merge_packed = _np_pack_merge()
+        sharded = ShardedIndex(torch.from_numpy(D[lo:hi]), lo, local_topk=lambda *a: None, pack=pack, merge_packed=merge_packed,
+                               local_rerank=_cpu_rerank, wire=_cpu_wire())
+        retr = GDRRetriever(FakeModel(), None, index, args, sharded=sharded)
+        retr._dci = _CpuDci(index, args, csz)
+        ok, n_docs = 1, 0
+        for step in range(2):                                     # two steps: the collectives stay in lockstep
+            batch = {"source_ids": torch.zeros((Bl, L), dtype=torch.int64), "texts": [f"q{rank}_{step}_{b}" for b in range(Bl)]}
+            state = retr._step_launch(batch)
+            out = retr._step_finish(state)
+            # expectation: the unsharded rerank over the whole corpus for this rank's own queries
+            _c, offs, ids, stride = retr._dci.candidates(state["ids"], Bl, R)
+            q = state["enc_h"][:, 0].contiguous()
+            beam = state["scores"].to(torch.float32).view(Bl, R)
+            rv, ri = _cpu_rerank(q, torch.from_numpy(D), offs, ids, beam, args.score_rate, R, 0, N, "tanh", False)
+            ok &= int(torch.equal(out["rerank_values"], rv))
+            want = [[[str(int(x)) for x in ri[b, ai]] for ai in range(3)] for b in range(Bl)]
+            ok &= int(out["doc_ids"] == want)
+            ok &= int(len(out["inf_index_batch"]) == Bl and out["inf_index_batch"][0][1][0][1] == ",".join(want[0][1]))
+            n_docs += int((ri >= 0).sum())
+        np.save(os.path.join(tmp, f"gr{rank}.npy"), np.array([ok, n_docs, hi - lo]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _np_pack_merge():
+    """numpy stand-ins of ops.topk_pack / ops.topk_merge_packed (the wire form of gdr_hip.h; padding entries sort last)."""
+    import torch
+
+    def pack(v, i, st):
+        Bq, kk = v.shape
+        pairs = np.zeros((Bq, kk + 1, 2), dtype=np.int32)
+        pairs[:, :kk, 0] = v.numpy().view(np.int32)
+        pairs[:, :kk, 1] = i.numpy()
+        return torch.from_numpy(pairs.view(np.int64).reshape(Bq, kk + 1))
+
+    def merge_packed(pairs):
+        G, Bq, k1 = pairs.shape
+        kk = k1 - 1
+        raw = pairs.numpy().view(np.int32).reshape(G, Bq, k1, 2)
+        v = np.ascontiguousarray(raw[:, :, :kk, 0]).view(np.float32).transpose(1, 0, 2).reshape(Bq, G * kk)
+        i = raw[:, :, :kk, 1].transpose(1, 0, 2).reshape(Bq, G * kk)
+        big = np.where(i < 0, np.iinfo(np.int32).max, i)
+        key = np.lexsort((big, -v), axis=1)[:, :kk]
+        return (torch.from_numpy(np.take_along_axis(v, key, 1)), torch.from_numpy(np.take_along_axis(i, key, 1)),
+                torch.zeros(Bq, dtype=torch.int32))
+
+    return pack, merge_packed
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_two_stage_retriever_gloo(tmp_path, world):
+    """The COMPOSED sharded two-stage path (BASELINE config C5's layout; main_models.py:1337-1642 with :1434-1462,1574-1637
+    sharded) under gloo at world size 2: GDRRetriever(sharded=ShardedIndex) — every rank decodes its own queries, builds
+    their candidate blocks, rerank_own exchanges / scores / merges, positions map back to doc ids, the host formats the
+    reference's step output.  Stand-ins for the compute (encoder + beam decode, cluster lookup, per-shard rerank); the
+    retriever and the collective logic are the product code.  Equals the unsharded rerank over the whole corpus bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gloo_retriever_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rows = [np.load(tmp_path / f"gr{r}.npy").tolist() for r in range(world)]
+    assert all(r[0] == 1 and r[1] > 0 for r in rows), rows
+
+
+def test_launcher_spawns_fresh_ranks_and_relays_one_json_line(tmp_path, monkeypatch, capsys):
+    """`python bench.py --gpus N` with no RANK in the environment (the driver's multi-GPU command; the reference's analogue of
+    one command fanning out over the GPUs is Data_process/NQ_dataset/bert/bert_NQ.sh:5-12): gdr_amd.launch.spawn_ranks starts
+    N fresh rank processes under torch.distributed.run — proven here with a stub rank script on CPU: two children with RANK
+    0 / 1 and WORLD_SIZE 2 ran, one JSON line came back, a failing rank makes the launcher's code non-zero — and bench.main()
+    routes `--gpus 2` into it with its own path as the script, lets only the JSON line through to stdout and exits with the
+    launcher's code."""
+    import json
+    from gdr_amd import launch
+    stub = tmp_path / "rank_stub.py"
+    stub.write_text(
+        "import json, os, sys\n"
+        "rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "open(os.path.join(sys.argv[1], f'seen{rank}'), 'w').write(os.environ['MASTER_ADDR'] + ' ' + ' '.join(sys.argv[2:]))\n"
+        "print(f'[rank {rank}] noise')\n"
+        "if '--fail' in sys.argv and rank == 1: sys.exit(3)\n"
+        "if rank == 0: print(json.dumps({'metric': 'stub', 'n_gpus': world}))\n")
+    rc, text = launch.spawn_ranks(2, [str(tmp_path), "--steps", "2"], script=str(stub), relay=False)
+    assert rc == 0, text
+    assert sorted(f.name for f in tmp_path.glob("seen*")) == ["seen0", "seen1"]
+    assert (tmp_path / "seen1").read_text() == "127.0.0.1 --steps 2"
+    js = [json.loads(ln) for ln in text.splitlines() if ln.startswith("{")]
+    assert js == [{"metric": "stub", "n_gpus": 2}]
+    rc, _ = launch.spawn_ranks(2, [str(tmp_path), "--fail"], script=str(stub), relay=False)
+    assert rc != 0
+    # bench.py's side of it
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_spawn(n, argv, script=None, module=None, relay=True, **kw):
+        seen.update(n=n, argv=list(argv), script=script)
+        relay("[rank 1] noise\n")
+        relay('{"metric": "x"}\n')
+        return 5, ""
+
+    monkeypatch.setattr(launch, "spawn_ranks", fake_spawn)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--launcher"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 5
+    assert seen["n"] == 2 and seen["argv"] == ["--gpus", "2", "--steps", "3"] and seen["script"] == os.path.join(REPO, "bench.py")
+    cap = capsys.readouterr()
+    assert cap.out == '{"metric": "x"}\n' and "noise" in cap.err
 
 
 def test_trie_flattening_matches_reference_treebuilder_semantics():
