@@ -85,6 +85,9 @@ _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 SIGNATURES = {
     "gdr_last_error": (C.c_char_p, []),
     "gdr_abi_version": (_i, []),
+    "gdr_device_fault_pending": (_i, []),
+    "gdr_device_fault_clear": (None, []),
+    "gdr_device_fault_inject_for_tests": (None, []),
     "gdr_prof_enable": (_i, [_i]),
     "gdr_prof_collect": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gdr_linear_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
@@ -168,6 +171,14 @@ def check(rc, what):
     if rc != 0:
         msg = lib().gdr_last_error().decode("utf-8", "replace")
         raise GdrError(f"{what} failed (code {rc}): {msg}")
+
+
+def check_device_fault(what):
+    """Raises if a kernel has reported a device-side fault since the last gdr_device_fault_clear() (today: a stream-K
+    hand-off that timed out, include/gdr_hip.h) — called where the host has just synchronised with the device, before the
+    result it read back is trusted.  The fault stays pending until the caller clears it."""
+    if lib().gdr_device_fault_pending():
+        raise GdrError(f"{what}: " + lib().gdr_last_error().decode("utf-8", "replace"))
 
 
 def ptr(t):

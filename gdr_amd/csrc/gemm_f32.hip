@@ -710,8 +710,11 @@ struct StreamKArgs {
 // A take-over spin that runs out (the predecessor workgroup never became resident for seconds — a co-tenant kernel that
 // starves it; the kernel itself assumes its <= 512 workgroups are co-resident, 2 per CU) used to trap, which aborts the
 // whole process.  Now the waiting lane raises this process-wide word (pinned host memory, mapped into every device) and
-// the workgroup goes on with whatever the hand-off buffer holds: the launch completes, its output is WRONG, and the next
-// stream-K launch from the host (streamk_poll_error) reports GDR_EHIP once.  No hang, no abort.
+// the workgroup goes on with whatever the hand-off buffer holds: the launch completes, its output is WRONG.  The word is
+// STICKY: it stays raised until the caller acknowledges it with gdr_device_fault_clear(), every stream-K launch enqueued
+// while it is raised fails with GDR_EHIP, and gdr_device_fault_pending() lets a caller check it where it synchronises
+// anyway (the Python side does after every result read-back: ops.finish_generate_output, sim_topk's status read,
+// GDRRetriever's step output) — so an invalid result is never handed out as GDR_OK unnoticed, whichever launch was last.
 static int32_t* streamk_err_word() {
   static int32_t* word = [] {
     int32_t* h = nullptr;
@@ -724,16 +727,35 @@ static int32_t* streamk_err_word() {
   }();
   return word;
 }
+static const char* const kStreamKFault =
+    "linear(stream-K): a hand-off between workgroups timed out in an earlier launch (its 512 workgroups were not co-resident: "
+    "another kernel held the CUs for seconds); results produced since the last gdr_device_fault_clear() are invalid";
 static int streamk_poll_error() {
   int32_t* w = streamk_err_word();
   if (w && __atomic_load_n(w, __ATOMIC_RELAXED) != 0) {
-    __atomic_store_n(w, 0, __ATOMIC_RELAXED);
-    set_error("linear(stream-K): a hand-off between workgroups timed out in an EARLIER launch (its 512 workgroups were not "
-              "co-resident: another kernel held the CUs for seconds); that launch's output is invalid");
+    set_error("%s", kStreamKFault);
     return GDR_EHIP;
   }
   return GDR_OK;
 }
+}  // namespace gdr
+extern "C" int gdr_device_fault_pending(void) {
+  int32_t* w = gdr::streamk_err_word();
+  if (w && __atomic_load_n(w, __ATOMIC_RELAXED) != 0) {
+    gdr::set_error("%s", gdr::kStreamKFault);
+    return 1;
+  }
+  return 0;
+}
+extern "C" void gdr_device_fault_clear(void) {
+  int32_t* w = gdr::streamk_err_word();
+  if (w) __atomic_store_n(w, 0, __ATOMIC_RELAXED);
+}
+extern "C" void gdr_device_fault_inject_for_tests(void) {   // raises the word exactly as a timed-out take-over would
+  int32_t* w = gdr::streamk_err_word();
+  if (w) __atomic_store_n(w, 1, __ATOMIC_RELAXED);
+}
+namespace gdr {
 // When it runs: the whole-tile form takes ceil(T/G) rounds (measured: a last round with <= 256 tiles is no shorter), this
 // form T/G rounds plus the hand-off (one 64 KB write-through publish and one 64 KB take-over per workgroup, ~5 K-steps of
 // time at 2 workgroups per CU).  It is used when the whole-tile form's idle tail, (G - T mod G)/G of a round, exceeds

@@ -419,6 +419,7 @@ class GDRRetriever:
         if dci is not None:
             dec = codec.dec_2d(codec.decode_token(a, outs.cpu().numpy()), R)
         idx_h = idx.cpu().tolist()
+        _ffi.check_device_fault("validation_step_i")             # everything of this step has been read back
         doc_ids = [[[str(x) for x in idx_h[b][ai]] for ai in range(len(a.score_rate))] for b in range(B)]
         inf_result, inf_index = [], []
         texts = batch.get("texts")

@@ -130,6 +130,7 @@ def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_o
     vals, idx, status = _sim_topk_raw(Q, D, k, idx_offset, workspace, flags)
     if exact_on_overflow:
         bad = torch.nonzero(status).flatten()
+        _ffi.check_device_fault("sim_topk")                              # nonzero() synchronised
         if bad.numel():
             for lo in range(0, bad.numel(), 64):                     # bounded workspace: 64 queries * N * 8 B
                 rows = bad[lo:lo + 64]
@@ -739,4 +740,6 @@ def beam_search_table(table, out_vocab, num_beams, max_length, length_penalty, n
 def finish_generate_output(ids, lens, scores, max_length):
     """Host tail of generation_utils.py:905-919: width = min(max(len)+1, max_length); scores as Python floats."""
     sent_max_len = min(int(lens.max().item()) + 1, max_length)
-    return ids[:, :sent_max_len].contiguous(), scores.cpu().tolist()
+    out = ids[:, :sent_max_len].contiguous(), scores.cpu().tolist()
+    _ffi.check_device_fault("generate")                      # the host has just synchronised: a faulted launch must not pass
+    return out

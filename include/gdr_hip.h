@@ -287,6 +287,16 @@ int gdr_rerank_wire_unpack(const int32_t* wire, int B, int d, int R, int cand_st
 int gdr_rerank_positions_to_ids(const int32_t* pos, const int32_t* cand_ids, int B, int per_query, int cand_stride,
                                 int32_t* out_ids, void* stream);
 
+/* Device-side faults that do not abort the process.  The stream-K form of the linear GEMM hands raw accumulators from one
+ * workgroup to the next behind a bounded spin; if that spin ever runs out (the launch's workgroups were not co-resident)
+ * the launch completes with INVALID output and raises a sticky, process-wide fault word.  While it is raised every
+ * stream-K launch fails with GDR_EHIP; gdr_device_fault_pending() returns 1 (message in gdr_last_error()) so that a
+ * caller can check it wherever it synchronises with the device before trusting a result; gdr_device_fault_clear()
+ * acknowledges it.  Nothing clears it implicitly.  gdr_device_fault_inject_for_tests() raises it by hand (host only). */
+int gdr_device_fault_pending(void);
+void gdr_device_fault_clear(void);
+void gdr_device_fault_inject_for_tests(void);
+
 /* T5 relative-position buckets (transformers/modeling_t5.py:242-288) for relative_position =
  * key_pos - query_pos, written to a HOST int32[qlen*klen] table; the attention kernels use the same
  * host routine, so tests pin it bit-exact against the reference. */

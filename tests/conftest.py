@@ -74,3 +74,40 @@ def ranked_lists_match(ref_items, ref_scores, got_items, tol):
             permuted += sum(1 for x, y in zip(a, b) if x != y)
         j = e + 1
     return permuted
+
+
+def hypothesis_lists_match(ref_items, ref_scores, got_items, tol):
+    """The rule for lists of beam HYPOTHESES under a noisy arithmetic (the bf16 precision mode), with teeth.
+    `tol` is ABSOLUTE and must come from the measured score gap between the two implementations (the caller asserts that
+    gap first): two hypotheses whose reference scores differ by more than 2*tol cannot legitimately swap.  Neighbours of the
+    reference list closer than 2*tol chain into one tie group.  For every position p of `got`:
+      * the item is the reference's item at p: fine;
+      * the item sits at another reference position r: p and r must lie in the SAME tie group (asserted in every group, the
+        last one included — it is only 'cut' for items that left the list, next case);
+      * the item is not in the reference list at all (it crossed the cut at k): p must lie in the LAST tie group, i.e. tie with
+        the list's worst score.
+    Returns (moved, foreign, group_sizes) so that the caller can print that the rule is not one big group."""
+    k = len(ref_items)
+    assert len(got_items) == k, (len(got_items), k)
+    sc = np.asarray(ref_scores, dtype=np.float64)
+    group, sizes = np.zeros(k, np.int64), [1]
+    for i in range(1, k):
+        if abs(sc[i - 1] - sc[i]) <= 2 * tol:
+            group[i] = group[i - 1]
+            sizes[-1] += 1
+        else:
+            group[i] = group[i - 1] + 1
+            sizes.append(1)
+    pos = {x: i for i, x in enumerate(ref_items)}
+    assert len(pos) == k, "reference hypotheses are distinct"
+    moved = foreign = 0
+    for p, x in enumerate(got_items):
+        r = pos.get(x)
+        if r is None:
+            assert group[p] == group[k - 1], ("a hypothesis outside the reference list at a slot that does not tie with the cut",
+                                              p, x, sc[p], sc[k - 1], tol)
+            foreign += 1
+        elif r != p:
+            assert group[p] == group[r], ("two hypotheses swapped outside a tolerance-tie group", p, r, sc[p], sc[r], tol)
+            moved += 1
+    return moved, foreign, sizes

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, ranked_lists_match
+from conftest import hypothesis_lists_match, golden, ranked_lists_match
 from gdr_amd.config import GDRConfig
 from gdr_amd import synth
 
@@ -385,16 +385,28 @@ def test_generate_bf16_mode_vs_oracle_emulation(dev, kind, B, R, use_table):
     np.testing.assert_allclose(sc, fs, rtol=3e-2, atol=3e-2)
     got, ref = dec.cpu().numpy(), rd.numpy()
     W = min(got.shape[1], ref.shape[1])
-    permuted = 0
+    # ids.  First the measured score gap between the GPU and the emulation on the hypotheses both returned: it bounds the
+    # bf16 noise of a hypothesis score, and the tie tolerance of the id rule is that measured gap (absolute), not a guess
+    glists = [[tuple(r[:W]) for r in got[b * R:(b + 1) * R].tolist()] for b in range(B)]
+    rlists = [[tuple(r[:W]) for r in ref[b * R:(b + 1) * R].tolist()] for b in range(B)]
+    gap = 0.0
     for b in range(B):
-        glist = [tuple(r[:W]) for r in got[b * R:(b + 1) * R].tolist()]
-        rlist = [tuple(r[:W]) for r in ref[b * R:(b + 1) * R].tolist()]
-        gset, rset = set(glist), set(rlist)
-        assert len(gset & rset) >= 0.7 * R, (b, len(gset & rset))
-        permuted += ranked_lists_match(rlist, rs[b], glist, 1.5e-2)     # raises on an id that differs outside a tie group
-        if rs[b, 0] - rs[b, 1] > 3e-2 * (1 + abs(rs[b, 0])):
-            assert tuple(got[b * R][:W]) == tuple(ref[b * R][:W])
-    print(f"bf16 generate {kind} R={R} table={use_table}: {permuted} slots permuted inside tolerance-tie groups, 0 ids differ outside them")
+        where = {x: i for i, x in enumerate(rlists[b])}
+        gap = max([gap] + [abs(sc[b, p] - rs[b, where[x]]) for p, x in enumerate(glists[b]) if x in where])
+    assert gap <= 5e-3, f"hypothesis scores of the GPU and the emulation differ by {gap:.2e} on shared hypotheses"
+    tie = max(gap, 2e-4)
+    moved = foreign = shared = 0
+    sizes = []
+    for b in range(B):
+        m, f, sz = hypothesis_lists_match(rlists[b], rs[b], glists[b], tie)   # raises when two non-tied hypotheses swap
+        moved, foreign, shared = moved + m, foreign + f, shared + len(set(glists[b]) & set(rlists[b]))
+        sizes.append(sz)
+        if rs[b, 0] - rs[b, 1] > 2 * tie:
+            assert glists[b][0] == rlists[b][0]
+    assert shared >= (0.95 if kind == "base" else 0.8) * B * R, (shared, B * R)
+    print(f"bf16 generate {kind} R={R} table={use_table}: score gap {gap:.2e} -> tie window {2 * tie:.2e} (absolute); "
+          f"{shared}/{B * R} hypotheses shared, {moved} moved inside a tie group, {foreign} crossed the cut inside the last group; "
+          f"tie-group sizes per query: {sizes}")
 
 
 def test_generate_graph_replay_is_identical(dev):

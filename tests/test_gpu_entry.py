@@ -21,7 +21,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, golden, order_insensitive_topk_match, ranked_lists_match
+from conftest import REPO, golden, hypothesis_lists_match, order_insensitive_topk_match, ranked_lists_match
 from gdr_amd.config import GDRConfig
 from gdr_amd import synth
 
@@ -303,10 +303,11 @@ def test_c5_composed_bf16_two_stage_on_1m_corpus(dev, base_weights):
     so that every decoded id names a cluster) -> device cluster lookup -> in-cluster rerank over the bf16 corpus
     (gdr_rerank_topk_bf16; main_models.py:1574-1637).  The reference has no bf16 mode, so parity is stated per stage
     against the oracle applied to the same bf16-rounded operands:
-      stage 1 (3 of the 64 queries): the oracle's emulation of the decode path's rounding points on the GPU's own encoder
-              states; scores within 3e-2; ids compared rank by rank with the tolerance-tie rule — an id may differ from the
-              emulation only inside a group of hypotheses whose scores are closer than the bf16 noise; the count of ids
-              that differ OUTSIDE such groups is asserted to be 0 (conftest.ranked_lists_match raises on the first one);
+      stage 1 (8 of the 64 queries): the oracle's emulation of the decode path's rounding points on the GPU's own encoder
+              states; scores within 3e-2 of it; the score gap on shared hypotheses is MEASURED, asserted <= 5e-3 and used as
+              the absolute tie tolerance of the id rule (conftest.hypothesis_lists_match): a hypothesis may sit at another
+              rank than the emulation's only inside a group of hypotheses whose emulation scores chain closer than twice that
+              gap, in every group including the last; >= 95 % of the ids are the emulation's; the group sizes are printed;
       stage 2 (all 64 queries): the oracle rerank on the bf16-rounded corpus rows and the GPU's stage-1 output: values
               to 1e-4, ids exact outside fp32 tolerance ties."""
     from gdr_amd import codec, ops
@@ -334,7 +335,7 @@ def test_c5_composed_bf16_two_stage_on_1m_corpus(dev, base_weights):
     assert all(s in look for row in out["clusters"] for s in row), "constrained beams decode real clusters only"
     got_scores = np.array(out["inf_result_batch_prob"], np.float64).reshape(B, R)
     # ---- stage 1 vs the oracle's bf16 emulation, on the GPU's own encoder states
-    nq = 3
+    nq = 8
     enc_cpu = state["enc_h"][:nq].cpu()
     idx = torch.arange(nq).view(-1, 1).repeat(1, R).view(-1)
     enc_x, mask_x = enc_cpu.index_select(0, idx), torch.from_numpy(mask[:nq]).index_select(0, idx)
@@ -348,14 +349,24 @@ def test_c5_composed_bf16_two_stage_on_1m_corpus(dev, base_weights):
     dec = codec_ref.dec_2d(codec_ref.decode_token(rd.numpy(), output_vocab_size=V, kary=V), R)
     rs2 = np.array(rs, np.float64).reshape(nq, R)
     np.testing.assert_allclose(got_scores[:nq], rs2, rtol=3e-2, atol=3e-2)
-    BF16_TOL = 1.5e-2                                          # hypothesis-score noise of two correct bf16 decodes
-    permuted = shared = 0
+    # the measured score gap on the hypotheses both sides returned IS the bf16 noise of a hypothesis score; the tie tolerance
+    # of the id rule is that gap (absolute) — with a tolerance wider than the list's own spread the rule would be one group
+    gap = 0.0
     for q in range(nq):
-        permuted += ranked_lists_match(dec[q], rs2[q], out["clusters"][q], BF16_TOL)   # raises on an id differing outside a tie group
-        shared += len(set(dec[q]) & set(out["clusters"][q]))
-    assert shared >= 0.7 * nq * R, (shared, permuted)
-    print(f"C5 stage 1: {shared}/{nq * R} ids shared with the emulation, {permuted} slots permuted inside tolerance-tie groups, "
-          "0 ids differ outside them")
+        where = {x: i for i, x in enumerate(dec[q])}
+        gap = max([gap] + [abs(got_scores[q, p] - rs2[q, where[x]]) for p, x in enumerate(out["clusters"][q]) if x in where])
+    assert gap <= 5e-3, f"stage-1 scores of the GPU and the emulation differ by {gap:.2e} on shared hypotheses"
+    tie = max(gap, 2e-4)
+    moved = foreign = shared = 0
+    sizes = []
+    for q in range(nq):
+        m, f, sz = hypothesis_lists_match(dec[q], rs2[q], out["clusters"][q], tie)   # raises when two non-tied hypotheses swap
+        moved, foreign, shared = moved + m, foreign + f, shared + len(set(dec[q]) & set(out["clusters"][q]))
+        sizes.append(sz)
+    assert shared >= 0.95 * nq * R, (shared, moved, foreign)
+    assert max(max(sz) for sz in sizes) < R, "the tie rule must not degenerate into one group"
+    print(f"C5 stage 1 ({nq} queries): score gap {gap:.2e} -> tie window {2 * tie:.2e}; {shared}/{nq * R} ids shared with the "
+          f"emulation, {moved} moved inside a tie group, {foreign} crossed the cut inside the last group; tie-group sizes: {sizes}")
     # ---- stage 2 on all 64 queries: oracle rerank on the bf16-rounded rows the GPU gathered
     q_emb = state["enc_h"][:, 0].cpu()
     cand = [[m for s_ in row for m in range(int(offsets[look[s_]]), int(offsets[look[s_] + 1]))] for row in out["clusters"]]

@@ -523,3 +523,34 @@ def test_linear_with_streamk_scratch_is_bit_identical_to_whole_tiles(dev, M, N, 
     assert torch.equal(h0, h1)
     ref = (A[:64].cpu().double() @ W.cpu().double().T).float()                # and it is the right product
     torch.testing.assert_close(ops.linear(A, W, splitk_ws=ws)[:64].cpu(), ref, rtol=TOL, atol=TOL)
+
+
+def test_device_fault_is_sticky_and_reaches_the_caller(dev):
+    """A stream-K hand-off that times out leaves its launch's output invalid (gemm_f32.hip).  The fault word it raises must
+    not be lost or handed to an unrelated call: it stays pending until gdr_device_fault_clear(), every stream-K launch
+    enqueued meanwhile fails with GDR_EHIP, and the Python surface refuses to hand out a result it has just read back
+    (finish_generate_output, sim_topk).  Raised by hand here — a real timeout needs a co-tenant kernel starving the chip."""
+    from gdr_amd import ops, _ffi
+    l = _ffi.lib()
+    A = torch.randn(12308, 768).to(dev)
+    W = torch.randn(768, 768).to(dev)
+    ws = torch.empty(48 << 20, dtype=torch.uint8, device=dev)
+    good = ops.linear(A, W, splitk_ws=ws)                       # 582 tiles: the stream-K tail runs
+    assert l.gdr_device_fault_pending() == 0
+    l.gdr_device_fault_inject_for_tests()
+    try:
+        assert l.gdr_device_fault_pending() == 1 and l.gdr_device_fault_pending() == 1      # reading does not clear it
+        with pytest.raises(_ffi.GdrError, match="hand-off"):
+            ops.linear(A, W, splitk_ws=ws)
+        with pytest.raises(_ffi.GdrError, match="hand-off"):
+            ops.linear(A, W, splitk_ws=ws)                       # still pending for the next caller
+        D = torch.randn(20000, 768).to(dev)
+        with pytest.raises(_ffi.GdrError, match="sim_topk"):
+            ops.sim_topk(A[:4].contiguous(), D, 10)
+        ids = torch.zeros((2, 5), dtype=torch.int64, device=dev)
+        with pytest.raises(_ffi.GdrError, match="generate"):
+            ops.finish_generate_output(ids, torch.ones(2, dtype=torch.int32, device=dev), torch.zeros(2, dtype=torch.float64, device=dev), 5)
+    finally:
+        l.gdr_device_fault_clear()
+    assert l.gdr_device_fault_pending() == 0
+    assert torch.equal(ops.linear(A, W, splitk_ws=ws), good)

@@ -59,6 +59,18 @@ assert E(l.gdr_rerank_topk(FAKE, FAKE, 768, FAKE, FAKE, FAKE, 4, 10, FAKE, 2, 10
 assert E(l.gdr_rerank_topk_bf16(FAKE, FAKE, 768, FAKE, FAKE, FAKE, 4, 10, FAKE, 2, 10, 2, FAKE, FAKE, 120, 0, 0, 100, 0, FAKE, 1 << 20, None))
 ci = _ffi.GdrClusterIndex(10, 4, 12, FAKE.value, FAKE.value, FAKE.value, FAKE.value, FAKE.value)   # table_size not a power of two
 assert E(l.gdr_cluster_candidates(C.byref(ci), FAKE, 2, 3, 10, FAKE, FAKE, FAKE, 36, None))
+assert E(l.gdr_rerank_wire_pack(FAKE, FAKE, FAKE, None, 4, 768, 10, 120, FAKE, None))
+assert E(l.gdr_rerank_wire_pack(FAKE, FAKE, FAKE, FAKE, 4, 768, 0, 120, FAKE, None))
+assert E(l.gdr_rerank_wire_unpack(FAKE, 0, 768, 10, 120, FAKE, FAKE, FAKE, FAKE, None))
+assert E(l.gdr_rerank_positions_to_ids(FAKE, FAKE, 4, 0, 120, FAKE, None))
+# the sticky device-fault word (hipHostMalloc may fail without a GPU: then nothing is ever pending)
+l.gdr_device_fault_clear()
+assert l.gdr_device_fault_pending() == 0
+l.gdr_device_fault_inject_for_tests()
+p1 = l.gdr_device_fault_pending()
+assert p1 in (0, 1) and l.gdr_device_fault_pending() == p1          # reading does not clear it
+l.gdr_device_fault_clear()
+assert l.gdr_device_fault_pending() == 0
 # ---- drivers: host pointer tables with fake device pointers; validation + workspace carving run, the first launch fails
 layers = (_ffi.GdrT5EncLayer * 2)()
 for ly in layers:
