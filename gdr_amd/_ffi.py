@@ -127,6 +127,7 @@ SIGNATURES = {
     "gdr_t5_generate_bf16": (_i, [C.POINTER(GdrT5DecoderWeights), _vp, _vp, _i, _i, _i, _i, C.c_double, _i,
                                   C.POINTER(GdrTrie), C.POINTER(GdrPrefixTable), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gdr_t5_generate_early_exits": (C.c_int64, []),
+    "gdr_t5_generate_last_done_step": (_i, []),
     "gdr_t5_prefix_table_build_bf16": (_i, [C.POINTER(GdrT5DecoderWeights), _i, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp,
                                             _vp, _sz, _vp]),
     "gdr_t5_prefix_table_workspace_bytes": (_sz, [C.POINTER(GdrT5DecoderWeights), _i]),

@@ -667,8 +667,10 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamBufs bb, BeamDims 
           // generation_utils.py:836-838 `if all(done): break` — the host polls this word between steps (generate_impl)
           if (atomicAdd(bb.n_done, 1) + 1 == bd.B) {
             *bb.live = 0;  // the steps already enqueued skip their linears (StreamK::live) and their miss-row chain
-            if (bb.all_done_host)
+            if (bb.all_done_host) {
+              __hip_atomic_store(bb.all_done_host + 64, cur_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the step it happened at
               __hip_atomic_store(bb.all_done_host, bb.done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
           }
         }
       }
@@ -820,12 +822,13 @@ static int beam_end(const BeamBufs& bb, const BeamDims& bd, int max_length, int 
 static int32_t* done_words() {
   static int32_t* words = [] {
     int32_t* h = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void**>(&h), 64 * sizeof(int32_t), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) !=
+    // words 0..63: the epoch words; words 64..127: the decode step (cur_len) at which word i's call saw its last query finish
+    if (hipHostMalloc(reinterpret_cast<void**>(&h), 128 * sizeof(int32_t), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) !=
         hipSuccess) {
       (void)hipGetLastError();
       return static_cast<int32_t*>(nullptr);
     }
-    for (int i = 0; i < 64; ++i) h[i] = 0;
+    for (int i = 0; i < 128; ++i) h[i] = 0;
     return h;
   }();
   return words;
@@ -905,13 +908,39 @@ static int dec_linear(bool bf16, void* abf, const float* A, int64_t lda, const f
   if (int rc = launch_cast_f32_bf16(A, abf, M * (int64_t)K, st)) return rc;
   return launch_linear_bf16(abf, K, W, ldw, C, ldc, M, N, K, epi, bias, res, ldr, st, m_dev);
 }
+// bf16 mode: a linear whose output feeds nothing but the next linear (wi -> wo_ff, linear1 -> linear2) emits it as bf16 straight
+// from the GEMM epilogue — no fp32 copy is written and the consumer needs no cast launch (the rounding is the cast kernel's RNE of
+// the same fp32 value: results are bit-identical).  out->buf receives the rows, out->src is set to `C` (the fp32 buffer the
+// consumer names as its operand).  Returns 1 when the LDS-DMA kernel does not serve the shape (the caller runs the fp32 form).
+static int dec_linear_out16(void* abf, const float* A, int64_t lda, const float* W, int64_t ldw, const float* C, int64_t ldc,
+                            int64_t M, const int64_t* m_dev, int N, int K, int epi, const float* bias, hipStream_t st,
+                            const Bf16Image* img, Bf16Image* out) {
+  if (!out || !out->buf || lda != K || K % 64 != 0 || ldc != N) return 1;
+  if (M == 0) return GDR_OK;
+  const bool nb = epi == GDR_EPI_BIAS || epi == GDR_EPI_BIAS_RELU;
+  const int act = (epi == GDR_EPI_RELU || epi == GDR_EPI_BIAS_RELU) ? 1 : 0;
+  if (epi == GDR_EPI_RESIDUAL || epi == GDR_EPI_BIAS_RESIDUAL || epi == GDR_EPI_BIAS_GELU || (nb && !bias)) return 1;
+  const void* a16 = abf;
+  if (img && img->buf && img->src == A) {
+    a16 = img->buf;
+  } else if (int rc = launch_cast_f32_bf16(A, abf, M * (int64_t)K, st)) {
+    return rc;
+  }
+  ProfScope prof(PROF_LINEAR, 2.0 * (double)M * (double)N * (double)K, st);
+  const int rc = launch_linear_bf16_glds(a16, K, W, ldw, static_cast<float*>(out->buf), ldc, M, N, K, nb, 0, act, bias, nullptr, 0, 1, st,
+                                         m_dev);
+  if (rc == 0) out->src = C;
+  return rc;
+}
 // A linear whose output rows are whole model rows, followed by the norm that always comes next on the decode path:
 // C = epilogue(A·W^T), ne.Y = norm(C).  fp32 with split-K: the reduction kernel applies the norm while it holds the
 // finished row (one launch instead of two or three); otherwise the linear and the norm kernels run one after another.
 static int dec_linear_norm(bool bf16, void* abf, const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
                            int64_t M, const int64_t* m_dev, int N, int K, int epi, const float* bias, const float* res,
                            int64_t ldr, float* skw, hipStream_t st, const NormEpilogue& ne, StreamK* sk = nullptr,
-                           Bf16Image* img = nullptr) {
+                           Bf16Image* img = nullptr, const Bf16Image* a_img = nullptr) {
+  // img: receives the bf16 image of the norm's output; a_img (optional): where THIS linear's operand already lies as bf16
+  // (an attention context or a ReLU output emitted as bf16 by its producer) — otherwise img is looked at for the operand too
   if (M == 0) return GDR_OK;
   static const bool fuse_on = [] {
     const char* e = getenv("GDR_DECODE_FUSE_NORM");  // A/B knob: 0 = always separate launches
@@ -928,7 +957,8 @@ static int dec_linear_norm(bool bf16, void* abf, const float* A, int64_t lda, co
                                            m_dev, &ne, nullptr, sk ? sk->live : nullptr);
     if (rc <= 0) return rc;
   }
-  if (int rc = dec_linear(bf16, abf, A, lda, W, ldw, C, ldc, M, m_dev, N, K, epi, bias, res, ldr, skw, st, sk, img)) return rc;
+  if (int rc = dec_linear(bf16, abf, A, lda, W, ldw, C, ldc, M, m_dev, N, K, epi, bias, res, ldr, skw, st, sk, a_img ? a_img : img))
+    return rc;
   // bf16 mode: the last norm of this call also leaves its output rounded to bf16 for the linear that reads it next
   void* y16 = (bf16 && img && img->buf && ne.ldy == N) ? img->buf : nullptr;
   if (img) img->src = y16 ? ne.Y : nullptr;
@@ -952,7 +982,7 @@ static const float* w_at(const float* W, size_t elems, bool bf16) {
 
 // ------------------------------------------------------------------------------------------ model workspace
 struct GenWs {
-  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, abf, abf2, img1, img2, total;
+  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, abf, abf2, img1, img2, c16a, c16b, f16a, f16b, total;
 };
 
 static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
@@ -985,6 +1015,10 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
   g.abf2 = carve(o, 2 * abf_main);                      //            ... of the side stream (adaptor chain, cross K/V projections)
   g.img1 = carve(o, 2 * rows * d);                      // bf16 mode: the bf16 image of the last normed rows of either chain (Bf16Image)
   g.img2 = carve(o, 2 * rows * d);
+  g.c16a = carve(o, 2 * rows * (inner > d ? inner : d));   // bf16 mode: attention contexts / ReLU outputs emitted as bf16 by their
+  g.c16b = carve(o, 2 * rows * d);                         // producers (a: decoder chain, b: adaptor chain) — the operand of
+  g.f16a = carve(o, 2 * rows * ffw);                       // the linear behind them, which then needs no cast launch
+  g.f16b = carve(o, 2 * rows * (size_t)w.adaptor_ff);
   g.total = o;
   return g;
 }
@@ -1016,6 +1050,21 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   GDR_CHECK_ARG(!ptab || !trie || (trie->child == ptab->child && trie->n_nodes == ptab->n_nodes),
                 "generate: the trie constraint and the prefix table must be built over the same trie arrays");
   GDR_CHECK_ARG(!ptab || (dm.d_model % 32 == 0 && w->adaptor_ff % 32 == 0), "generate: prefix-table mode needs d %% 32 == 0");
+  if (ptab && ptab->complete_levels > 1) {
+    // complete_levels = c claims that levels 0 .. c-1 of the table hold ALL V^s prefixes of their length: at steps s < c the
+    // miss-row chain is not even enqueued, so an overstated c would read head rows nobody computed.  It can be checked
+    // against the table's own size: sum_{s<c} V^s nodes must fit in n_table, and no level lies beyond the decode length.
+    GDR_CHECK_ARG(ptab->complete_levels <= w->max_out_len - 1, "generate: prefix table complete_levels=%d exceeds the %d decode steps",
+                  ptab->complete_levels, w->max_out_len - 1);
+    int64_t need = 0, pw = 1;
+    for (int s = 0; s < ptab->complete_levels; ++s) {
+      need += pw;
+      pw *= ptab->V;
+      if (need > ptab->n_table) break;
+    }
+    GDR_CHECK_ARG(need <= ptab->n_table, "generate: prefix table claims %d complete levels (>= %lld nodes) but holds %d nodes",
+                  ptab->complete_levels, (long long)need, ptab->n_table);
+  }
   BeamDims bd{B, num_beams, w->out_vocab, dm.vocab_size, max_length, num_return_sequences, length_penalty,
               trie ? trie->child : (ptab ? ptab->child : nullptr), trie ? trie->eos_ok : nullptr,
               trie ? trie->n_nodes : (ptab ? ptab->n_nodes : 0)};
@@ -1045,6 +1094,13 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
         *skw = F(g.splitk), *ctx2 = F(g.ctx2), *ff2 = F(g.ff2), *skw2 = F(g.splitk2), *qkv_c = F(g.qkv_c);
   void *abf = base + g.abf, *abf2 = base + g.abf2;
   Bf16Image img1{nullptr, bf16 ? base + g.img1 : nullptr}, img2{nullptr, bf16 ? base + g.img2 : nullptr};
+  Bf16Image c16a{nullptr, bf16 ? base + g.c16a : nullptr}, c16b{nullptr, bf16 ? base + g.c16b : nullptr};
+  Bf16Image f16a{nullptr, bf16 ? base + g.f16a : nullptr}, f16b{nullptr, bf16 ? base + g.f16b : nullptr};
+  // the bf16-mode attention kernels write the context's bf16 image only (d_kv % 4 == 0 rows of 8-byte pieces)
+  auto ctx_to = [&](AttnArgs& at_, Bf16Image& im, float* fp32_ctx) {
+    if (bf16 && im.buf) at_.out = nullptr, at_.out_bf16 = im.buf, im.src = fp32_ctx;
+    else at_.out = fp32_ctx;
+  };
   GDR_CHECK_ARG(!bf16 || (dm.d_model % 8 == 0 && dm.d_ff % 8 == 0 && (dm.num_heads * dm.d_kv) % 8 == 0 && w->adaptor_ff % 8 == 0),
                 "generate(bf16): dims must be multiples of 8");
   const int d = dm.d_model, H = dm.num_heads, dk = dm.d_kv, inner = H * dk;
@@ -1170,7 +1226,8 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
         float* slot = cache + s * aslab;
         GDR_TRY(LIN2(xa, d, al.in_w, d, slot, 3 * d, rows_s, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0));
         AttnArgs at{};
-        at.q = slot, at.k = cache + d, at.v = cache + 2 * d, at.out = ctx2;
+        at.q = slot, at.k = cache + d, at.v = cache + 2 * d;
+        ctx_to(at, c16b, ctx2);
         at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
         at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
         at.B = rows_s, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
@@ -1180,10 +1237,17 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
         at.kv_rows = bb.kv_rows, at.kv_group = 1;
         GDR_TRY(launch_attention(at, as));
         // tmp = norm2(norm1(out_proj(ctx) + xa) + cross_const); xa = norm3(lin2(relu(lin1(tmp))) + tmp)
-        GDR_TRY(LIN2N(ctx2, d, al.out_w, d, tmp, d, rows_s, nullptr, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d, ln2(al, tmp)));
-        GDR_TRY(LIN2(tmp, d, al.lin1_w, d, ff2, aff, rows_s, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
-        GDR_TRY(LIN2N(ff2, aff, al.lin2_w, aff, xa, d, rows_s, nullptr, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d,
-                      ln(al.ln3_w, al.ln3_b, xa)));
+        GDR_TRY(dec_linear_norm(bf16, abf2, ctx2, d, al.out_w, d, tmp, d, rows_s, nullptr, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d,
+                                skw2, as, ln2(al, tmp), &sk2, &img2, &c16b));
+        int r16 = bf16 ? dec_linear_out16(abf2, tmp, d, al.lin1_w, d, ff2, aff, rows_s, nullptr, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, as,
+                                          &img2, &f16b) : 1;
+        if (r16 < 0) return r16;
+        if (r16 == 1) {
+          f16b.src = nullptr;
+          GDR_TRY(LIN2(tmp, d, al.lin1_w, d, ff2, aff, rows_s, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
+        }
+        GDR_TRY(dec_linear_norm(bf16, abf2, ff2, aff, al.lin2_w, aff, xa, d, rows_s, nullptr, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp,
+                                d, skw2, as, ln(al.ln3_w, al.ln3_b, xa), &sk2, &img2, &f16b));
         return GDR_OK;
     };
     // prefix-table mode, steps at which every possible prefix is a table node (step 0: the root; deeper while the trie's
@@ -1216,7 +1280,8 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
                            3 * d / 4, slot);
         GDR_CHECK_LAUNCH("scatter_slot_kernel");
         AttnArgs at{};
-        at.q = qkv_c, at.k = cache + d, at.v = cache + 2 * d, at.out = ctx2;
+        at.q = qkv_c, at.k = cache + d, at.v = cache + 2 * d;
+        ctx_to(at, c16b, ctx2);
         at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
         at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
         at.B = rows_s, at.H = aH, at.dk = ahd, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s;
@@ -1225,10 +1290,17 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
         at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 1;
         at.kv_rows = bb.kv_rows_c, at.kv_group = 1, at.b_count_dev = nm;
         GDR_TRY(launch_attention(at, as));
-        GDR_TRY(LIN2N(ctx2, d, al.out_w, d, tmp, d, rows_s, nm, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d, ln2(al, tmp)));
-        GDR_TRY(LIN2D(tmp, d, al.lin1_w, d, ff2, aff, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
-        GDR_TRY(LIN2N(ff2, aff, al.lin2_w, aff, xa, d, rows_s, nm, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d,
-                      ln(al.ln3_w, al.ln3_b, xa)));
+        GDR_TRY(dec_linear_norm(bf16, abf2, ctx2, d, al.out_w, d, tmp, d, rows_s, nm, d, d, GDR_EPI_BIAS_RESIDUAL, al.out_b, xa, d, skw2,
+                                as, ln2(al, tmp), &sk2, &img2, &c16b));
+        int r16 = bf16 ? dec_linear_out16(abf2, tmp, d, al.lin1_w, d, ff2, aff, rows_s, nm, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, as, &img2,
+                                          &f16b) : 1;
+        if (r16 < 0) return r16;
+        if (r16 == 1) {
+          f16b.src = nullptr;
+          GDR_TRY(LIN2D(tmp, d, al.lin1_w, d, ff2, aff, aff, d, GDR_EPI_BIAS_RELU, al.lin1_b, nullptr, 0));
+        }
+        GDR_TRY(dec_linear_norm(bf16, abf2, ff2, aff, al.lin2_w, aff, xa, d, rows_s, nm, d, aff, GDR_EPI_BIAS_RESIDUAL, al.lin2_b, tmp, d,
+                                skw2, as, ln(al.ln3_w, al.ln3_b, xa), &sk2, &img2, &f16b));
         return GDR_OK;
     };
     // ---------------- T5 decoder stack (modeling_t5.py:498-584, 685-821)
@@ -1240,7 +1312,8 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       // (the first block's norm rides on the embedding launch: embed_rmsnorm_kernel)
       GDR_TRY(LIN(nx, d, ly.wqkv, d, slot, 3 * inner, rows_s, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
       AttnArgs at{};
-      at.q = slot, at.k = cache + inner, at.v = cache + 2 * inner, at.out = ctx;
+      at.q = slot, at.k = cache + inner, at.v = cache + 2 * inner;
+      ctx_to(at, c16a, ctx);
       at.ldq = at.ldk = at.ldv = 3 * inner, at.ldo = inner;
       at.q_bstride = 1, at.k_bstride = 0, at.o_bstride = 1;
       at.B = rows_s, at.H = H, at.dk = dk, at.Lq = 1, at.Lk = s + 1, at.q_pos0 = s, at.scale = 1.0f;
@@ -1248,7 +1321,8 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       at.key_mask = nullptr, at.mask_bstride = 0, at.causal = 1, at.causal_neg_inf = 0;
       at.kv_rows = bb.kv_rows, at.kv_group = 1;
       GDR_TRY(launch_attention(at, stream));
-      GDR_TRY(LINN(ctx, inner, ly.wo, inner, xd, d, rows_s, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, rms(ly.ln_cross, nx)));
+      GDR_TRY(dec_linear_norm(bf16, abf, ctx, inner, ly.wo, inner, xd, d, rows_s, nullptr, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, skw,
+                              stream, rms(ly.ln_cross, nx), &sk1, &img1, &c16a));
       // cross attention over the encoder states of the row's query
       // the q projection's split-K slabs go to the attention kernel un-reduced (it sums them while it stages the beam rows_s'
       // queries): one dependent launch less per layer and step
@@ -1266,7 +1340,8 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       const float* ckv = crosskv + l * ckv_layer;
       // the R beam rows_s of a query are consecutive and share its K/V: one workgroup per (query, head) stages K/V
       // once and serves all R rows_s (they all sit at decoder position s)
-      ca.q = qc, ca.k = ckv, ca.v = ckv + inner, ca.out = ctx;
+      ca.q = qc, ca.k = ckv, ca.v = ckv + inner;
+      ctx_to(ca, c16a, ctx);
       ca.ldq = inner, ca.ldk = ca.ldv = 2 * inner, ca.ldo = inner;
       ca.q_bstride = R_s, ca.k_bstride = L, ca.o_bstride = R_s;
       ca.B = B, ca.H = H, ca.dk = dk, ca.Lq = R_s, ca.Lk = L, ca.q_pos0 = s, ca.scale = 1.0f, ca.q_same_pos = 1;
@@ -1279,11 +1354,18 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
         return GDR_EHIP;
       }
       GDR_TRY(launch_attention(ca, stream));
-      GDR_TRY(LINN(ctx, inner, ly.wo_c, inner, xd, d, rows_s, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, rms(ly.ln_ff, nx)));
-      GDR_TRY(LIN(nx, d, ly.wi, d, ff, dm.d_ff, rows_s, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0));
+      GDR_TRY(dec_linear_norm(bf16, abf, ctx, inner, ly.wo_c, inner, xd, d, rows_s, nullptr, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, skw,
+                              stream, rms(ly.ln_ff, nx), &sk1, &img1, &c16a));
+      int r16 = bf16 ? dec_linear_out16(abf, nx, d, ly.wi, d, ff, dm.d_ff, rows_s, nullptr, dm.d_ff, d, GDR_EPI_RELU, nullptr, stream, &img1,
+                                        &f16a) : 1;
+      if (r16 < 0) return r16;
+      if (r16 == 1) {
+          f16a.src = nullptr;
+          GDR_TRY(LIN(nx, d, ly.wi, d, ff, dm.d_ff, rows_s, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0));
+        }
       const bool last = l + 1 == dm.num_layers;  // the norm behind the block: the next block's first, or final_layer_norm
-      GDR_TRY(LINN(ff, dm.d_ff, ly.wo_ff, dm.d_ff, xd, d, rows_s, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, xd, d,
-                   rms(last ? w->final_ln : w->layers[l + 1].ln_self, last ? hl : nx)));
+      GDR_TRY(dec_linear_norm(bf16, abf, ff, dm.d_ff, ly.wo_ff, dm.d_ff, xd, d, rows_s, nullptr, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, xd, d,
+                              skw, stream, rms(last ? w->final_ln : w->layers[l + 1].ln_self, last ? hl : nx), &sk1, &img1, &f16a));
       return GDR_OK;
     };
     // The two chains are enqueued layer by layer in turn: a host thread that first enqueued the whole adaptor chain left
@@ -1334,6 +1416,13 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
 }  // namespace gdr
 
 extern "C" int64_t gdr_t5_generate_early_exits(void) { return gdr::g_early_exits.load(); }
+
+extern "C" int gdr_t5_generate_last_done_step(void) {
+  int32_t* words = gdr::done_words();
+  const int32_t e = gdr::g_done_epoch.load();
+  if (!words || e == 0) return 0;
+  return __atomic_load_n(words + (e & 63), __ATOMIC_RELAXED) == e ? __atomic_load_n(words + 64 + (e & 63), __ATOMIC_RELAXED) : 0;
+}
 
 extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B,
                                int L, int num_beams, int max_length, double length_penalty,

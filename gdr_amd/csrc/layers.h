@@ -18,7 +18,7 @@ struct AttnArgs {
   const float* v;
   float* out;      // row (b*o_bstride + i), head h at column h*dk
   void* out_bf16;  // when non-null the context is written here as bf16 (same indexing, ldo in elements) instead of `out`:
-                   // it only feeds the next linear of the bf16 precision mode.  Not supported by the Lq = 1 decode form.
+                   // it only feeds the next linear of the bf16 precision mode (every kernel form).
   int64_t ldq, ldk, ldv, ldo;          // row strides in floats
   int64_t q_bstride, k_bstride, o_bstride;  // rows per batch entry
   int B, H, dk, Lq, Lk;

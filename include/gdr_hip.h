@@ -466,6 +466,11 @@ int gdr_t5_generate_bf16(const GdrT5DecoderWeights* w, const float* enc_hidden, 
  * weights never finish early; a trained model does after the docid's length + 1 steps, a trie-constrained call always does.
  * Returns how many generate calls of this process left their loop on the host side (monitoring / tests). */
 int64_t gdr_t5_generate_early_exits(void);
+/* The device half of the same exit, observable: the decode step (cur_len, 1-based) at which the LAST query of the most recent
+ * gdr_t5_generate call of this process became done, written by the beam bookkeeping kernel into host-mapped memory; 0 when
+ * that call ran to max_length without every query finishing (or ran with the per-step trace).  Read it after the call's
+ * stream has been synchronised.  Deterministic (unlike the host-side counter above, which races with the GPU by design). */
+int gdr_t5_generate_last_done_step(void);
 int gdr_t5_prefix_table_build_bf16(const GdrT5DecoderWeights* w, int n_levels, const int32_t* level_off,
                                    const int64_t* node_tok, const int32_t* node_anc, float* kv, float* W, void* workspace,
                                    size_t workspace_bytes, void* stream);

@@ -122,6 +122,49 @@ def test_generate_tiny_vs_oracle(dev, B, R, L):
     assert np.array_equal(dec.cpu().numpy(), rd.numpy())
 
 
+def test_generate_with_wide_heads_takes_the_generic_decode_attention(dev):
+    """d_kv = 132 > 128: the Lq = 1 attention of a decode step is outside the row-group kernel's range and must fall through
+    to the generic attention kernel (T5Attention semantics, modeling_t5.py:316-421) instead of being refused."""
+    from gdr_amd.modeling import GDRModel
+    from oracle import beam_ref
+    cfg = GDRConfig.tiny(d_kv=132, num_heads=2)
+    sd = synth.make_state_dict(cfg, seed=17)
+    ids, mask = synth.make_tokens(3, L=7, vocab_hi=cfg.vocab_size, seed=4, min_len=2)
+    (rd, rs), _ = beam_ref.generate(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask), 4, restricted_head=True)
+    (dec, sc), _ = GDRModel(cfg, sd, dev).generate(torch.from_numpy(ids).to(dev), attention_mask=torch.from_numpy(mask).to(dev),
+                                                   max_length=cfg.max_output_length, num_beams=4, length_penalty=0.8,
+                                                   num_return_sequences=4, output_scores=True)
+    np.testing.assert_allclose(np.array(sc), np.array(rs), rtol=1e-4, atol=1e-4)
+    assert np.array_equal(dec.cpu().numpy(), rd.numpy())
+
+
+@pytest.mark.parametrize("B,R,L", [(128, 3, 40), (130, 20, 23)])
+def test_generate_many_queries_takes_the_mfma_cross_attention_vs_oracle(dev, B, R, L):
+    """From 1 536 (query, head) pairs on, the beam rows' cross-attention over the encoder states (T5Attention,
+    modeling_t5.py:316-421) runs as attention_cross_mfma16_kernel — S^T = K.Q^T and P.V on MFMA, a wave per 16 beam rows —
+    instead of the generic lane-per-key kernel: same scores, bias, mask and softmax, another summation order.  t5-base widths
+    (12 heads, d_kv = 64) with two encoder / decoder blocks so that the CPU oracle stays cheap; ragged lengths (masked keys),
+    one and two 16-row tiles, key counts that are not multiples of 16."""
+    from gdr_amd.modeling import GDRModel
+    from oracle import beam_ref
+    cfg = GDRConfig.base()
+    cfg.num_layers, cfg.num_decoder_layers, cfg.adaptor_layer_num = 2, 2, 1
+    assert B * cfg.num_heads >= 1536 and cfg.d_kv == 64
+    sd = synth.make_state_dict(cfg, seed=31)
+    ids, mask = synth.make_tokens(B, L=L, seed=B + R, min_len=3)
+    (rd, rs), _ = beam_ref.generate(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask), R, max_length=6, restricted_head=True)
+    (dec, sc), _ = GDRModel(cfg, sd, dev).generate(torch.from_numpy(ids).to(dev), attention_mask=torch.from_numpy(mask).to(dev),
+                                                   max_length=6, num_beams=R, length_penalty=0.8, num_return_sequences=R,
+                                                   output_scores=True)
+    sc, rs = np.array(sc).reshape(B, R), np.array(rs).reshape(B, R)
+    np.testing.assert_allclose(sc, rs, rtol=1e-4, atol=1e-4)
+    got, ref = dec.cpu().numpy(), rd.numpy()
+    W = min(got.shape[1], ref.shape[1])
+    for b in range(B):
+        ranked_lists_match([tuple(r[:W]) for r in ref[b * R:(b + 1) * R].tolist()], rs[b],
+                           [tuple(r[:W]) for r in got[b * R:(b + 1) * R].tolist()], 1e-4)
+
+
 def test_two_stage_retrieval_vs_oracle(dev):
     """validation_step_i end to end on a tiny model: decode -> id_mapping -> rerank, vs the oracle composition of
     the same stages.  The cluster index is built from the strings the (oracle) decode produces — random weights

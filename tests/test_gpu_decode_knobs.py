@@ -44,7 +44,9 @@ for rep in range(3):
                                        num_return_sequences=10, output_scores=True)
 out["trie_5x10"] = {"ids": dec.cpu().tolist(), "scores": [float(s) for s in scores]}
 from gdr_amd import _ffi
+torch.cuda.synchronize()
 out["early_exits"] = int(_ffi.lib().gdr_t5_generate_early_exits())
+out["last_done_step"] = int(_ffi.lib().gdr_t5_generate_last_done_step())     # of the trie-constrained call just above
 print("RESULT " + json.dumps(out))
 """
 
@@ -59,21 +61,24 @@ def _run(**env):
 
 def test_decode_scheduling_switches_do_not_change_generate():
     base = _run()
-    n_exits = base.pop("early_exits")
+    n_exits, done_step = base.pop("early_exits"), base.pop("last_done_step")
+    # the device half of `if all(done): break` is deterministic: beams constrained to the 30 000-doc corpus' trie (docids of
+    # depth 3) are all finished — EOS forced — by step depth + 2, and the kernel that sees the last query finish records it
+    assert 0 < done_step <= 3 + 2, done_step
     exact = _run(GDR_DECODE_SLAB_Q="0")
-    exact.pop("early_exits")
+    exact.pop("early_exits"), exact.pop("last_done_step")
     assert exact == base, "slab-sourced cross-attention q must be bit-identical to the reduction launch"
     # GDR_DECODE_EARLY_EXIT=0 runs every step although all queries are done (generation_utils.py:836-838 breaks there): done
     # queries only pad, so nothing may change — and the default run must actually have skipped (device side) or left early
     full = _run(GDR_DECODE_EARLY_EXIT="0")
-    assert full.pop("early_exits") == 0
+    assert full.pop("early_exits") == 0 and full.pop("last_done_step") == 0
     assert full == base, "leaving the step loop when every query is done must not change any output"
     assert n_exits >= 0
     # GDR_DECODE_DEDUP0=0 runs step 0 on all B*R identical beam rows instead of one row per query: the same numbers from
     # launches of another shape (other split-K factors), i.e. fp32 summation order only
     for env in (dict(GDR_DECODE_FUSE_NORM="0"), dict(GDR_DECODE_DEDUP0="0")):
         other = _run(**env)
-        other.pop("early_exits")
+        other.pop("early_exits"), other.pop("last_done_step")
         for key in base:
             a, b = base[key], other[key]
             sa, sb = np.asarray(a["scores"]), np.asarray(b["scores"])

@@ -225,3 +225,46 @@ def test_l2_normalize_vs_torch(dev):
     got = ops.l2_normalize(x.to(dev)).cpu()
     torch.testing.assert_close(got, torch.nn.functional.normalize(x, dim=-1), rtol=1e-6, atol=1e-7)
     assert torch.equal(got[5], torch.zeros(768))
+
+
+def test_one_oversized_cluster_does_not_break_the_step(dev):
+    """The device candidate blocks are `num_beams x largest cluster of the corpus` wide.  One outlier cluster (here 1 000 docs
+    at 10 beams: 10 000 > the rerank's 8 192-candidate cap) must not make every step fail when the clusters actually decoded
+    are small (the host CSR path sized its bound from the data): ops.block_max_cand then reads the real per-query counts — and
+    a query that REALLY decodes more than 8 192 candidates is refused with a clear error, as before."""
+    from gdr_amd import _ffi, codec, ops
+    from oracle import retrieval_ref
+    V, ml, d, R, B = 30, 10, 64, 10, 4
+    sizes = np.full(300, 12, np.int64)
+    sizes[7] = 1000                                            # the outlier
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    N = int(offsets[-1])
+    names = ["-".join(str(x) for x in synth.cluster_digits(c, 2, V)) for c in range(300)]
+    index = codec.ClusterIndex(names, offsets, np.arange(N, dtype=np.int32))
+    rng = np.random.Generator(np.random.PCG64(3))
+    picks = [int(x) for x in rng.choice([c for c in range(300) if c != 7], size=B * R)]
+    rows = _rows_for(names, picks, V, ml, rng)
+    D = synth.make_corpus(N, d, seed=3)
+    Q, _ = synth.make_queries(D, B, seed=4)
+    Q *= 0.3
+    beam = np.sort(rng.standard_normal((B, R)).astype(np.float32), axis=1)[:, ::-1].copy()
+    dci = ops.DeviceClusterIndex(index, dev, V)
+    Qd, Dd, bd = torch.from_numpy(Q).to(dev), torch.from_numpy(D).to(dev), torch.from_numpy(beam).to(dev)
+    cl, offs, ids, stride = dci.candidates(torch.from_numpy(rows).to(dev), B, R)
+    assert stride == R * 1000 > ops.RERANK_MAX_CAND
+    mc = ops.block_max_cand(offs, R, stride)
+    assert mc == R * 12
+    v, i = ops.rerank_topk(Qd, Dd, offs, ids, bd, [0, 1.5], R, max_cand=mc, cand_stride=stride)
+    dec = codec.dec_2d(codec.decode_token(rows, kary=V, output_vocab_size=V), R)
+    mem = [[m for s_ in row for m in index[s_]] for row in dec]
+    num = [[len(index[s_]) for s_ in row] for row in dec]
+    ref = retrieval_ref.rerank(torch.from_numpy(Q), torch.from_numpy(D), mem, num, beam.tolist(), [0, 1.5], R)
+    for b in range(B):
+        for a in range(2):
+            np.testing.assert_allclose(v[b, a].cpu().numpy(), ref[b][a][0].numpy(), rtol=TOL, atol=TOL)
+            ranked_lists_match(ref[b][a][1].tolist(), ref[b][a][0].numpy(), i[b, a].cpu().tolist(), TOL)
+    # a query that really decodes the outlier ten times: 10 000 candidates
+    rows2 = _rows_for(names, [7] * (B * R), V, ml, rng)
+    _c, offs2, _i, _s = dci.candidates(torch.from_numpy(rows2).to(dev), B, R)
+    with pytest.raises(_ffi.GdrError, match="at most 8192"):
+        ops.block_max_cand(offs2, R, stride)

@@ -102,6 +102,9 @@ for fn in (l.gdr_t5_generate, l.gdr_t5_generate_bf16):
     assert E(fn(C.byref(dw), FAKE, FAKE, 4, 16, 10, 10, 0.8, 10, None, None, FAKE, FAKE, FAKE, None, None, FAKE, gneed, None))    # EHIP
 trie = _ffi.GdrTrie(FAKE.value, FAKE.value, 5, 7)                                    # V mismatch
 assert E(l.gdr_t5_generate(C.byref(dw), FAKE, FAKE, 4, 16, 10, 10, 0.8, 10, C.byref(trie), None, FAKE, FAKE, FAKE, None, None, FAKE, gneed, None))
+ptab = _ffi.GdrPrefixTable(FAKE.value, 40, 30, 31, FAKE.value, FAKE.value, 3)     # 3 complete levels need 1 + 30 + 900 nodes
+assert E(l.gdr_t5_generate(C.byref(dw), FAKE, FAKE, 4, 16, 10, 10, 0.8, 10, None, C.byref(ptab), FAKE, FAKE, FAKE, None, None, FAKE, gneed, None))
+assert b"complete levels" in l.gdr_last_error()
 lo = (C.c_int32 * 3)(0, 1, 4)
 tneed = l.gdr_t5_prefix_table_workspace_bytes(C.byref(dw), 3)
 assert E(l.gdr_t5_prefix_table_build(C.byref(dw), 2, lo, FAKE, FAKE, FAKE, FAKE, FAKE, 8, None))
