@@ -522,6 +522,7 @@ def two_stage_main(a):
         outs = list(retr.validation_steps(iter([batch] * n), depth=max(1, a.depth)))
         return outs[-1] if outs else None
 
+    run(max(1, a.depth))           # set-up, not warm-up: every stream of the pipeline allocates its scratch (GBs of hipMalloc) once
     if a.warmup:
         run(a.warmup)
     fence(dist)

@@ -116,15 +116,20 @@ traffic["source"] = f"profiles/{tag}_bench_pmc_hbm.md"
 json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
 
 # ---------------------------------------------------------------------------------------------- MFMA utilisation
+NORM = ("Per launch averages.  `MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x busy cycles), busy cycles = SQ_BUSY_CYCLES / 32 "
+        "(the counter sums the 32 shader engines' sequencers; it only advances while waves are resident).  Through round 3 the "
+        "denominator was duration x GRBM_GUI_ACTIVE / 8 / duration; GRBM_GUI_ACTIVE also counts cycles OUTSIDE a short kernel's own "
+        "span, which read as impossible clocks (2.9-5.2 GHz) for kernels under ~50 us and under-stated their MFMA share — the last "
+        "column keeps those old figures for comparison.  `busy cycles / duration` must stay below the chip's 2.4 GHz; for launches "
+        "of >= 300 us the two normalisations agree within ~5 % (the SQ is idle only in the ramp and the tail).  Durations are those "
+        "of the profiled pass.\n\n")
 m, c = counters("pmc_mfma/*/*counter_collection.csv"), counters("pmc_clk/*/*counter_collection.csv")
 with open(f"profiles/{tag}_mfma_busy.md", "w") as o:
     o.write(f"# {tag} — MFMA utilisation of the GEMM kernels in the bench (rocprofv3 --pmc)\n\n"
             "Two counter passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-recall --no-stages` (ragged encoder):\n\n" + CMD +
-            "\nPer launch averages.  `clock` = GRBM_GUI_ACTIVE / 8 XCDs / duration (MI355X_MICROARCH.md, DVFS give-back);\n"
-            "`MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock): the share of SIMD-cycles in which the matrix "
-            "pipe is executing.  Durations are those of the profiled pass (profiled runs clock 2-3 % lower than un-profiled).\n\n"
-            "| kernel | grid | launches | avg us | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES | GRBM_GUI_ACTIVE | clock GHz | MFMA busy |\n"
-            "|---|---|---|---|---|---|---|---|---|\n")
+            "\n" + NORM +
+            "| kernel | grid | launches | avg us | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES | GRBM_GUI_ACTIVE | busy cycles / duration (GHz) | MFMA busy | (old: GRBM clock, MFMA busy) |\n"
+            "|---|---|---|---|---|---|---|---|---|---|\n")
     for k in sorted(m, key=lambda k: -sum(m[k]["dur_ns"])):
         if not any(s in k[0] for s in ("gemm_nt", "attention_mfma")):
             continue
@@ -133,9 +138,11 @@ with open(f"profiles/{tag}_mfma_busy.md", "w") as o:
         dur_c = avg(c[k]["dur_ns"]) if k in c else 0.0
         clk = gui / 8 / dur_c if dur_c else 0.0                      # cycles per ns = GHz
         busy = avg(m[k]["SQ_VALU_MFMA_BUSY_CYCLES"])
-        frac = busy / (1024 * dur * clk) if clk else 0.0
+        frac_old = busy / (1024 * dur * clk) if clk else 0.0
+        sqc = avg(m[k]["SQ_BUSY_CYCLES"]) / 32.0                       # busy cycles of one shader engine (32 SQ instances are summed)
+        frac = busy / (1024 * sqc) if sqc else 0.0
         o.write(f"| `{short(k[0])[:48]}` | {k[1]} | {len(m[k]['dur_ns'])} | {dur / 1e3:.1f} | {busy:.3e} | "
-                f"{avg(m[k]['SQ_BUSY_CYCLES']):.3e} | {gui:.3e} | {clk:.2f} | {frac:.3f} |\n")
+                f"{avg(m[k]['SQ_BUSY_CYCLES']):.3e} | {gui:.3e} | {sqc / dur:.2f} | {frac:.3f} | {clk:.2f}, {frac_old:.3f} |\n")
     o.write("\nReading: for the fp32 GEMMs MFMA busy x clock / 2.4 GHz is the fraction of the 157.3 TFLOP/s peak that the issue "
             "stream could deliver; what bench.py reports as `roofline.frac` is lower by the tile-edge waste (rows past the live "
             "count are computed and discarded) and by the epilogue / prologue phases in which no MFMA is issued.\n")
@@ -149,7 +156,8 @@ if m:
                 "averages over all four calls; `grid` = threads.  The 64x64-tile split-K kernel of the decode linears is listed by grid: "
                 "122 880 threads = 480 workgroups (the N = 768 projections split 4 ways, wi un-split, wo split 4 ways), 92 160 = 360 (qkv / "
                 "in_proj), 163 840 = 640 (adaptor lin1).\n\n"
-                "| kernel | grid | launches | avg us | SQ_VALU_MFMA_BUSY_CYCLES | clock GHz | MFMA busy |\n|---|---|---|---|---|---|---|\n".replace("{tag}", tag))
+                "\n\n".replace("{tag}", tag) + NORM +
+                "| kernel | grid | launches | avg us | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES | busy cycles / duration (GHz) | MFMA busy | (old: GRBM clock, MFMA busy) |\n|---|---|---|---|---|---|---|---|---|\n")
         for k in sorted(m, key=lambda k: -sum(m[k]["dur_ns"])):
             if "gemm_nt" not in k[0]:
                 continue
@@ -158,8 +166,11 @@ if m:
             dur_c = avg(c[k]["dur_ns"]) if k in c else 0.0
             clk = gui / 8 / dur_c if dur_c else 0.0
             busy = avg(m[k]["SQ_VALU_MFMA_BUSY_CYCLES"])
-            frac = busy / (1024 * dur * clk) if clk else 0.0
-            o.write(f"| `{short(k[0])[:48]}` | {k[1]} | {len(m[k]['dur_ns'])} | {dur / 1e3:.1f} | {busy:.3e} | {clk:.2f} | {frac:.3f} |\n")
+            frac_old = busy / (1024 * dur * clk) if clk else 0.0
+            sqc = avg(m[k]["SQ_BUSY_CYCLES"]) / 32.0
+            frac = busy / (1024 * sqc) if sqc else 0.0
+            o.write(f"| `{short(k[0])[:48]}` | {k[1]} | {len(m[k]['dur_ns'])} | {dur / 1e3:.1f} | {busy:.3e} | {avg(m[k]['SQ_BUSY_CYCLES']):.3e} | "
+                    f"{sqc / dur:.2f} | {frac:.3f} | {clk:.2f}, {frac_old:.3f} |\n")
     print(open(f"profiles/{tag}_generate_mfma_busy.md").read())
 print(open(f"profiles/{tag}_mfma_busy.md").read())
 print(open(f"profiles/{tag}_bench_pmc_hbm.md").read()[-3000:])
