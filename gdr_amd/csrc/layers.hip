@@ -872,15 +872,13 @@ static int launch_attention_cross_mfma16(const AttnArgs& a, hipStream_t stream) 
   return GDR_OK;
 }
 // When the beam-row form above serves a call: the shared-K/V decode shape (all Lq rows at one position, d_kv = 64, finished q
-// rows, 16-byte rows), and enough (query, head) pairs that the launch is throughput-bound — below that the generic kernel's
-// four-waves-per-row-group chain is the shorter one (64 queries x 10 beams: 14.6 us against 22 us, measured in round 3).
+// rows — not split-K slabs —, 16-byte rows).  Measured against the generic kernel inside generate() (tools/exp_cross_attn.py,
+// profiles/r04_cross_attention_ab.txt): never slower — 768 (query, head) pairs x 30 beam rows 29.7 -> 28.2 ms per call, 6 144
+// pairs x 10 rows 70.2 -> 67.0 ms, bf16 mode 6 144 pairs x 30 rows 56.9 -> 51.2 ms — and equal within noise where few pairs
+// make the launch latency-bound (12 pairs x 100 rows), so there is no size threshold.
 static bool cross_mfma_wanted(const AttnArgs& a) {
-  static const int min_pairs = [] {
-    const char* e = getenv("GDR_ATTN_CROSS_MFMA");  // A/B knob: (query, head) pairs from which the MFMA form runs; 0 = never
-    return e ? atoi(e) : 1536;
-  }();
-  return min_pairs > 0 && a.q_same_pos && a.Lq > 1 && a.Lq <= 128 && a.dk == 64 && !a.q_part && !a.kv_rows && !a.seq_off &&
-         !a.qkv_bf16 && a.ldo % 4 == 0 && a.ldq % 4 == 0 && (int64_t)a.B * a.H >= min_pairs;
+  return a.q_same_pos && a.Lq > 1 && a.Lq <= 128 && a.dk == 64 && !a.q_part && !a.kv_rows && !a.seq_off && !a.qkv_bf16 &&
+         a.ldo % 4 == 0 && a.ldq % 4 == 0;
 }
 
 // ------------------------------------------------------------------------------------------ attention, Lq == 1

@@ -138,18 +138,19 @@ def test_generate_with_wide_heads_takes_the_generic_decode_attention(dev):
     assert np.array_equal(dec.cpu().numpy(), rd.numpy())
 
 
-@pytest.mark.parametrize("B,R,L", [(128, 3, 40), (130, 20, 23)])
+@pytest.mark.parametrize("B,R,L", [(520, 3, 40), (130, 20, 23)])
 def test_generate_many_queries_takes_the_mfma_cross_attention_vs_oracle(dev, B, R, L):
-    """From 1 536 (query, head) pairs on, the beam rows' cross-attention over the encoder states (T5Attention,
-    modeling_t5.py:316-421) runs as attention_cross_mfma16_kernel — S^T = K.Q^T and P.V on MFMA, a wave per 16 beam rows —
-    instead of the generic lane-per-key kernel: same scores, bias, mask and softmax, another summation order.  t5-base widths
+    """With finished q rows (the bf16 mode, or more than 1 536 beam rows in fp32: below that the attention sums the q
+    projection's split-K slabs itself in the generic kernel) the beam rows' cross-attention over the encoder states
+    (T5Attention, modeling_t5.py:316-421) runs as attention_cross_mfma16_kernel — S^T = K.Q^T and P.V on MFMA, a wave per 16
+    beam rows: same scores, bias, mask and softmax as the generic lane-per-key kernel, another summation order.  t5-base widths
     (12 heads, d_kv = 64) with two encoder / decoder blocks so that the CPU oracle stays cheap; ragged lengths (masked keys),
     one and two 16-row tiles, key counts that are not multiples of 16."""
     from gdr_amd.modeling import GDRModel
     from oracle import beam_ref
     cfg = GDRConfig.base()
     cfg.num_layers, cfg.num_decoder_layers, cfg.adaptor_layer_num = 2, 2, 1
-    assert B * cfg.num_heads >= 1536 and cfg.d_kv == 64
+    assert cfg.d_kv == 64
     sd = synth.make_state_dict(cfg, seed=31)
     ids, mask = synth.make_tokens(B, L=L, seed=B + R, min_len=3)
     (rd, rs), _ = beam_ref.generate(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask), R, max_length=6, restricted_head=True)
