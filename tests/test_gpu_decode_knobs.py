@@ -1,5 +1,5 @@
 """Scheduling choices of the decode path must not change what generate() returns: the cross-attention that sums the q
-projection's split-K slabs itself (GDR_DECODE_SLAB_Q) is bit-identical to the separate reduction launch; the fused
+projection's split-K slabs itself (GDR_DECODE_SLAB_Q; with finished q rows the MFMA beam-row form runs), the fused
 reduce + residual + norm launch (GDR_DECODE_FUSE_NORM) and step 0 on one row per query instead of all B*R identical beam rows
 (GDR_DECODE_DEDUP0) may differ in fp32 summation order only; leaving the step loop once every query is done
 (GDR_DECODE_EARLY_EXIT, generation_utils.py:836-838) changes nothing at all.  Each switch selects code that also runs by default for other
@@ -65,9 +65,6 @@ def test_decode_scheduling_switches_do_not_change_generate():
     # the device half of `if all(done): break` is deterministic: beams constrained to the 30 000-doc corpus' trie (docids of
     # depth 3) are all finished — EOS forced — by step depth + 2, and the kernel that sees the last query finish records it
     assert 0 < done_step <= 3 + 2, done_step
-    exact = _run(GDR_DECODE_SLAB_Q="0")
-    exact.pop("early_exits"), exact.pop("last_done_step")
-    assert exact == base, "slab-sourced cross-attention q must be bit-identical to the reduction launch"
     # GDR_DECODE_EARLY_EXIT=0 runs every step although all queries are done (generation_utils.py:836-838 breaks there): done
     # queries only pad, so nothing may change — and the default run must actually have skipped (device side) or left early
     full = _run(GDR_DECODE_EARLY_EXIT="0")
@@ -76,7 +73,10 @@ def test_decode_scheduling_switches_do_not_change_generate():
     assert n_exits >= 0
     # GDR_DECODE_DEDUP0=0 runs step 0 on all B*R identical beam rows instead of one row per query: the same numbers from
     # launches of another shape (other split-K factors), i.e. fp32 summation order only
-    for env in (dict(GDR_DECODE_FUSE_NORM="0"), dict(GDR_DECODE_DEDUP0="0")):
+    # GDR_DECODE_SLAB_Q=0 reduces the cross-attention q projection in a launch of its own; the attention then gets finished q
+    # rows and (round 4) takes the MFMA beam-row form instead of the generic kernel that sums the slabs: same scores, another
+    # summation order — like the two switches after it
+    for env in (dict(GDR_DECODE_SLAB_Q="0"), dict(GDR_DECODE_FUSE_NORM="0"), dict(GDR_DECODE_DEDUP0="0")):
         other = _run(**env)
         other.pop("early_exits"), other.pop("last_done_step")
         for key in base:
