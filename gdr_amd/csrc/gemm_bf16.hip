@@ -36,11 +36,17 @@ struct Bf16GemmArgs {
 
 __device__ __forceinline__ float gelu_erf_b(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int EPI>  // 0 linear, 1 similarity sample, 2 similarity filter
+// BM = rows of A per tile: 128, or 64 for the linears of a few thousand rows (the decode legs of config C5: 1 920 beam rows x
+// N = 768 are 90 tiles of 128 x 128 on 256 CUs; 64-row tiles double the workgroups — the W operand is re-read twice as often,
+// which L2 absorbs at these sizes — and halve the accumulators, 32 x 64 per wave).  The similarity forms use 128.
+template <int EPI, int BM = 128>  // EPI: 0 linear, 1 similarity sample, 2 similarity filter
 __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16GemmArgs g) {
-  __shared__ __attribute__((aligned(1024))) char smem[2 * 128 * 128];  // As [128 rows][128 B], Bs likewise
+  static_assert(BM == 128 || (BM == 64 && EPI == 0), "64-row tiles serve the linear form only");
+  constexpr int MI = BM / 32;   // 16-row accumulator blocks per wave along M: 4 or 2
+  constexpr int AI = BM / 32;   // A staging instructions per wave (8 rows each): 4 or 2
+  __shared__ __attribute__((aligned(1024))) char smem[BM * 128 + 128 * 128];  // As [BM rows][128 B], Bs [128 rows][128 B]
   char* const As = smem;
-  char* const Bs = smem + 128 * 128;
+  char* const Bs = smem + BM * 128;
   unsigned bid = blockIdx.x;
   const int64_t Mv = (EPI == 0 && g.m_dev) ? *g.m_dev : g.M;
   {
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     // are spread evenly.
     unsigned nblk = gridDim.x;
     if (EPI == 0 && g.m_dev) {
-      const int64_t live = ((Mv + 127) / 128) * (int64_t)g.tiles_n;
+      const int64_t live = ((Mv + BM - 1) / BM) * (int64_t)g.tiles_n;
       if (live < (int64_t)nblk) {
         if ((int64_t)bid >= live) return;  // uniform
         nblk = (unsigned)live;
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
   int64_t m0, slot_base = 0;
   int64_t n0;
   if (EPI == 0) {
-    m0 = (int64_t)(bid / (unsigned)g.tiles_n) * 128;
+    m0 = (int64_t)(bid / (unsigned)g.tiles_n) * BM;
     n0 = (int64_t)(bid % (unsigned)g.tiles_n) * 128;
   } else {
     int64_t dt = bid / (unsigned)g.tiles_n;  // doc tile of this pass
@@ -85,31 +91,40 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
 
   // ---- staging map: instruction i of this wave covers tile rows (wave*4 + i)*8 .. +7; lane = (row_in, chunk') ----
   const int srow = lane >> 3, schunk = lane & 7;
-  const char* a_src[4];
+  const char* a_src[AI];
   const char* w_src[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (wave * 4 + i) * 8 + srow;
     const int chunk = schunk ^ ((row >> 1) & 7);
-    int64_t ra = m0 + row;
-    ra = ra < Mv ? ra : Mv - 1;  // rows past the edge are computed and discarded
     int64_t rw = n0 + row;
     rw = rw < g.Nrows ? rw : g.Nrows - 1;
-    a_src[i] = g.A + (ra * g.lda) * 2 + chunk * 16;
     w_src[i] = g.W + (rw * g.ldw) * 2 + chunk * 16;
   }
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = (wave * AI + i) * 8 + srow;
+    const int chunk = schunk ^ ((row >> 1) & 7);
+    int64_t ra = m0 + row;
+    ra = ra < Mv ? ra : Mv - 1;  // rows past the edge are computed and discarded
+    a_src[i] = g.A + (ra * g.lda) * 2 + chunk * 16;
+  }
   // ---- fragment reads: lane (r16, q4) reads 16 B = k 8*q4..+7 of a 32-k half; 4 row blocks of A, 4 of W ----
-  int a_off[4], b_off[4], a_sw[4], b_sw[4];
+  int a_off[MI], b_off[4], a_sw[MI], b_sw[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int ra = wm * 64 + i * 16 + r16, rb = wn * 64 + i * 16 + r16;
-    a_off[i] = ra * 128, a_sw[i] = (ra >> 1) & 7;
+    const int rb = wn * 64 + i * 16 + r16;
     b_off[i] = rb * 128, b_sw[i] = (rb >> 1) & 7;
   }
-
-  f32x4b acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i) {
+    const int ra = wm * (BM / 2) + i * 16 + r16;
+    a_off[i] = ra * 128, a_sw[i] = (ra >> 1) & 7;
+  }
+
+  f32x4b acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4b){0.f, 0.f, 0.f, 0.f};
 
@@ -118,22 +133,23 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     const int koff = kt * 128;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
-                                       (__attribute__((address_space(3))) void*)(As + (wave * 4 + i) * 1024), 16, 0, 0);
+      if (i < AI)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
+                                         (__attribute__((address_space(3))) void*)(As + (wave * AI + i) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + koff),
                                        (__attribute__((address_space(3))) void*)(Bs + (wave * 4 + i) * 1024), 16, 0, 0);
     }
     __syncthreads();  // emits vmcnt(0): the DMA writes are complete and visible
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      float4 fa[4], fb[4];
+      float4 fa[MI], fb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const float4*>(As + a_off[i] + (((kk * 4 + q4) ^ a_sw[i]) << 4));
+        if (i < MI) fa[i] = *reinterpret_cast<const float4*>(As + a_off[i] + (((kk * 4 + q4) ^ a_sw[i]) << 4));
         fb[i] = *reinterpret_cast<const float4*>(Bs + b_off[i] + (((kk * 4 + q4) ^ b_sw[i]) << 4));
       }
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, fb[ni]),
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
   // ---- similarity epilogues: lane&15 <-> query, registers <-> 4 consecutive docs ----
   if (EPI == 1) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
       const int64_t q = m0 + wm * 64 + mi * 16 + r16;
       if (q >= Mv) continue;
       float* cv = g.sim.cand_val + q * g.sim.cap + slot_base;
@@ -168,7 +184,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
   }
   if (EPI == 2) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
       const int64_t q = m0 + wm * 64 + mi * 16 + r16;
       const bool q_ok = q < Mv;
       const float thr = q_ok ? g.sim.thr[q] : INFINITY;
@@ -211,8 +227,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
   // panel of a packed batch) are simply skipped — a per-ROW test, so the valid rows of an edge panel keep the vector path
   const bool cols_vec = n0 + 128 <= g.N && (g.ldc & 3) == 0 && (!g.has_residual || (g.ldr & 3) == 0);
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int64_t m = m0 + wm * 64 + mi * 16 + r16;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int64_t m = m0 + wm * (BM / 2) + mi * 16 + r16;
     if (m >= Mv) continue;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -273,13 +289,20 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
   g.tiles_n = (N + 127) / 128;
   g.has_bias = has_bias, g.has_residual = has_residual, g.act = act, g.out_bf16 = out_bf16;
   g.m_dev = m_dev;
-  const int64_t blocks = ((M + 127) / 128) * g.tiles_n;
+  int64_t blocks = ((M + 127) / 128) * g.tiles_n;
   if (blocks <= 0) return 0;
   if (blocks > 0x7fffffffLL) {
     set_error("linear_bf16: grid too large");
     return GDR_EINVAL;
   }
-  hipLaunchKernelGGL(gemm_nt_bf16_glds_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  // fewer than ~2 tiles of 128 rows per CU: 64-row tiles (same k order per output element: bit-identical results)
+  if (blocks < 600) {
+    blocks = ((M + 63) / 64) * g.tiles_n;
+    hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 64>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+    GDR_CHECK_LAUNCH("gemm_nt_bf16_glds_kernel<64-row tiles>");
+    return 0;
+  }
+  hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 128>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
   GDR_CHECK_LAUNCH("gemm_nt_bf16_glds_kernel");
   return 0;
 }

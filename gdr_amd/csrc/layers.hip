@@ -721,6 +721,194 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
   }
 }
 
+// The same self-attention when q, k, v arrive as bf16 (the qkv linear of the bf16 precision mode emits them so, BASELINE config
+// C5) on v_mfma_f32_16x16x32_bf16 — 16x the fp32 MFMA rate: the kernel above spends about half of its time in 96 fp32 MFMAs per
+// wave (3 key tiles), this one needs 6 + 24.
+//   S^T = K.Q^T : both operands are bf16 as they stand (products exact in fp32, fp32 accumulate): K rows from a padded bf16 LDS
+//                 image (144-byte rows: conflict-free 16-byte fragment reads), Q fragments straight from global memory.
+//   O^T = V^T.P^T: the probabilities are fp32 registers; each is split EXACTLY into three bf16 pieces p = hi + mid + lo
+//                 (truncations of the successive remainders: 3 x 8 mantissa bits cover fp32's 24), three MFMAs per 32-key block
+//                 accumulate hi.V + mid.V + lo.V — the fp32 product p.v summed in fp32, no new rounding point.  The k-slots of a
+//                 block are permuted so that the S^T registers are the B operand as they stand: slot e of lane-quarter q4 is key
+//                 16*(2u + e/4) + 4*q4 + e%4; the A operand reads V transposed (Vt[d][key], bf16, 272-byte rows) to match.
+// Same bias / mask / softmax arithmetic as above; T5's scale of 1.0 only (launch_attention checks).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t bf16_trunc_bits(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void attention_mfma_bf16_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  constexpr int DK = 64, KS = 144, VS = 272, LP = 16 * NT, NTHR = 64 * NT, NB = (NT + 1) / 2, VKEYS = 32 * NB;
+  const int Lr = a.Lk;
+  unsigned char* Ks = smem_b;                                   // [Lr][144 B]  K rows, bf16
+  unsigned char* Vt = Ks + (size_t)((Lr * KS + 15) & ~15);      // [64][272 B]  V transposed: Vt[d][key], bf16, keys < VKEYS
+  float* RelB = reinterpret_cast<float*>(Vt + DK * VS);         // [2*LP]
+  float* Mk = RelB + 2 * LP;                                    // [LP]
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int L = a.seq_len ? a.seq_len[b] : a.Lk, tid = threadIdx.x;
+  const int64_t qrow0 = a.seq_off ? a.seq_off[b] : (int64_t)b * a.q_bstride;
+  const int64_t krow0 = a.seq_off ? a.seq_off[b] : (int64_t)b * a.k_bstride;
+  const int64_t orow0 = a.seq_off ? a.seq_off[b] : (int64_t)b * a.o_bstride;
+  const __bf16* q16 = reinterpret_cast<const __bf16*>(a.q);
+  const __bf16* k16 = reinterpret_cast<const __bf16*>(a.k);
+  const __bf16* v16 = reinterpret_cast<const __bf16*>(a.v);
+  // this wave's query fragments (B operand of S^T): lane (c16, q4) holds Q[16w + c16][32kk + 8q4 .. +7]
+  uint4 qv[2];
+  {
+    const int wq = tid >> 6, lq = tid & 63;
+    if (16 * wq < L) {
+      const int64_t qr = qrow0 + min(16 * wq + (lq & 15), L - 1);
+      const __bf16* qp = q16 + qr * a.ldq + h * DK + 8 * (lq >> 4);
+      qv[0] = *reinterpret_cast<const uint4*>(qp);
+      qv[1] = *reinterpret_cast<const uint4*>(qp + 32);
+    }
+  }
+  for (int e = tid; e < 2 * LP; e += NTHR) {
+    float v = 0.f;
+    if (a.rel_bias) {
+      int n = e - (LP - 1), bucket = 0;
+      if (a.bidirectional) {
+        if (n < 0) {
+          bucket = a.num_buckets >> 1;
+          n = -n;
+        }
+      } else if (n < 0) {
+        n = 0;
+      }
+      bucket += a.lut.v[n < 127 ? n : 127];
+      v = a.rel_bias[bucket * a.H + h];
+    }
+    RelB[e] = v;
+  }
+  for (int j = tid; j < LP; j += NTHR) {
+    float v = -INFINITY;
+    if (j < L) v = (a.key_mask && a.key_mask[(int64_t)b * a.mask_bstride + j] == 0) ? (a.causal_neg_inf ? -INFINITY : -1e9f) : 0.f;
+    Mk[j] = v;
+  }
+  // V^T keys past this sequence's end must be finite: their probability is exactly 0, and 0 x garbage must stay 0
+  for (int e = tid; e < DK * (VKEYS / 2); e += NTHR) {
+    const int d = e / (VKEYS / 2), kp = e - d * (VKEYS / 2);
+    if (2 * kp + 1 >= L) reinterpret_cast<uint32_t*>(Vt + d * VS)[kp] = 0u;   // pairs (2kp, 2kp+1); a live key of a mixed pair is rewritten below
+  }
+  __syncthreads();
+  for (int e = tid; e < L * (DK / 8); e += NTHR) {
+    const int r = e >> 3, c = e & 7;
+    *reinterpret_cast<uint4*>(Ks + r * KS + 16 * c) = *reinterpret_cast<const uint4*>(k16 + (krow0 + r) * a.ldk + h * DK + 8 * c);
+    const uint4 u = *reinterpret_cast<const uint4*>(v16 + (krow0 + r) * a.ldv + h * DK + 8 * c);
+    const uint32_t wv[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      reinterpret_cast<uint16_t*>(Vt + (8 * c + 2 * i) * VS)[r] = (uint16_t)(wv[i] & 0xffffu);
+      reinterpret_cast<uint16_t*>(Vt + (8 * c + 2 * i + 1) * VS)[r] = (uint16_t)(wv[i] >> 16);
+    }
+  }
+  __syncthreads();
+
+  const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, q4 = lane >> 4;
+  if (16 * w >= L) return;
+  const int nt_live = (L + 15) >> 4;
+  f32x4_t st[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) st[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t >= nt_live) continue;
+    const unsigned char* kr = Ks + min(16 * t + c16, L - 1) * KS + 16 * q4;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint4 kv = *reinterpret_cast<const uint4*>(kr + 64 * kk);
+      st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kv), __builtin_bit_cast(bf16x8_t, qv[kk]), st[t], 0, 0, 0);
+    }
+  }
+  const int i = 16 * w + c16;
+  const float masked = a.causal_neg_inf ? -INFINITY : -1e9f;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t >= nt_live) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * t + 4 * q4 + r;
+      float add = RelB[i - j + (LP - 1)] + Mk[j];
+      if (a.causal && j > i && Mk[j] == 0.f) add += masked;
+      const float s = st[t][r] + add;
+      st[t][r] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t >= nt_live) {
+      st[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};   // a skipped tile's probabilities are exactly 0 (its keys carry -inf)
+      continue;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = __expf(st[t][r] - mx);
+      st[t][r] = p;
+      sum += p;
+    }
+  }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  // exact three-way split of every probability, packed as the B operand of its 32-key block
+  uint4 ph[NB], pm[NB], pl[NB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    uint32_t hi[8], mid[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int t = 2 * u + (e >> 2);
+      const float p = t < NT ? st[t < NT ? t : 0][e & 3] : 0.f;
+      const uint32_t h1 = bf16_trunc_bits(p);
+      const float r1 = p - __uint_as_float(h1);
+      const uint32_t h2 = bf16_trunc_bits(r1);
+      const float r2 = r1 - __uint_as_float(h2);
+      hi[e] = h1 >> 16, mid[e] = h2 >> 16, lo[e] = bf16_trunc_bits(r2) >> 16;
+    }
+    ph[u] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+    pm[u] = make_uint4(mid[0] | (mid[1] << 16), mid[2] | (mid[3] << 16), mid[4] | (mid[5] << 16), mid[6] | (mid[7] << 16));
+    pl[u] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+  }
+#pragma unroll
+  for (int dt = 0; dt < DK / 16; ++dt) {
+    f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const unsigned char* vr = Vt + (16 * dt + c16) * VS + 8 * q4;   // Vt[d][32u + 16*(e/4) + 4*q4 + e%4]
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      if (2 * u >= nt_live) continue;
+      const uint2 v0 = *reinterpret_cast<const uint2*>(vr + 64 * u);
+      const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 64 * u + 32);
+      const bf16x8_t va = __builtin_bit_cast(bf16x8_t, make_uint4(v0.x, v0.y, v1.x, v1.y));
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, __builtin_bit_cast(bf16x8_t, ph[u]), o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, __builtin_bit_cast(bf16x8_t, pm[u]), o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, __builtin_bit_cast(bf16x8_t, pl[u]), o, 0, 0, 0);
+    }
+    if (i < L) {
+      const int64_t off = (orow0 + i) * a.ldo + h * DK + 16 * dt + 4 * q4;
+      const float4 ov = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+      if (a.out_bf16)
+        *reinterpret_cast<uint2*>(static_cast<__bf16*>(a.out_bf16) + off) = pack_bf16x4(ov.x, ov.y, ov.z, ov.w);
+      else
+        *reinterpret_cast<float4*>(a.out + off) = ov;
+    }
+  }
+}
+
+template <int NT>
+static int launch_attention_mfma_bf16(const AttnArgs& a, hipStream_t stream) {
+  const size_t lds = (size_t)((a.Lk * 144 + 15) & ~15) + 64 * 272 + sizeof(float) * 3 * 16 * NT;
+  if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(attention_mfma_bf16_kernel<NT>), 160 * 1024, "attention")) return rc__;
+  hipLaunchKernelGGL(attention_mfma_bf16_kernel<NT>, dim3((unsigned)(a.B * a.H)), dim3(64 * NT), lds, stream, a);
+  GDR_CHECK_LAUNCH("attention_mfma_bf16_kernel");
+  return GDR_OK;
+}
+
 template <int NT>
 static int launch_attention_mfma16(const AttnArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * ((size_t)2 * a.Lk * 68 + 3 * 16 * NT);
@@ -1015,6 +1203,18 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
                 "attention: the packed (ragged) form and bf16 q/k/v serve full self-attention with d_kv = 64 only");
   GDR_CHECK_ARG(!a.qkv_bf16 || (a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0), "attention: bf16 q/k/v need row strides %% 8 == 0");
   if (a.Lq == a.Lk && a.q_pos0 == 0 && !a.kv_rows && a.kv_group == 1 && !a.q_same_pos && a.dk == 64 && a.ldo % 4 == 0) {
+    if (a.qkv_bf16 && a.scale == 1.0f) {  // bf16 operands as they stand: the bf16-MFMA form
+      switch ((a.Lk + 15) / 16) {
+        case 1: return launch_attention_mfma_bf16<1>(a, stream);
+        case 2: return launch_attention_mfma_bf16<2>(a, stream);
+        case 3: return launch_attention_mfma_bf16<3>(a, stream);
+        case 4: return launch_attention_mfma_bf16<4>(a, stream);
+        case 5: return launch_attention_mfma_bf16<5>(a, stream);
+        case 6: return launch_attention_mfma_bf16<6>(a, stream);
+        case 7: return launch_attention_mfma_bf16<7>(a, stream);
+        default: return launch_attention_mfma_bf16<8>(a, stream);
+      }
+    }
     switch ((a.Lk + 15) / 16) {
       case 1: return launch_attention_mfma16<1>(a, stream);
       case 2: return launch_attention_mfma16<2>(a, stream);

@@ -133,6 +133,27 @@ def test_linear_bf16_matches_cpu_on_rounded_operands(dev, M, N, K):
     torch.testing.assert_close(ops.linear_bf16(A, W, epilogue=_ffi.EPI_RELU).cpu(), torch.relu(base), rtol=TOL, atol=TOL)
 
 
+def test_linear_bf16_tile_heights_give_the_same_bits(dev):
+    """gemm_nt_bf16_glds_kernel deals 64-row tiles when 128-row tiles would leave the chip under-filled (the decode legs of config
+    C5) and 128-row tiles otherwise: every output element is the same k-ordered MFMA chain either way, so the rows of a small
+    batch must equal the same rows computed inside a big one, bit for bit — with bias + ReLU and residual epilogues, a row count
+    that is not a multiple of 64, and against the fp32 product of the rounded operands."""
+    from gdr_amd import ops, _ffi
+    g = torch.Generator().manual_seed(9)
+    big, small, N, K = 15360, 1930, 768, 768                      # 720 tiles of 128 rows; 186 tiles of 64 rows
+    a, w = torch.randn(big, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    b, r = torch.randn(N, generator=g), torch.randn(big, N, generator=g)
+    A, W, Bv, Rv = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    for epi, kw_big, kw_small in ((_ffi.EPI_NONE, {}, {}), (_ffi.EPI_BIAS_RELU, dict(bias=Bv), dict(bias=Bv)),
+                                  (_ffi.EPI_RESIDUAL, dict(residual=Rv), dict(residual=Rv[:small].contiguous()))):
+        full = ops.linear_bf16(A, W, epilogue=epi, **kw_big)
+        part = ops.linear_bf16(A[:small].contiguous(), W, epilogue=epi, **kw_small)
+        assert torch.equal(full[:small], part), f"epilogue {epi}"
+    base = a[:small].bfloat16().float() @ w.bfloat16().float().T
+    torch.testing.assert_close(ops.linear_bf16(A[:small].contiguous(), W).cpu(), base, rtol=TOL, atol=TOL)
+    torch.testing.assert_close(ops.linear_bf16(A, W)[-300:].cpu(), a[-300:].bfloat16().float() @ w.bfloat16().float().T, rtol=TOL, atol=TOL)
+
+
 def test_linear_bf16_accumulator_map_on_integers(dev):
     """A = I with an asymmetric B: exact in bf16, catches a transposed accumulator map or a wrong swizzle."""
     from gdr_amd import ops
