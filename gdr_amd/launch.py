@@ -27,8 +27,9 @@ def free_port():
 
 def spawn_ranks(n, argv, script=None, module=None, env=None, relay=True, timeout=None):
     """Runs `script argv...` (or `-m module argv...`) as n ranks under torch.distributed.run, as a child process.
-    Returns (returncode, stdout text).  With relay=True every stdout line of the ranks is echoed to this process' stdout
-    as it arrives (rank 0's JSON line among them); stderr is inherited."""
+    Returns (returncode, stdout text).  relay=True echoes every stdout line of the ranks to this process' stdout as it
+    arrives; relay=callable hands each line to the callable instead (bench.py lets only rank 0's JSON line through to
+    stdout and sends the rest — RCCL's version banner, progress prints — to stderr); stderr is inherited."""
     if (script is None) == (module is None):
         raise ValueError("spawn_ranks: give exactly one of script= / module=")
     if n < 1:
@@ -47,7 +48,9 @@ def spawn_ranks(n, argv, script=None, module=None, env=None, relay=True, timeout
     try:
         for line in proc.stdout:
             lines.append(line)
-            if relay:
+            if callable(relay):
+                relay(line)
+            elif relay:
                 sys.stdout.write(line)
                 sys.stdout.flush()
         rc = proc.wait(timeout=timeout)

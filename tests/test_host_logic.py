@@ -540,6 +540,10 @@ def test_launcher_spawns_fresh_ranks_and_relays_one_json_line(tmp_path, monkeypa
     assert js == [{"metric": "stub", "n_gpus": 2}]
     rc, _ = launch.spawn_ranks(2, [str(tmp_path), "--fail"], script=str(stub), relay=False)
     assert rc != 0
+    got = []
+    rc, _ = launch.spawn_ranks(2, [str(tmp_path)], script=str(stub), relay=got.append)      # a callable gets every line
+    assert rc == 0 and sum(ln.startswith("{") for ln in got) == 1 and sum("noise" in ln for ln in got) == 2
+    assert capsys.readouterr().out == "", "a relay callable decides where lines go: nothing is echoed behind its back"
     # bench.py's side of it
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
