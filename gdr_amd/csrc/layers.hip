@@ -1101,9 +1101,66 @@ __global__ __launch_bounds__(256) void attention_decode_rows_kernel(const AttnAr
   auto row_of = [&](int j) -> int64_t {
     return a.kv_rows ? (int64_t)a.kv_rows[(int64_t)b * Lk + j] : (int64_t)kb * a.k_bstride + j;
   };
+  // Short key lists (a decode step: Lk <= max_length, ancestors reached through kv_rows): every memory operand of the wave is
+  // requested up front — lane j fetches the row index of key j, a shuffle hands it to the lanes that read that row, and all
+  // K AND V rows (V does not depend on the scores) are in flight together — instead of index -> K row -> ... -> index -> V row as
+  // four dependent round trips per RPI keys.  The arithmetic below is unchanged (same order: bit-identical results).
+  constexpr int MAXIT = 8;
+  const bool pre = Lk <= MAXIT * RPI;
+  float4 kreg[MAXIT], vreg[MAXIT];
+  if (pre) {
+    int myrow = 0;
+    if (lane < Lk) myrow = (int)row_of(lane);
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int j = it * RPI + g;
+      const int rj = __shfl(myrow, j < Lk ? j : 0);
+      kreg[it] = make_float4(0.f, 0.f, 0.f, 0.f), vreg[it] = kreg[it];
+      if (j < Lk && col_ok) {
+        kreg[it] = *reinterpret_cast<const float4*>(a.k + (int64_t)rj * a.ldk + h * dk + 4 * c);
+        vreg[it] = *reinterpret_cast<const float4*>(a.v + (int64_t)rj * a.ldv + h * dk + 4 * c);
+      }
+    }
+  }
   // ---- scores: key j = j0 + g, its row read by the LPR lanes of group g
   float mx = -INFINITY;
-  for (int j0 = 0; j0 < Lk; j0 += RPI) {
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int j0 = it * RPI;
+    if (!pre || j0 >= Lk) break;
+    const int j = j0 + g;
+    float part = 0.f;
+    if (j < Lk && col_ok) {
+      const float4 kk = kreg[it];
+      part = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
+    }
+#pragma unroll
+    for (int off = LPR >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (j < Lk) {
+      float add = 0.f;
+      if (a.rel_bias) {
+        int n = i_abs - j, bucket = 0;
+        if (a.bidirectional) {
+          if (n < 0) {
+            bucket = half;
+            n = -n;
+          }
+        } else if (n < 0) {
+          n = 0;
+        }
+        bucket += a.lut.v[n < 127 ? n : 127];
+        add = a.rel_bias[bucket * a.H + h];
+      }
+      bool allowed = true;
+      if (a.causal) allowed = j <= i_abs;
+      if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)kb * a.mask_bstride + j] != 0);
+      if (!allowed) add += masked;
+      const float sj = part + add;
+      if (c == 0) S[j] = sj;
+      mx = fmaxf(mx, sj);
+    }
+  }
+  for (int j0 = 0; j0 < Lk && !pre; j0 += RPI) {
     const int j = j0 + g;
     float part = 0.f;
     if (j < Lk && col_ok) {
@@ -1149,8 +1206,17 @@ __global__ __launch_bounds__(256) void attention_decode_rows_kernel(const AttnAr
   __builtin_amdgcn_wave_barrier();
   // ---- O = P·V: group g takes keys j0 + g, lane (g, c) accumulates columns 4c..4c+3; then the groups are summed
   float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int j = it * RPI + g;
+    if (pre && j < Lk && col_ok) {
+      const float4 vv = vreg[it];
+      const float pj = S[j];
+      o.x = fmaf(pj, vv.x, o.x), o.y = fmaf(pj, vv.y, o.y), o.z = fmaf(pj, vv.z, o.z), o.w = fmaf(pj, vv.w, o.w);
+    }
+  }
 #pragma unroll 4
-  for (int j0 = 0; j0 < Lk; j0 += RPI) {
+  for (int j0 = 0; j0 < Lk && !pre; j0 += RPI) {
     const int j = j0 + g;
     if (j < Lk && col_ok) {
       const float4 vv = *reinterpret_cast<const float4*>(a.v + row_of(j) * a.ldv + h * dk + 4 * c);
