@@ -278,7 +278,7 @@ def stages(dev, cfg, D, D_dev, a):
     ids_np, mask_np = {}, {}
     # C3 at infer.sh's eval batch, one query x 100 beams, C2's batch, and the batch sweep that shows where the decode chain stops
     # being launch-bound (a reduced --corpus, as the contract test runs, skips the sweep)
-    sweep = ((64, 10), (1, 100), (512, 10)) + (((128, 10), (256, 10), (1024, 10), (2048, 10)) if N >= 300000 else ())
+    sweep = ((64, 10), (1, 100), (512, 10)) + (((128, 10), (256, 10), (1024, 10), (2048, 10), (4096, 10)) if N >= 300000 else ())
     for B, R in sweep:
         ids, mask = synth.make_tokens(B, L=40, seed=11)
         ids_np[(B, R)], mask_np[(B, R)] = ids, mask
@@ -339,7 +339,7 @@ def stages(dev, cfg, D, D_dev, a):
             "note": "cluster lookup + dot + per-alpha select (3 launches, 20 calls back to back per timing); a gather of "
                     f"{gbytes / 1e6:.1f} MB is {gbytes / (HBM_PEAK_GBS * 1e9) * 1e6:.1f} us at the HBM peak — the stage is launch-bound, not "
                     "bandwidth-bound, at these sizes"}
-        nb, depth = (16, 4) if B == 1 else (8, 2) if B <= 64 else (4, 2)   # a stream of batches, `depth` in flight (GDRRetriever.validation_steps)
+        nb, depth = (16, 4) if B == 1 else (8, 2) if B <= 64 else (4, 2) if B <= 1024 else (3, 2)   # a stream of batches, `depth` in flight (GDRRetriever.validation_steps)
         tp = timed(lambda: list(retr.validation_steps(iter([batch] * nb), depth=depth)), reps=3, warm=1) / nb
         skey = "c3_two_stage_infer_sh" if B == 1 else "c3_two_stage" if B == 64 else f"c3_two_stage_B{B}"
         if not a.no_cpu_baseline and B in (1, 64):

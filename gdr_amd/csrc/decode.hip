@@ -320,15 +320,17 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
   for (int c = threadIdx.x & 63; c < d4; c += 64) dst[c] = src[c];
 }
 
-// slot[rows_map[i]] = src[i] (rows of d3 floats), i < *n_dev: the compacted (q,k,v) of this step into the cache slot
+// slot[rows_map[i]][c0 ..] = src[i][c0 ..] (rows of n4 float4, columns from c0 on), i < *n_dev: the compacted (k, v) of this
+// step into the cache slot — the q third of a row stays in the compacted buffer, where this step's attention reads it; nobody
+// reads q from the cache in the prefix-table mode (descendants need their ancestors' K / V only)
 __global__ __launch_bounds__(256) void scatter_slot_kernel(const float* __restrict__ src, const int32_t* __restrict__ rows_map,
-                                                           const int64_t* __restrict__ n_dev, int n4,
+                                                           const int64_t* __restrict__ n_dev, int n4, int c0,
                                                            float* __restrict__ slot) {
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= *n_dev) return;
   const float4* s4 = reinterpret_cast<const float4*>(src) + i * n4;
   float4* d4 = reinterpret_cast<float4*>(slot) + (int64_t)rows_map[i] * n4;
-  for (int c = threadIdx.x & 63; c < n4; c += 64) d4[c] = s4[c];
+  for (int c = c0 + (threadIdx.x & 63); c < n4; c += 64) d4[c] = s4[c];
 }
 
 // Teacher forcing: logits[r][c] = table[b][pos][last_token][token(pos,c)]
@@ -969,6 +971,10 @@ static int dec_linear_norm(bool bf16, void* abf, const float* A, int64_t lda, co
   if (ne.kind == 1)
     return m_dev ? launch_rmsnorm_dev(C, ne.w1, ne.Y, m_dev, M, N, ne.eps, st, y16)
                  : launch_rmsnorm(C, ne.w1, ne.Y, M, N, ne.eps, nullptr, 1, st, y16);
+  if (ne.kind == 3) {  // norm1 -> + addv -> norm2 with the row held in registers (one launch, no intermediate pass)
+    const int rc2 = launch_layernorm2(C, ne.w1, ne.b1, ne.w2, ne.b2, ne.addv, ne.Y, m_dev, M, N, ne.eps, st, y16);
+    if (rc2 <= 0) return rc2;
+  }
   // LayerNorm(s): the second one reads the first one's output through Y
   float* y1 = ne.kind == 3 ? C : ne.Y;  // kind 3: norm1 may overwrite C (the pre-norm rows are not needed again)
   if (int rc = m_dev ? launch_layernorm_dev(C, ne.w1, ne.b1, y1, m_dev, M, N, ne.eps, nullptr, st, ne.kind == 3 ? nullptr : y16)
@@ -1281,7 +1287,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
         float* slot = cache + s * aslab;
         GDR_TRY(LIN2D(xa, d, al.in_w, d, qkv_c, 3 * d, 3 * d, d, GDR_EPI_BIAS, al.in_b, nullptr, 0));
         hipLaunchKernelGGL(scatter_slot_kernel, dim3((unsigned)((rows_s + 3) / 4)), dim3(256), 0, as, qkv_c, bb.miss_rows, nm,
-                           3 * d / 4, slot);
+                           3 * d / 4, d / 4, slot);
         GDR_CHECK_LAUNCH("scatter_slot_kernel");
         AttnArgs at{};
         at.q = qkv_c, at.k = cache + d, at.v = cache + 2 * d;

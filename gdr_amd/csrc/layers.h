@@ -87,5 +87,9 @@ int launch_layernorm(const float* x, const float* w, const float* b, float* y, i
                      const float* addv, hipStream_t stream, void* y16 = nullptr);
 int launch_layernorm_dev(const float* x, const float* w, const float* b, float* y, const int64_t* rows_dev, int64_t max_rows,
                          int d, float eps, const float* addv, hipStream_t stream, void* y16 = nullptr);
+// y = LN(LN(x; w1, b1) + addv; w2, b2) in one pass (bit-identical to the two launches); rows_dev may be null (= max_rows rows);
+// returns 1 when d > 2048 (not served: run the two launches)
+int launch_layernorm2(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* addv, float* y,
+                      const int64_t* rows_dev, int64_t max_rows, int d, float eps, hipStream_t stream, void* y16 = nullptr);
 
 }  // namespace gdr

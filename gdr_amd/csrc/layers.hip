@@ -357,6 +357,91 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// y = LN(LN(x; w1, b1) + addv; w2, b2) — the adaptor's norm1 -> (+ the constant single-key cross-attention output) -> norm2
+// (nn.TransformerDecoderLayer, post-LN; modeling_t5.py:1241-1244) in ONE pass: the row stays in registers between the two
+// norms instead of going through memory and a second launch.  Same expressions and reduction order as two layernorm_kernel
+// launches: bit-identical.  d <= 2048.
+__global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                         const float* __restrict__ b1, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, const float* __restrict__ addv,
+                                                         float* __restrict__ y, int64_t rows, int d4, float eps,
+                                                         const int64_t* __restrict__ rows_dev, uint2* __restrict__ y16) {
+  constexpr int MAXC = 8;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rows_dev) rows = *rows_dev;
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float inv_d = 1.0f / (float)(d4 * 4);
+  const float4* xr = reinterpret_cast<const float4*>(x) + row * d4;
+  float4 v[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < d4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float4* wr[2] = {reinterpret_cast<const float4*>(w1), reinterpret_cast<const float4*>(w2)};
+  const float4* br[2] = {reinterpret_cast<const float4*>(b1), reinterpret_cast<const float4*>(b2)};
+  const float4* av = reinterpret_cast<const float4*>(addv);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && av) {
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d4) {
+          const float4 t = av[c];
+          v[i].x += t.x, v[i].y += t.y, v[i].z += t.z, v[i].w += t.w;
+        }
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+      if (lane + 64 * i < d4) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    const float mean = wave_sum(s) * inv_d;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+      if (lane + 64 * i < d4) {
+        const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+        ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv_d + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d4) {
+        const float4 g = wr[pass][c], bb = br[pass][c];
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g.x + bb.x, o.y = (v[i].y - mean) * rstd * g.y + bb.y;
+        o.z = (v[i].z - mean) * rstd * g.z + bb.z, o.w = (v[i].w - mean) * rstd * g.w + bb.w;
+        v[i] = o;
+      }
+    }
+  }
+  float4* yr = reinterpret_cast<float4*>(y) + row * d4;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d4) {
+      yr[c] = v[i];
+      if (y16) (y16 + row * d4)[c] = pack_bf16x4(v[i].x, v[i].y, v[i].z, v[i].w);
+    }
+  }
+}
+
+// returns 1 when d is too wide for the one-pass form (the caller runs two layernorm launches)
+int launch_layernorm2(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* addv, float* y,
+                      const int64_t* rows_dev, int64_t max_rows, int d, float eps, hipStream_t stream, void* y16) {
+  GDR_CHECK_ARG(d % 4 == 0, "layernorm: d %% 4 != 0");
+  if (d > 2048) return 1;
+  if (max_rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(layernorm2_kernel, dim3((unsigned)((max_rows + 3) / 4)), dim3(256), 0, stream, x, w1, b1, w2, b2, addv, y,
+                     max_rows, d / 4, eps, rows_dev, static_cast<uint2*>(y16));
+  GDR_CHECK_LAUNCH("layernorm2_kernel");
+  return GDR_OK;
+}
+
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int d, float eps,
                      const float* addv, hipStream_t stream, void* y16) {
   GDR_CHECK_ARG(d % 4 == 0, "layernorm: d %% 4 != 0");
