@@ -278,7 +278,7 @@ def stages(dev, cfg, D, D_dev, a):
     ids_np, mask_np = {}, {}
     # C3 at infer.sh's eval batch, one query x 100 beams, C2's batch, and the batch sweep that shows where the decode chain stops
     # being launch-bound (a reduced --corpus, as the contract test runs, skips the sweep)
-    sweep = ((64, 10), (1, 100), (512, 10)) + (((128, 10), (256, 10), (1024, 10), (2048, 10), (4096, 10)) if N >= 300000 else ())
+    sweep = ((64, 10), (1, 100), (512, 10)) + (((128, 10), (256, 10), (1024, 10), (2048, 10)) if N >= 300000 else ())
     for B, R in sweep:
         ids, mask = synth.make_tokens(B, L=40, seed=11)
         ids_np[(B, R)], mask_np[(B, R)] = ids, mask
@@ -341,6 +341,10 @@ def stages(dev, cfg, D, D_dev, a):
                     "bandwidth-bound, at these sizes"}
         nb, depth = (16, 4) if B == 1 else (8, 2) if B <= 64 else (4, 2) if B <= 1024 else (3, 2)   # a stream of batches, `depth` in flight (GDRRetriever.validation_steps)
         tp = timed(lambda: list(retr.validation_steps(iter([batch] * nb), depth=depth)), reps=3, warm=1) / nb
+        if B >= 512:           # the grow-only per-stream scratch of a big batch (tens of GB at 2 048 queries) must not pile up
+            retr = st = q_emb = bs32 = offs2 = cids2 = None
+            model.dec.ws.bufs.clear(), model.enc.ws.bufs.clear(), ops._RERANK_WS.clear()
+            torch.cuda.empty_cache()
         skey = "c3_two_stage_infer_sh" if B == 1 else "c3_two_stage" if B == 64 else f"c3_two_stage_B{B}"
         if not a.no_cpu_baseline and B in (1, 64):
             # the CPU path beside this stage (SURVEY §8d "per config"): the oracle in the reference's formulation
