@@ -295,8 +295,10 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
     set_error("linear_bf16: grid too large");
     return GDR_EINVAL;
   }
-  // fewer than ~2 tiles of 128 rows per CU: 64-row tiles (same k order per output element: bit-identical results)
-  if (blocks < 600) {
+  // fewer than 2 tiles of 128 rows per CU: 64-row tiles (same k order per output element: bit-identical results)
+  // (tools/exp_bf16_linear.py, profiles/r04_bf16_tile_height_sweep.txt: 1 920 rows qkv 21.6 -> 18.2 us, o 18.9 -> 15.2, wi 22.8 ->
+  // 19.9, wo 57.4 -> 43.6; 4 096 rows o 23.2 -> 17.5, wo 58.5 -> 46.2; from ~2 tiles per CU on the 128-row form is as fast or faster)
+  if (blocks < 512) {
     blocks = ((M + 63) / 64) * g.tiles_n;
     hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 64>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
     GDR_CHECK_LAUNCH("gemm_nt_bf16_glds_kernel<64-row tiles>");

@@ -10,6 +10,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 
 
 def under_launcher():
@@ -45,6 +46,11 @@ def spawn_ranks(n, argv, script=None, module=None, env=None, relay=True, timeout
         e.pop(k, None)                                   # the children get their own
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=e, text=True, bufsize=1)
     lines = []
+    # the read loop below only ends when the ranks close their stdout: a watchdog enforces `timeout` on a hung launch
+    watchdog = threading.Timer(timeout, proc.kill) if timeout else None
+    if watchdog:
+        watchdog.daemon = True
+        watchdog.start()
     try:
         for line in proc.stdout:
             lines.append(line)
@@ -53,9 +59,12 @@ def spawn_ranks(n, argv, script=None, module=None, env=None, relay=True, timeout
             elif relay:
                 sys.stdout.write(line)
                 sys.stdout.flush()
-        rc = proc.wait(timeout=timeout)
+        rc = proc.wait()
     except BaseException:
         proc.kill()
         proc.wait()
         raise
+    finally:
+        if watchdog:
+            watchdog.cancel()
     return rc, "".join(lines)
