@@ -277,6 +277,235 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tiles, 8 waves (2 x 4), BK = 64, one workgroup per CU, 128 KiB of LDS = 2 buffers x {A_lo, A_hi, B_lo, B_hi} half-tiles of
+// 128 rows x 128 B — the "256^2 8-phase" schedule of cdna_hip_programming.md: four phases per K-tile, each [fragment reads of the
+// phase + one half-tile of LDS-DMA prefetch] barrier [16 MFMAs on one 64 x 32 quadrant of the wave's 128 x 64 block] barrier; the two
+// wave rows run one barrier apart so that on every SIMD one wave is in its MFMA cluster while the other reads / stages; the DMA stays
+// in flight across barriers behind ONE counted vmcnt(6) per K-tile.  Twice the flops per operand byte of the 128^2 kernel above: its K
+// loop runs at ~1 PFLOP/s where that one's runs at ~0.7 — but with one workgroup per CU every CU reaches its epilogue alone, so a launch
+// only wins where the K loop is long or the output small (round-3 lab, profiles/r03_bf16_lab_tile256.txt; adopted per shape in round 4:
+// K >= 2048 — the FFN's second linear, 70.9 us against 82.3 at 12 308 rows, 93.4 against 108.5 at 20 480 — and bf16 outputs with
+// N >= 2048).  Same k order per output element as the 128^2 kernel: bit-identical results (tests/test_gpu_parity.py).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // the LDS-DMA's destination travels in m0: named in the clobber list on purpose
+#define GLDS16(gptr_, lds_) \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_), "v"(gptr_) : "memory", "m0")
+
+constexpr int HALF_BYTES = 128 * 128;                 // one half-tile
+constexpr int OFF_A_LO = 0, OFF_A_HI = HALF_BYTES, OFF_B_LO = 2 * HALF_BYTES, OFF_B_HI = 3 * HALF_BYTES, BUF_BYTES = 4 * HALF_BYTES;
+
+__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16GemmArgs g) {
+  extern __shared__ __attribute__((aligned(1024))) char smem256[];
+  unsigned bid = blockIdx.x;
+  const int64_t Mv = g.m_dev ? *g.m_dev : g.M;
+  const int tiles_n = (g.N + 255) / 256;
+  {
+    // XCD-aware remap over the LIVE tile count (see gemm_nt_bf16_glds_kernel): hardware blocks past it exit
+    unsigned nblk = gridDim.x;
+    if (g.m_dev) {
+      const int64_t live = ((Mv + 255) / 256) * (int64_t)tiles_n;
+      if (live < (int64_t)nblk) {
+        if ((int64_t)bid >= live) return;  // uniform
+        nblk = (unsigned)live;
+      }
+    }
+    const unsigned q_ = nblk >> 3, r_ = nblk & 7u, xcd_ = bid & 7u, j_ = bid >> 3;
+    bid = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + j_;
+  }
+  const int64_t m0 = (int64_t)(bid / (unsigned)tiles_n) * 256;
+  if (m0 >= Mv) return;  // uniform
+  const int n0 = (int)(bid % (unsigned)tiles_n) * 256;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 2, wc = wave & 3, r16 = lane & 15, q4 = lane >> 4;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem256));
+  // ---- staging: instruction i of wave w covers local rows (w*2 + i)*8 + (lane>>3) of a half-tile
+  const int srow = lane >> 3, schunk = lane & 7;
+  const char* a_src[2][2];  // [half][instr]
+  const char* b_src[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int lr = (wave * 2 + i) * 8 + srow;
+      const int chunk = schunk ^ ((lr >> 1) & 7);
+      int64_t ra = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+      ra = ra < Mv ? ra : Mv - 1;
+      int rb = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+      rb = rb < g.N ? rb : g.N - 1;
+      a_src[h][i] = g.A + (ra * g.lda) * 2 + chunk * 16;
+      b_src[h][i] = g.W + ((int64_t)rb * g.ldw) * 2 + chunk * 16;
+    }
+  const unsigned st_dst = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 2048;  // + i*1024 + half offset + buffer offset
+#define STAGE(src_, half_off_, buf_, kt_)                                                   \
+  {                                                                                         \
+    const int koff_ = (kt_) * 128;                                                          \
+    GLDS16(src_[0] + koff_, st_dst + (buf_)*BUF_BYTES + (half_off_));                       \
+    GLDS16(src_[1] + koff_, st_dst + (buf_)*BUF_BYTES + (half_off_) + 1024);                \
+  }
+  // ---- fragment reads
+  const int sw = (r16 >> 1) & 7;
+  const int c0 = (q4 ^ sw) << 4;
+  const char* const fa_base = smem256 + (wr * 64 + r16) * 128 + c0;
+  const char* const fb_base = smem256 + (wc * 32 + r16) * 128 + c0;
+  float4 fa[4][2], fbl[2][2], fbh[2][2];
+#define READ_A(buf_, half_off_)                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                 \
+    fa[i][0] = *reinterpret_cast<const float4*>(fa_base + (buf_)*BUF_BYTES + (half_off_) + i * 2048);             \
+    fa[i][1] = *reinterpret_cast<const float4*>((fa_base + (buf_)*BUF_BYTES + (half_off_) + i * 2048) + 64 - 2 * (c0 & 64)); \
+  }
+#define READ_B(fb_, buf_, half_off_)                                                                              \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                 \
+    fb_[j][0] = *reinterpret_cast<const float4*>(fb_base + (buf_)*BUF_BYTES + (half_off_) + j * 2048);            \
+    fb_[j][1] = *reinterpret_cast<const float4*>((fb_base + (buf_)*BUF_BYTES + (half_off_) + j * 2048) + 64 - 2 * (c0 & 64)); \
+  }
+  f32x4b acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4b){0.f, 0.f, 0.f, 0.f};
+#define MFMA_Q(mh_, nh_, fb_)                                                                                      \
+  {                                                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
+            acc[(mh_)*4 + i][(nh_)*2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                               \
+                __builtin_bit_cast(bf16x8b, fb_[j][kk]), __builtin_bit_cast(bf16x8b, fa[i][kk]), acc[(mh_)*4 + i][(nh_)*2 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+  }
+#define BAR()                              \
+  {                                        \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_s_barrier();          \
+    asm volatile("" ::: "memory");         \
+  }
+  const int nk = g.K >> 6;  // even (launcher)
+  // prologue: K-tile 0 whole, K-tile 1 without A_hi
+  STAGE(b_src[0], OFF_B_LO, 0, 0)
+  STAGE(a_src[0], OFF_A_LO, 0, 0)
+  STAGE(b_src[1], OFF_B_HI, 0, 0)
+  STAGE(a_src[1], OFF_A_HI, 0, 0)
+  STAGE(b_src[0], OFF_B_LO, 1, 1)
+  STAGE(a_src[0], OFF_A_LO, 1, 1)
+  STAGE(b_src[1], OFF_B_HI, 1, 1)
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  BAR()
+  if (wr == 1) BAR()
+  for (int kt = 0; kt < nk; kt += 2) {
+    const int e2 = kt + 2 < nk ? kt + 2 : nk - 1, o1 = kt + 1, o3 = kt + 3 < nk ? kt + 3 : nk - 1;
+    // p1
+    READ_B(fbl, 0, OFF_B_LO)
+    __builtin_amdgcn_sched_barrier(0);
+    READ_A(0, OFF_A_LO)
+    STAGE(a_src[1], OFF_A_HI, 1, o1)
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    BAR()
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_Q(0, 0, fbl)
+    BAR()
+    // p2
+    READ_B(fbh, 0, OFF_B_HI)
+    STAGE(b_src[0], OFF_B_LO, 0, e2)
+    BAR()
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_Q(0, 1, fbh)
+    BAR()
+    // p3
+    READ_A(0, OFF_A_HI)
+    STAGE(a_src[0], OFF_A_LO, 0, e2)
+    BAR()
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_Q(1, 1, fbh)
+    BAR()
+    // p4
+    STAGE(b_src[1], OFF_B_HI, 0, e2)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    BAR()
+    MFMA_Q(1, 0, fbl)
+    BAR()
+    // p5
+    READ_B(fbl, 1, OFF_B_LO)
+    __builtin_amdgcn_sched_barrier(0);
+    READ_A(1, OFF_A_LO)
+    STAGE(a_src[1], OFF_A_HI, 0, e2)
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    BAR()
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_Q(0, 0, fbl)
+    BAR()
+    // p6
+    READ_B(fbh, 1, OFF_B_HI)
+    STAGE(b_src[0], OFF_B_LO, 1, o3)
+    BAR()
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_Q(0, 1, fbh)
+    BAR()
+    // p7
+    READ_A(1, OFF_A_HI)
+    STAGE(a_src[0], OFF_A_LO, 1, o3)
+    BAR()
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_Q(1, 1, fbh)
+    BAR()
+    // p8
+    STAGE(b_src[1], OFF_B_HI, 1, o3)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    BAR()
+    MFMA_Q(1, 0, fbl)
+    BAR()
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wr == 0) BAR()
+  // ---- epilogue: row m = m0 + wr*128 + mi*16 + r16, columns n0 + wc*64 + ni*16 + 4*q4 + 0..3 (N % 4 == 0, 16-byte rows: launcher)
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int64_t m = m0 + wr * 128 + mi * 16 + r16;
+    if (m >= Mv) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wc * 64 + ni * 16 + 4 * q4;
+      if (n >= g.N) continue;
+      float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+      if (g.has_bias) {
+        const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+        v[0] += b.x, v[1] += b.y, v[2] += b.z, v[3] += b.w;
+      }
+      if (g.has_residual) {
+        const float4 r = *reinterpret_cast<const float4*>(g.residual + m * g.ldr + n);
+        v[0] += r.x, v[1] += r.y, v[2] += r.z, v[3] += r.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (g.act == 1) v[j] = fmaxf(v[j], 0.f);
+        if (g.act == 2) v[j] = gelu_erf_b(v[j]);
+      }
+      if (g.out_bf16) {
+        union {
+          __bf16 h[4];
+          uint2 u;
+        } o;
+        o.h[0] = (__bf16)v[0], o.h[1] = (__bf16)v[1], o.h[2] = (__bf16)v[2], o.h[3] = (__bf16)v[3];
+        *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(g.C) + m * g.ldc + n) = o.u;
+      } else {
+        *reinterpret_cast<float4*>(g.C + m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+#pragma clang diagnostic pop
+#undef GLDS16
+#undef STAGE
+#undef READ_A
+#undef READ_B
+#undef MFMA_Q
+#undef BAR
+
 // Returns 1 if the shape is not served here (caller falls back to the generic core), 0 on launch, < 0 on error.
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
@@ -294,6 +523,15 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
   if (blocks > 0x7fffffffLL) {
     set_error("linear_bf16: grid too large");
     return GDR_EINVAL;
+  }
+  // deep contractions / bf16 outputs of a big batch: the 256^2 tile (see gemm_nt_bf16_tile256_kernel)
+  if (M >= 8192 && K % 128 == 0 && N % 4 == 0 && (ldc & 3) == 0 && (!has_residual || (ldr & 3) == 0) &&
+      (K >= 2048 || (out_bf16 && N >= 2048))) {
+    const int64_t b256 = ((M + 255) / 256) * (int64_t)((N + 255) / 256);
+    if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_nt_bf16_tile256_kernel), 2 * BUF_BYTES, "linear_bf16")) return rc__;
+    hipLaunchKernelGGL(gemm_nt_bf16_tile256_kernel, dim3((unsigned)b256), dim3(512), 2 * BUF_BYTES, stream, g);
+    GDR_CHECK_LAUNCH("gemm_nt_bf16_tile256_kernel");
+    return 0;
   }
   // fewer than 2 tiles of 128 rows per CU: 64-row tiles (same k order per output element: bit-identical results)
   // (tools/exp_bf16_linear.py, profiles/r04_bf16_tile_height_sweep.txt: 1 920 rows qkv 21.6 -> 18.2 us, o 18.9 -> 15.2, wi 22.8 ->

@@ -125,6 +125,23 @@ def set_seed(seed):
         torch.cuda.manual_seed_all(seed)
 
 
+def deal_spans(n, batch_size, world, rank):
+    """How `--n_gpu N` deals the query batches: span i = [i*batch_size, min(n, (i+1)*batch_size)) goes to rank i % world.
+    The sharded stage 2 is a fixed-size collective, so every rank runs the SAME number of steps: a rank that ran out of spans
+    repeats the last span (its output is dropped).  Returns (all_spans, my_spans, my_real) with len(my_spans) == ceil(len(all_spans) / world)
+    on every rank."""
+    all_spans = [(lo, min(n, lo + batch_size)) for lo in range(0, n, batch_size)]
+    n_steps = (len(all_spans) + world - 1) // world
+    mine = [all_spans[min(i * world + rank, len(all_spans) - 1)] for i in range(n_steps)]
+    real = [i * world + rank < len(all_spans) for i in range(n_steps)]
+    return all_spans, mine, real
+
+
+def reassemble_spans(per_rank, n_spans, world):
+    """The inverse on rank 0: per_rank[r] = rank r's REAL step outputs in its own order -> the outputs in span order."""
+    return [per_rank[i % world][i // world] for i in range(n_spans)]
+
+
 def _load_inputs(args, cfg):
     """Returns dict(source_ids, source_mask, gt_cluster list[str], gt_doc list[str], index, doc_embed (np or None))."""
     if args.data_npz:
@@ -192,13 +209,10 @@ def inference(args):
     n = data["source_ids"].shape[0] if args.n_test < 0 else min(args.n_test, data["source_ids"].shape[0])
     texts = data.get("texts") or ["q%d" % i for i in range(data["source_ids"].shape[0])]
     inf_result_cache, outputs = [], []
-    all_spans = [(lo, min(n, lo + args.eval_batch_size)) for lo in range(0, n, args.eval_batch_size)]
     # N ranks: span i goes to rank i % N.  The sharded stage 2 is a fixed-size collective, so every rank runs the same number
     # of steps with the same batch size: the last span is padded with its last query, and ranks that ran out of spans repeat
     # the last one — padding rows and repeated steps are dropped below
-    n_steps = (len(all_spans) + world - 1) // world
-    spans = [all_spans[min(i * world + rank, len(all_spans) - 1)] for i in range(n_steps)]
-    real = [i * world + rank < len(all_spans) for i in range(n_steps)]
+    all_spans, spans, real = deal_spans(n, args.eval_batch_size, world, rank)
     full = args.eval_batch_size if world > 1 else 0
 
     def take(arr, lo, hi):
@@ -246,7 +260,7 @@ def inference(args):
             return None, None
         per_rank_out = [g[0] for g in gathered]
         if two_stage:
-            outputs = [per_rank_out[i % world][i // world] for i in range(len(all_spans))]
+            outputs = reassemble_spans(per_rank_out, len(all_spans), world)
         else:
             per = [g[1] for g in gathered]                       # rows of span i: rank i % world, its (i // world)-th block
             inf_result_cache, cursor = [], [0] * world

@@ -149,6 +149,16 @@ def test_linear_bf16_tile_heights_give_the_same_bits(dev):
         full = ops.linear_bf16(A, W, epilogue=epi, **kw_big)
         part = ops.linear_bf16(A[:small].contiguous(), W, epilogue=epi, **kw_small)
         assert torch.equal(full[:small], part), f"epilogue {epi}"
+    # a deep contraction at a big batch takes the 256 x 256 tile (gemm_nt_bf16_tile256_kernel; K >= 2048, M >= 8192): the same
+    # k order again — rows of the big launch == the same rows through the 64-row tiles; row count not a multiple of 256
+    K2, big2 = 3072, 12308
+    a2, w2 = torch.randn(big2, K2, generator=g), torch.randn(N, K2, generator=g) * K2 ** -0.5
+    A2, W2, R2 = a2.to(dev), w2.to(dev), r[:big2].contiguous().to(dev)
+    for epi, kw_big, kw_small in ((_ffi.EPI_NONE, {}, {}), (_ffi.EPI_BIAS_RESIDUAL, dict(bias=Bv, residual=R2), dict(bias=Bv, residual=R2[:small].contiguous()))):
+        full = ops.linear_bf16(A2, W2, epilogue=epi, **kw_big)
+        part = ops.linear_bf16(A2[:small].contiguous(), W2, epilogue=epi, **kw_small)
+        assert torch.equal(full[:small], part), f"256-row tiles, epilogue {epi}"
+    torch.testing.assert_close(ops.linear_bf16(A2, W2)[-200:].cpu(), a2[-200:].bfloat16().float() @ w2.bfloat16().float().T, rtol=TOL, atol=TOL)
     base = a[:small].bfloat16().float() @ w.bfloat16().float().T
     torch.testing.assert_close(ops.linear_bf16(A[:small].contiguous(), W).cpu(), base, rtol=TOL, atol=TOL)
     torch.testing.assert_close(ops.linear_bf16(A, W)[-300:].cpu(), a[-300:].bfloat16().float() @ w.bfloat16().float().T, rtol=TOL, atol=TOL)

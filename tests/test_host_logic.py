@@ -569,6 +569,24 @@ def test_launcher_spawns_fresh_ranks_and_relays_one_json_line(tmp_path, monkeypa
     assert cap.out == '{"metric": "x"}\n' and "noise" in cap.err
 
 
+@pytest.mark.parametrize("n,bs,world", [(10, 4, 1), (10, 4, 2), (10, 4, 3), (10, 4, 4), (64, 8, 8), (3, 4, 4), (9, 3, 2)])
+def test_n_gpu_batch_dealing_round_trips(n, bs, world):
+    """`main.py --n_gpu N` (the reference's analogue: Lightning's DistributedSampler over the validation set,
+    main_models.py:1990-1999): every rank must run the same number of fixed-size steps for the sharded stage 2's collectives;
+    the real steps, put back in span order on rank 0, must cover every query exactly once, in order."""
+    from gdr_amd.main import deal_spans, reassemble_spans
+    per_rank, steps = [], set()
+    for rank in range(world):
+        all_spans, mine, real = deal_spans(n, bs, world, rank)
+        steps.add(len(mine))
+        assert len(mine) == len(real) and all(0 <= lo < hi <= n and hi - lo <= bs for lo, hi in mine)
+        per_rank.append([list(range(lo, hi)) for (lo, hi), r in zip(mine, real) if r])    # a step's "output": its query ids
+    assert len(steps) == 1, "every rank runs the same number of steps"
+    back = reassemble_spans(per_rank, len(all_spans), world)
+    assert [q for span in back for q in span] == list(range(n))
+    assert sum(len(p) for p in per_rank) == len(all_spans)
+
+
 def test_trie_flattening_matches_reference_treebuilder_semantics():
     """codec.Trie (flat arrays for the device) encodes exactly the nested children of TreeBuilder.add
     (main_models.py:135-151) for the docid sequences of the reference-made fixture."""
