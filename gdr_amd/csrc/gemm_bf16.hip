@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
 // in flight across barriers behind ONE counted vmcnt(6) per K-tile.  Twice the flops per operand byte of the 128^2 kernel above: its K
 // loop runs at ~1 PFLOP/s where that one's runs at ~0.7 — but with one workgroup per CU every CU reaches its epilogue alone, so a launch
 // only wins where the K loop is long or the output small (round-3 lab, profiles/r03_bf16_lab_tile256.txt; adopted per shape in round 4:
-// K >= 2048 — the FFN's second linear, 70.9 us against 82.3 at 12 308 rows, 93.4 against 108.5 at 20 480 — and bf16 outputs with
-// N >= 2048).  Same k order per output element as the 128^2 kernel: bit-identical results (tests/test_gpu_parity.py).
+// K >= 2048 — the FFN's second linear: 88.9 -> 78.3 us at 12 308 rows, 125.9 -> 93.1 us = 1.04 PFLOP/s at 20 480,
+// profiles/r04_bf16_tile_height_sweep.txt).  Same k order per output element as the 128^2 kernel: bit-identical results (tests/test_gpu_parity.py).
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"   // the LDS-DMA's destination travels in m0: named in the clobber list on purpose
 #define GLDS16(gptr_, lds_) \
@@ -524,9 +524,10 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
     set_error("linear_bf16: grid too large");
     return GDR_EINVAL;
   }
-  // deep contractions / bf16 outputs of a big batch: the 256^2 tile (see gemm_nt_bf16_tile256_kernel)
-  if (M >= 8192 && K % 128 == 0 && N % 4 == 0 && (ldc & 3) == 0 && (!has_residual || (ldr & 3) == 0) &&
-      (K >= 2048 || (out_bf16 && N >= 2048))) {
+  // deep contractions of a big batch: the 256^2 tile (see gemm_nt_bf16_tile256_kernel).  NOT the wide bf16-output linears (qkv,
+  // wi: K = 768): as one tile per workgroup their 441 / 588 live tiles quantise badly on 256 CUs and the C2 bf16 step LOST 6 %
+  // (4.39 -> 4.65 ms) when they were routed here; the lab's gain on those shapes came from the persistent form of this tile
+  if (M >= 8192 && K % 128 == 0 && K >= 2048 && N % 4 == 0 && (ldc & 3) == 0 && (!has_residual || (ldr & 3) == 0)) {
     const int64_t b256 = ((M + 255) / 256) * (int64_t)((N + 255) / 256);
     if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_nt_bf16_tile256_kernel), 2 * BUF_BYTES, "linear_bf16")) return rc__;
     hipLaunchKernelGGL(gemm_nt_bf16_tile256_kernel, dim3((unsigned)b256), dim3(512), 2 * BUF_BYTES, stream, g);
