@@ -80,6 +80,8 @@ _FLAGS = [
     ("n_queries", int, 512), ("res1_save_path", str, ""), ("device", str, "cuda:0"),
     ("pipeline_depth", int, 2),              # eval batches in flight on the GPU (each on its own stream) while the host decodes
                                              #    / formats the previous one; 1 = strictly one after another
+    ("dist_backend", str, "nccl"),           # torch.distributed backend of the `--n_gpu N` ranks: nccl (= RCCL over xGMI), or gloo —
+                                             #    collectives staged through the host, which lets several ranks share ONE GPU (tests)
     ("prefix_table", int, 1),                # 1: build the device prefix table over the corpus' docid trie at load
     ("constrain_tree", int, 0),              # 1: apply the trie constraint of generation_utils_previous.py:714-729 (the
                                              #    shipped generate() ignores decode_tree even with --tree 1)
@@ -177,10 +179,13 @@ def inference(args):
     world, rank, sharded_index = 1, 0, None
     if launch.under_launcher():                              # a rank of `--n_gpu N` (or of torch.distributed.run typed by hand)
         import torch.distributed as dist
-        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())   # more ranks than GPUs: they share
         torch.cuda.set_device(local_rank)
         args.device = f"cuda:{local_rank}"
-        dist.init_process_group("nccl", device_id=torch.device(args.device))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(args.device))
+        else:
+            dist.init_process_group(args.dist_backend)
         world, rank = dist.get_world_size(), dist.get_rank()
     dev = torch.device(args.device)
     data = _load_inputs(args, cfg)

@@ -138,6 +138,26 @@ def test_main_eval_sharded_two_stage_under_one_rank_rccl_equals_unsharded(tmp_pa
     assert open(a + ".docs.tsv").read() == open(b + ".docs.tsv").read() and len(_read_tsv(a + ".docs.tsv")) == 70
 
 
+def test_main_eval_n_gpu_2_ranks_sharing_one_gpu_equals_the_one_process_run(tmp_path):
+    """`--n_gpu 2` with REAL compute on both ranks: the launcher starts two rank processes that share this box's one GPU
+    (`--dist_backend gloo`: RCCL refuses two ranks on one device; gloo stages the same collectives through the host).  Rank r holds
+    rows [lo, hi) of the corpus (cluster-aligned), decodes spans r, r + 2, ... (10 queries in batches of 4: three spans — rank 1 runs
+    out and repeats its last one, the short last batch is padded), `rerank_own` exchanges the wire rows (world 2: every query's
+    candidates really are split over two shards), merges, maps positions back; rank 0 gathers and writes.  res1 and doc-level
+    TSVs byte-identical to the one-process run — the N > 1 logic end to end on the HIP kernels (main_models.py:1434-1462,
+    1574-1637; per-GPU launch: bert_NQ.sh:5-12)."""
+    a, b = str(tmp_path / "a.tsv"), str(tmp_path / "b.tsv")
+    argv = INFER_SH + ["--infer_ckpt", "", "--num_return_sequences", "10", "--eval_batch_size", "4", "--corpus_rows", "30000",
+                       "--n_queries", "10", "--constrain_tree", "1"]
+    argv2 = [x for x in argv]
+    argv2[argv2.index("--n_gpu") + 1] = "2"
+    out = _run_main(argv2 + ["--dist_backend", "gloo", "--res1_save_path", a])
+    assert "2 GPU(s)" in out and "GDR_RESULT " in out
+    _run_main(argv + ["--res1_save_path", b])
+    assert open(a).read() == open(b).read() and len(_read_tsv(a)) == 10
+    assert open(a + ".docs.tsv").read() == open(b + ".docs.tsv").read() and len(_read_tsv(a + ".docs.tsv")) == 70
+
+
 def test_main_eval_missing_checkpoint_is_an_error(tmp_path):
     """A non-empty --infer_ckpt that does not exist must fail (the reference's torch.load raises, main.py:121), not fall
     back to random weights."""
