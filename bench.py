@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--constrained", action="store_true",
                     help="c3 / c5: constrain the beams to the corpus' docid trie (generation_utils_previous.py:714-729) — every "
                          "hypothesis names a real cluster and the call leaves its step loop early, as a trained model does")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the ranks: nccl (= RCCL over xGMI, the product path) or gloo (collectives staged "
+                         "through the host: lets N ranks share ONE GPU, which RCCL refuses — used by the tests to run the N > 1 code "
+                         "path with real compute on a one-GPU box; its numbers are not a scaling measurement)")
     ap.add_argument("--launcher", action="store_true",
                     help="start the rank processes through torch.distributed.run even for --gpus 1 (a 1-rank RCCL group)")
     ap.add_argument("--k", type=int, default=100)
@@ -468,12 +472,16 @@ def init_ranks(a):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         a.gpus = world
+    local_rank %= max(1, torch.cuda.device_count())                      # more ranks than GPUs (--backend gloo): they share
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
         _t = torch.ones(1, device=dev)
         dist.all_reduce(_t)                  # communicator set-up stays out of the timed region even with --warmup 0
         torch.cuda.synchronize()
@@ -568,6 +576,7 @@ def two_stage_main(a):
                                   "; unconstrained beams of random weights run all 9 steps, every decoded string is mapped to a real 12-doc cluster")
                                + (f"; corpus row-sharded {world} ways, stage 2 = one all-gather of queries + candidate blocks, per-shard "
                                   "scoring, one all-to-all of the packed lists, merge" if sharded is not None else ""),
+                       "dist_backend": a.backend if dist.is_initialized() else None,
                        "batch_per_gpu": B, "global_batch": B * world, "beams": R, "seq_len": 40, "corpus_rows": a.corpus,
                        "dim": cfg.d_model, "k": R, "alphas": 7, "candidates_per_query": n_cand, "pipeline_depth": max(1, a.depth),
                        "corpus_resident_in_hbm": True, "docid_depth": id_depth},
@@ -703,6 +712,7 @@ def main():
                         ("one all-gather of the packed per-shard top-k, merge of all queries on every rank" if a.replicated_merge
                          else "one all-to-all of the packed per-shard top-k on a side stream under the next batch's encoder, "
                               "local merge")),
+                       "dist_backend": a.backend if dist.is_initialized() else None,
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 40,
                        "corpus_rows": a.corpus, "dim": cfg.d_model, "k": a.k, "corpus_resident_in_hbm": True,
                        "encoder_rows": "ragged" if ragged else "padded", "live_token_rows_per_gpu": live_rows},

@@ -95,6 +95,20 @@ def test_bench_two_stage_workloads_and_the_self_launch():
     assert u["config"]["workload"].startswith("C3/constrained:") and u["value"] > 0
 
 
+def test_bench_gpus_2_on_one_gpu_through_gloo():
+    """`python bench.py --gpus 2` as the driver types it (no launcher, no RANK in the environment): bench.py starts its two ranks
+    itself; `--backend gloo` lets them share this box's one GPU (RCCL refuses that), so the whole N > 1 path runs with real
+    compute — C2 layout: row-sharded corpus, query all-gather, per-shard top-k, ONE all-to-all of the packed lists on a side
+    stream, merge; C3 layout: data-parallel decode + ShardedIndex.rerank_own over two shards — and rank 0 prints one JSON line."""
+    j = _run("--gpus", "2", "--backend", "gloo", "--no-stages")
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 128 and j["config"]["workload"].startswith("C4-layout")
+    assert j["config"]["dist_backend"] == "gloo" and j["value"] > 0 and j["cpu_baseline"] is None
+    assert abs(j["value"] - 128 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    k = _run("--gpus", "2", "--backend", "gloo", "--workload", "c3", "--batch", "8")
+    assert k["n_gpus"] == 2 and k["config"]["workload"].startswith("C3/sharded") and k["config"]["global_batch"] == 16
+    assert k["value"] > 0 and k["config"]["candidates_per_query"] == 120
+
+
 def test_bench_under_torchrun_one_rank_rccl():
     """The N > 1 code path (process group over RCCL, query all-gather, all-to-all of the per-shard lists, barrier + max
     over ranks) with a 1-rank group — what one GPU can exercise of it."""
