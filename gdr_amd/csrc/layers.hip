@@ -1190,7 +1190,8 @@ __global__ __launch_bounds__(256) void attention_decode_rows_kernel(const AttnAr
   // requested up front — lane j fetches the row index of key j, a shuffle hands it to the lanes that read that row, and all
   // K AND V rows (V does not depend on the scores) are in flight together — instead of index -> K row -> ... -> index -> V row as
   // four dependent round trips per RPI keys.  The arithmetic below is unchanged (same order: bit-identical results).
-  constexpr int MAXIT = 8;
+  constexpr int MAXIT = LPR == 16 ? 4 : 6;  // 16 / 12 keys: a decode step has <= max_length (10); 64 VGPRs of operands at 8
+                                            // iterations cost three waves per SIMD of occupancy for nothing
   const bool pre = Lk <= MAXIT * RPI;
   float4 kreg[MAXIT], vreg[MAXIT];
   if (pre) {
