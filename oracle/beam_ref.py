@@ -71,10 +71,12 @@ def build_trie(seqs):
 
 def beam_search(step_fn, batch_size, num_beams, vocab_size, max_length, length_penalty,
                 num_return_sequences=None, eos_token_id=1, pad_token_id=0, start_token_id=0,
-                trace=None, decode_tree=None):
+                trace=None, decode_tree=None, prefix_trace=None):
     """step_fn(seq int64[B*R, cur_len]) -> next-token logits fp32[B*R, vocab_size] (last position,
     positional mask already applied).  Returns (decoded int64[B*nret, <=max_length], scores list[float]).
-    ``trace`` (a list) receives per step (top_scores[B,2R], top_tokens[B,2R]) for golden comparison."""
+    ``trace`` (a list) receives per step (top_scores[B,2R], top_tokens[B,2R]) for golden comparison; ``prefix_trace`` (a
+    list) the beams' token prefixes int64[B*R, cur_len] as they stand BEFORE that step — together they let a test explain why a
+    hypothesis is absent from the final list (which cut it fell at, and by how much)."""
     R = num_beams
     nret = num_return_sequences or R
     hyps = [BeamHypotheses(R, length_penalty) for _ in range(batch_size)]
@@ -93,6 +95,8 @@ def beam_search(step_fn, batch_size, num_beams, vocab_size, max_length, length_p
         next_scores, next_tokens = torch.topk(next_scores, 2 * R, dim=1, largest=True, sorted=True)  # :775
         if trace is not None:
             trace.append((next_scores.clone(), next_tokens.clone()))
+        if prefix_trace is not None:
+            prefix_trace.append(input_ids.clone())
         next_batch_beam = []
         for b in range(batch_size):                                       # :783
             if done[b]:

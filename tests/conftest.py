@@ -76,7 +76,48 @@ def ranked_lists_match(ref_items, ref_scores, got_items, tol):
     return permuted
 
 
-def hypothesis_lists_match(ref_items, ref_scores, got_items, tol):
+def beam_cut_explains_absence(trace, prefix_trace, q, R, Vd, row, tol, lp=0.8, eos=1, final_cut=None):
+    """Beam search prunes at EVERY step, so a hypothesis can be missing from the reference's final list although its final
+    score would have ranked well: its prefix fell at an intermediate cut.  That is legitimate under a noisy arithmetic only if it
+    fell by a TIE.  Replays the reference's selection (generation_utils.py:800-829) from the oracle's per-step trace
+    (beam_ref.beam_search(trace=, prefix_trace=)) for the token row `row` (START, tokens..., [EOS, PAD...]) of query q and
+    returns a short description of the cut it tied with — or None when it fell by more than `tol` (absolute, on the final-score
+    scale; per-step scores are sums of log-probabilities, i.e. final score x cur_len^lp) or cannot be found among the 2R
+    ranked candidates of the step at all."""
+    toks = [int(t) for t in row]
+    if eos in toks[1:]:
+        toks = toks[:1 + toks[1:].index(eos)]
+    n = len(toks) - 1                                           # tokens after START
+    for s in range(min(n + 1, len(trace))):
+        sc, tk = trace[s][0][q].tolist(), trace[s][1][q].tolist()
+        pref = prefix_trace[s][q * R:(q + 1) * R].tolist()
+        if toks[:s + 1] not in pref:
+            return None                                         # the prefix is not a beam although no cut explained it
+        j = pref.index(toks[:s + 1])
+        want = j * Vd + (toks[s + 1] if s < n else eos)
+        if want not in tk:
+            return None
+        r = tk.index(want)
+        tol_s = tol * float(s + 1) ** lp                        # the step's scores are not length-normalised
+        if s == n:                                              # the EOS candidate: counted only at rank < R (:811-813)
+            if r >= R:
+                return f"EOS at rank {r} of step {s} ties the rank-{R - 1} candidate" if abs(sc[r] - sc[R - 1]) <= 2 * tol_s else None
+            if final_cut is not None and abs(sc[r] / float(s + 1) ** lp - final_cut) <= 2 * tol:
+                return f"finished with a score that ties the final cut"
+            return None
+        non_eos = [i for i, t in enumerate(tk) if t % Vd != eos]
+        p = non_eos.index(r)
+        if p >= R:                                              # not among the R continued beams: it fell here
+            cut = sc[non_eos[R - 1]]
+            return f"pruned at step {s} (rank {p} of the non-EOS candidates) in a tie with the cut" if abs(sc[r] - cut) <= 2 * tol_s else None
+    # survived every recorded step: an open beam at max_length — it is in the final list unless it ties the final cut
+    if final_cut is not None:
+        last = len(trace) - 1
+        return "open beam tying the final cut" if abs(sc[r] / float(last + 2) ** lp - final_cut) <= 2 * tol else None
+    return None
+
+
+def hypothesis_lists_match(ref_items, ref_scores, got_items, tol, explain_foreign=None):
     """The rule for lists of beam HYPOTHESES under a noisy arithmetic (the bf16 precision mode), with teeth.
     `tol` is ABSOLUTE and must come from the measured score gap between the two implementations (the caller asserts that
     gap first): two hypotheses whose reference scores differ by more than 2*tol cannot legitimately swap.  Neighbours of the
@@ -84,8 +125,9 @@ def hypothesis_lists_match(ref_items, ref_scores, got_items, tol):
       * the item is the reference's item at p: fine;
       * the item sits at another reference position r: p and r must lie in the SAME tie group (asserted in every group, the
         last one included — it is only 'cut' for items that left the list, next case);
-      * the item is not in the reference list at all (it crossed the cut at k): p must lie in the LAST tie group, i.e. tie with
-        the list's worst score.
+      * the item is not in the reference list at all: either its slot p lies in the LAST tie group (it crossed the final cut at k
+        in a tie), or — beam search prunes at every step — `explain_foreign(item)` (beam_cut_explains_absence on the oracle's
+        per-step trace) names the intermediate cut it fell at in the reference, by a tie.  Anything else fails.
     Returns (moved, foreign, group_sizes) so that the caller can print that the rule is not one big group."""
     k = len(ref_items)
     assert len(got_items) == k, (len(got_items), k)
@@ -104,8 +146,10 @@ def hypothesis_lists_match(ref_items, ref_scores, got_items, tol):
     for p, x in enumerate(got_items):
         r = pos.get(x)
         if r is None:
-            assert group[p] == group[k - 1], ("a hypothesis outside the reference list at a slot that does not tie with the cut",
-                                              p, x, sc[p], sc[k - 1], tol)
+            why = None if group[p] == group[k - 1] or explain_foreign is None else explain_foreign(x)
+            assert group[p] == group[k - 1] or why, ("a hypothesis outside the reference list: its slot does not tie with the final "
+                                                     "cut and no intermediate cut of the reference's search explains it by a tie",
+                                                     p, x, sc[p], sc[k - 1], tol)
             foreign += 1
         elif r != p:
             assert group[p] == group[r], ("two hypotheses swapped outside a tolerance-tie group", p, r, sc[p], sc[r], tol)

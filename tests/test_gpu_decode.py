@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import hypothesis_lists_match, golden, ranked_lists_match
+from conftest import beam_cut_explains_absence, hypothesis_lists_match, golden, ranked_lists_match
 from gdr_amd.config import GDRConfig
 from gdr_amd import synth
 
@@ -414,9 +414,9 @@ def test_generate_bf16_mode_vs_oracle_emulation(dev, kind, B, R, use_table):
     enc_cpu = enc_h.cpu()
     idx = torch.arange(B).view(-1, 1).repeat(1, R).view(-1)
     enc_x, mask_x = enc_cpu.index_select(0, idx), mt.index_select(0, idx)
-    trace = []
+    trace, ptrace = [], []
     rd, rs = beam_ref.beam_search(lambda seq: _bf16_step_logits(sd, cfg, seq, enc_x, mask_x), B, R, cfg.decode_vocab_size, ml,
-                                  0.8, R, trace=trace)
+                                  0.8, R, trace=trace, prefix_trace=ptrace)
     # fp32 oracle on the same encoder states
     fd, fs = beam_ref.beam_search(lambda seq: t5_ref.decode_logits(sd, cfg, seq, enc_x, mask_x, restricted=True), B, R,
                                   cfg.decode_vocab_size, ml, 0.8, R)
@@ -442,7 +442,9 @@ def test_generate_bf16_mode_vs_oracle_emulation(dev, kind, B, R, use_table):
     moved = foreign = shared = 0
     sizes = []
     for b in range(B):
-        m, f, sz = hypothesis_lists_match(rlists[b], rs[b], glists[b], tie)   # raises when two non-tied hypotheses swap
+        def explain(hyp, b=b):         # a hypothesis the emulation's list lacks: it must have fallen at a cut of ITS search by a tie
+            return beam_cut_explains_absence(trace, ptrace, b, R, cfg.decode_vocab_size, list(hyp), tie, final_cut=rs[b, -1])
+        m, f, sz = hypothesis_lists_match(rlists[b], rs[b], glists[b], tie, explain_foreign=explain)   # raises when two non-tied hypotheses swap
         moved, foreign, shared = moved + m, foreign + f, shared + len(set(glists[b]) & set(rlists[b]))
         sizes.append(sz)
         if rs[b, 0] - rs[b, 1] > 2 * tie:

@@ -21,7 +21,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, golden, hypothesis_lists_match, order_insensitive_topk_match, ranked_lists_match
+from conftest import REPO, beam_cut_explains_absence, golden, hypothesis_lists_match, order_insensitive_topk_match, ranked_lists_match
 from gdr_amd.config import GDRConfig
 from gdr_amd import synth
 
@@ -327,7 +327,9 @@ def test_c5_composed_bf16_two_stage_on_1m_corpus(dev, base_weights):
               states; scores within 3e-2 of it; the score gap on shared hypotheses is MEASURED, asserted <= 5e-3 and used as
               the absolute tie tolerance of the id rule (conftest.hypothesis_lists_match): a hypothesis may sit at another
               rank than the emulation's only inside a group of hypotheses whose emulation scores chain closer than twice that
-              gap, in every group including the last; >= 95 % of the ids are the emulation's; the group sizes are printed;
+              gap, in every group including the last; an id the emulation's list lacks must be explained by a TIE at a cut of the
+              emulation's own beam search (final or intermediate: conftest.beam_cut_explains_absence replays its per-step
+              selection from the oracle's trace); >= 95 % of the ids are the emulation's; the group sizes are printed;
       stage 2 (all 64 queries): the oracle rerank on the bf16-rounded corpus rows and the GPU's stage-1 output: values
               to 1e-4, ids exact outside fp32 tolerance ties."""
     from gdr_amd import codec, ops
@@ -365,7 +367,8 @@ def test_c5_composed_bf16_two_stage_on_1m_corpus(dev, base_weights):
         with t5_ref.bf16_linears():
             return t5_ref.decode_logits(sd, cfg, seq, enc_x, mask_x, restricted=True)
 
-    rd, rs = beam_ref.beam_search(step, nq, R, cfg.decode_vocab_size, 10, 0.8, R, decode_tree=tree)
+    trace, ptrace = [], []
+    rd, rs = beam_ref.beam_search(step, nq, R, cfg.decode_vocab_size, 10, 0.8, R, decode_tree=tree, trace=trace, prefix_trace=ptrace)
     dec = codec_ref.dec_2d(codec_ref.decode_token(rd.numpy(), output_vocab_size=V, kary=V), R)
     rs2 = np.array(rs, np.float64).reshape(nq, R)
     np.testing.assert_allclose(got_scores[:nq], rs2, rtol=3e-2, atol=3e-2)
@@ -379,14 +382,21 @@ def test_c5_composed_bf16_two_stage_on_1m_corpus(dev, base_weights):
     tie = max(gap, 2e-4)
     moved = foreign = shared = 0
     sizes = []
+    why = []
     for q in range(nq):
-        m, f, sz = hypothesis_lists_match(dec[q], rs2[q], out["clusters"][q], tie)   # raises when two non-tied hypotheses swap
+        def explain(name, q=q):        # a cluster id the emulation's final list lacks: which cut of ITS search did it fall at, and by how much?
+            row = [0] + codec_ref.encode_single_newid(name, kary=V)
+            w = beam_cut_explains_absence(trace, ptrace, q, R, cfg.decode_vocab_size, row, tie, final_cut=rs2[q, -1])
+            why.append((q, name, w))
+            return w
+        m, f, sz = hypothesis_lists_match(dec[q], rs2[q], out["clusters"][q], tie, explain_foreign=explain)   # raises when two non-tied hypotheses swap
         moved, foreign, shared = moved + m, foreign + f, shared + len(set(dec[q]) & set(out["clusters"][q]))
         sizes.append(sz)
     assert shared >= 0.95 * nq * R, (shared, moved, foreign)
     assert max(max(sz) for sz in sizes) < R, "the tie rule must not degenerate into one group"
     print(f"C5 stage 1 ({nq} queries): score gap {gap:.2e} -> tie window {2 * tie:.2e}; {shared}/{nq * R} ids shared with the "
-          f"emulation, {moved} moved inside a tie group, {foreign} crossed the cut inside the last group; tie-group sizes: {sizes}")
+          f"emulation, {moved} moved inside a tie group, {foreign} outside the emulation's list, each explained by a tie at a cut "
+          f"of the emulation's own search: {why}; tie-group sizes: {sizes}")
     # ---- stage 2 on all 64 queries: oracle rerank on the bf16-rounded rows the GPU gathered
     q_emb = state["enc_h"][:, 0].cpu()
     cand = [[m for s_ in row for m in range(int(offsets[look[s_]]), int(offsets[look[s_] + 1]))] for row in out["clusters"]]
