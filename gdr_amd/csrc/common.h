@@ -104,6 +104,7 @@ struct NormEpilogue {
   float eps;
   float* Y;                 // normed rows [M, ldy]
   int64_t ldy;
+  int y16_only = 0;         // bf16 mode: the normed rows feed bf16 linears only — when their bf16 image is written, the fp32 copy is not
 };
 // Split-K slabs left UN-reduced for a consumer that sums them itself (the decode cross-attention reads its q rows so and the
 // reduction launch disappears): element (m, n) = sum over s < S, in that order, of

@@ -968,9 +968,12 @@ static int dec_linear_norm(bool bf16, void* abf, const float* A, int64_t lda, co
   // bf16 mode: the last norm of this call also leaves its output rounded to bf16 for the linear that reads it next
   void* y16 = (bf16 && img && img->buf && ne.ldy == N) ? img->buf : nullptr;
   if (img) img->src = y16 ? ne.Y : nullptr;
-  if (ne.kind == 1)
+  if (ne.kind == 1) {
+    if (y16 && ne.y16_only)  // nobody reads these rows as fp32 (bf16 mode: every consumer is a linear): write the bf16 image alone
+      return m_dev ? launch_rmsnorm_bf16_dev(C, ne.w1, y16, m_dev, M, N, ne.eps, st) : launch_rmsnorm_bf16(C, ne.w1, y16, M, N, ne.eps, st);
     return m_dev ? launch_rmsnorm_dev(C, ne.w1, ne.Y, m_dev, M, N, ne.eps, st, y16)
                  : launch_rmsnorm(C, ne.w1, ne.Y, M, N, ne.eps, nullptr, 1, st, y16);
+  }
   if (ne.kind == 3) {  // norm1 -> + addv -> norm2 with the row held in registers (one launch, no intermediate pass)
     const int rc2 = launch_layernorm2(C, ne.w1, ne.b1, ne.w2, ne.b2, ne.addv, ne.Y, m_dev, M, N, ne.eps, st, y16);
     if (rc2 <= 0) return rc2;
@@ -1129,7 +1132,11 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   dec_linear_norm(bf16, abf, A_, lda_, W_, ldw_, C_, ldc_, M_, nullptr, N_, K_, epi_, bias_, res_, ldr_, skw, stream, ne_, &sk1, &img1)
 #define LIN2N(A_, lda_, W_, ldw_, C_, ldc_, M_, md_, N_, K_, epi_, bias_, res_, ldr_, ne_) \
   dec_linear_norm(bf16, abf2, A_, lda_, W_, ldw_, C_, ldc_, M_, md_, N_, K_, epi_, bias_, res_, ldr_, skw2, as, ne_, &sk2, &img2)
-  auto rms = [&](const float* wgt, float* y) { return NormEpilogue{1, wgt, nullptr, nullptr, nullptr, nullptr, dm.eps, y, (int64_t)dm.d_model}; };
+  // the decoder's normed rows `nx` feed linears only; in the bf16 mode those read the bf16 image, so the fp32 copy is not written
+  // (the final norm's rows `hl` go into the fp32 head dot: kept)
+  auto rms = [&](const float* wgt, float* y) {
+    return NormEpilogue{1, wgt, nullptr, nullptr, nullptr, nullptr, dm.eps, y, (int64_t)dm.d_model, (bf16 && y != hl) ? 1 : 0};
+  };
   auto ln = [&](const float* w1, const float* b1, float* y) {
     return NormEpilogue{2, w1, b1, nullptr, nullptr, nullptr, w->adaptor_eps, y, (int64_t)dm.d_model};
   };

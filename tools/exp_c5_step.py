@@ -57,7 +57,7 @@ o = retr._step_finish(st)
 torch.cuda.synchronize()
 t3 = time.perf_counter()
 out["one_step_split_ms"] = {"enqueue": round((t1 - t0) * 1e3, 2), "gpu_wait": round((t2 - t1) * 1e3, 2), "finish": round((t3 - t2) * 1e3, 2)}
-for depth in (1, 2, 3):
-    n = 6
+for depth in (1, 2, 3, 4):
+    n = 12
     out[f"stream_depth{depth}_ms_per_step"] = round(timed(lambda: list(retr.validation_steps(iter([batch] * n), depth=depth)), reps=3, warm=1) / n, 2)
 print(json.dumps(out))
