@@ -61,6 +61,8 @@ struct BeamBufs {
   int32_t* done;        // [B]
   int32_t* n_done;      // [1] queries whose beam search is done (generation_utils.py:827-829)
   int32_t* live;        // [1] 1 until n_done reaches B: the linears and the miss-row chain of later steps look at it
+  const int32_t* live_gate;  // = live when the call may skip the steps behind the last query's end (no per-step trace wanted), else
+                             // null: the attention / reduction / head / beam kernels of such a step exit at once through it
   int32_t* all_done_host;  // host-mapped word (may be null): receives `done_epoch` when n_done reaches B
   int32_t done_epoch;
 };
@@ -155,9 +157,11 @@ __device__ __forceinline__ float dfkey_inv(uint32_t k) {
 // logits[r][c] = sum_i (h[r][i] * d^-0.5) * (A[r][c*d + i] + E[c][i])      (modeling_t5.py:1575-1576,1637-1639)
 __global__ __launch_bounds__(256) void head_logits_kernel(const float* __restrict__ h, const float* __restrict__ A,
                                                           const float* __restrict__ E, int rows, int V1, int d,
-                                                          float scale, float* __restrict__ logits) {
+                                                          float scale, float* __restrict__ logits,
+                                                          const int32_t* __restrict__ live) {
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= (int64_t)rows * V1) return;
+  if (live && *live == 0) return;  // every query is done: these logits are never ranked
   const int r = (int)(item / V1), c = (int)(item % V1), lane = threadIdx.x & 63;
   const float4* h4 = reinterpret_cast<const float4*>(h + (size_t)r * d);
   const float4* a4 = reinterpret_cast<const float4*>(A + ((size_t)r * V1 + c) * d);
@@ -181,9 +185,10 @@ __global__ __launch_bounds__(256) void head_logits_table_kernel(const float* __r
                                                                 const int32_t* __restrict__ node,
                                                                 const int32_t* __restrict__ miss_index, int n_table,
                                                                 int rows, int V1, int d, float scale,
-                                                                float* __restrict__ logits) {
+                                                                float* __restrict__ logits, const int32_t* __restrict__ live) {
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= (int64_t)rows * V1) return;
+  if (live && *live == 0) return;  // every query is done: these logits are never ranked
   const int r = (int)(item / V1), c = (int)(item % V1), lane = threadIdx.x & 63;
   const float4* h4 = reinterpret_cast<const float4*>(h + (size_t)r * d);
   const int mi = miss_index[r];
@@ -263,6 +268,7 @@ __global__ __launch_bounds__(256) void prefix_fill_kernel(BeamBufs bb, int rows,
                                                           float* __restrict__ acache_slot, int64_t cache_layer_stride,
                                                           int n_layers, int d3) {
   const int r = blockIdx.x;
+  if (bb.live_gate && *bb.live_gate == 0) return;  // every query is done: nobody will look for ancestors in this step's slots
   const int mi = bb.miss_index[r];
   if (mi >= 0) {
     for (int p = threadIdx.x; p < stride; p += 256) bb.kv_rows_c[(size_t)mi * stride + p] = bb.kv_rows[(size_t)r * stride + p];
@@ -281,9 +287,11 @@ __global__ __launch_bounds__(256) void prefix_fill_kernel(BeamBufs bb, int rows,
 // of the decoder stack (modeling_t5.py:725, :164-171), arithmetic of rmsnorm_kernel (layers.hip).  One wave per row.
 __global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const float* __restrict__ table, const int64_t* __restrict__ tok,
                                                             int rows, int d4, int vocab, const float* __restrict__ w, float eps,
-                                                            float* __restrict__ xd, float* __restrict__ nx) {
+                                                            float* __restrict__ xd, float* __restrict__ nx,
+                                                            const int32_t* __restrict__ live) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (live && *live == 0) return;  // every query is done (beam_update_kernel): this step's rows are never read
   const int lane = threadIdx.x & 63;
   int64_t id = tok[row];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
@@ -358,6 +366,7 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims b
                                                         float* __restrict__ step_scores,
                                                         int32_t* __restrict__ step_tokens) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [npad]
+  if (bb.live_gate && *bb.live_gate == 0) return;  // uniform: every query is done, nothing is ranked any more
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int R = bd.R, V1 = bd.V + 1, nthr = blockDim.x, nwaves = blockDim.x >> 6;
   float* lse_max = reinterpret_cast<float*>(keys + npad);  // [R]
@@ -603,6 +612,9 @@ __device__ __forceinline__ void anc_update_query(const BeamBufs& bb, const BeamD
 __global__ __launch_bounds__(256) void beam_update_kernel(BeamBufs bb, BeamDims bd, int cur_len, int cur) {
   extern __shared__ __attribute__((aligned(16))) char bsm[];
   __shared__ int n_sh;
+  // every query was done BEFORE this step (the word is only cleared by a previous launch of this kernel): the step would pad
+  // every entry (:786-794) and nothing reads the padding — beam_finalize takes done queries from their hypothesis heaps
+  if (bb.live_gate && *bb.live_gate == 0) return;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int R = bd.R, ml = bd.maxlen;
   const int32_t* seq_c = bb.seq[cur];
@@ -1113,6 +1125,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   auto ctx_to = [&](AttnArgs& at_, Bf16Image& im, float* fp32_ctx) {
     if (bf16 && im.buf) at_.out = nullptr, at_.out_bf16 = im.buf, im.src = fp32_ctx;
     else at_.out = fp32_ctx;
+    at_.live = bb.live_gate;  // a step behind the last query's end: the attention launch exits at once
   };
   GDR_CHECK_ARG(!bf16 || (dm.d_model % 8 == 0 && dm.d_ff % 8 == 0 && (dm.num_heads * dm.d_kv) % 8 == 0 && w->adaptor_ff % 8 == 0),
                 "generate(bf16): dims must be multiples of 8");
@@ -1176,6 +1189,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       bb.all_done_host = done_word, bb.done_epoch = my_epoch;  // travels with every beam_update launch
     }
     sk1.live = sk2.live = bb.live;  // the device-side half: steps already enqueued when the last query finishes skip their work
+    bb.live_gate = bb.live;         // ... and so do their attention, reduction, head and beam bookkeeping launches
   }
   SideLease lease;
   struct { bool ok; hipStream_t s; hipEvent_t fork, join; } ss{lease.ss != nullptr, lease.ss ? lease.ss->s : nullptr,
@@ -1225,7 +1239,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
     const int rows_s = (s == 0 && dedup0) ? B : rows;
     const int R_s = (s == 0 && dedup0) ? 1 : num_beams;
     hipLaunchKernelGGL(embed_rmsnorm_kernel, dim3((unsigned)((rows_s + 3) / 4)), dim3(256), 0, stream, w->dec_embed, bb.cur_tok, rows_s,
-                       d / 4, dm.vocab_size, w->layers[0].ln_self, dm.eps, xd, nx);
+                       d / 4, dm.vocab_size, w->layers[0].ln_self, dm.eps, xd, nx, sk1.live);
     GDR_CHECK_LAUNCH("embed_rmsnorm_kernel");
     if (ss.ok) {
       if (hipEventRecord(ss.fork, stream) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess) {
@@ -1412,12 +1426,12 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       GDR_TRY(LIN(xa, d, hw, d, A, (int64_t)V1 * d, rows_s, V1 * d, d, GDR_EPI_NONE, nullptr, nullptr, 0));
       const int64_t items = (int64_t)rows_s * V1;
       hipLaunchKernelGGL(head_logits_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, hl, A, he, rows_s, V1, d,
-                         1.0f / sqrtf((float)d), bb.logits);
+                         1.0f / sqrtf((float)d), bb.logits, bb.live_gate);
       GDR_CHECK_LAUNCH("head_logits_kernel");
     } else {
       const int64_t items = (int64_t)rows_s * V1;
       hipLaunchKernelGGL(head_logits_table_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, hl, A, he, ptab->W,
-                         bb.node[cur], bb.miss_index, ptab->n_table, rows_s, V1, d, 1.0f / sqrtf((float)d), bb.logits);
+                         bb.node[cur], bb.miss_index, ptab->n_table, rows_s, V1, d, 1.0f / sqrtf((float)d), bb.logits, bb.live_gate);
       GDR_CHECK_LAUNCH("head_logits_table_kernel");
     }
     GDR_TRY(beam_step(bb, bd, s, cur, step_scores, step_tokens, stream, s == 0 && dedup0));

@@ -169,7 +169,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const float* _
                                                                   int64_t M, int N, float* __restrict__ C, int64_t ldc,
                                                                   const float* __restrict__ bias,
                                                                   const float* __restrict__ residual, int64_t ldr,
-                                                                  int act, const int64_t* __restrict__ m_dev) {
+                                                                  int act, const int64_t* __restrict__ m_dev,
+                                                                  const int32_t* __restrict__ live) {
+  if (live && *live == 0) return;  // every query of the generate call is done (StreamK::live): the slabs were never written
   if (m_dev) M = *m_dev;
   const int tile = blockIdx.x >> 2;
   const int e = ((blockIdx.x & 3) << 8) + threadIdx.x;  // float4 index inside the tile: 64 rows x 16 float4
@@ -222,8 +224,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_row_kernel(const float
                                                                     int64_t M, int N, float* __restrict__ C, int64_t ldc,
                                                                     const float* __restrict__ bias,
                                                                     const float* __restrict__ residual, int64_t ldr, int act,
-                                                                    const int64_t* __restrict__ m_dev, const NormEpilogue ne) {
+                                                                    const int64_t* __restrict__ m_dev, const NormEpilogue ne,
+                                                                    const int32_t* __restrict__ live) {
   __shared__ float red[4];
+  if (live && *live == 0) return;  // uniform: every query of the generate call is done
   if (m_dev) M = *m_dev;
   const int64_t m = blockIdx.x;
   if (m >= M) return;  // uniform
@@ -347,12 +351,12 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
     const float* bp = has_bias ? bias : nullptr;
     const float* rp = has_residual ? residual : nullptr;
     hipLaunchKernelGGL(splitk_reduce_norm_row_kernel, dim3((unsigned)M), dim3(256), 0, stream, ws, S, tiles_n, M, N, C, ldc, bp, rp,
-                       ldr, act, m_dev, *ne);
+                       ldr, act, m_dev, *ne, live);
     GDR_CHECK_LAUNCH("splitk_reduce_norm_row_kernel");
     return 0;
   }
   hipLaunchKernelGGL(splitk_reduce_small_kernel, dim3((unsigned)(tiles * 4)), dim3(256), 0, stream, ws, S, tiles_n, M, N, C, ldc,
-                     has_bias ? bias : nullptr, has_residual ? residual : nullptr, ldr, act, m_dev);
+                     has_bias ? bias : nullptr, has_residual ? residual : nullptr, ldr, act, m_dev, live);
   GDR_CHECK_LAUNCH("splitk_reduce_small_kernel");
   return 0;
 }

@@ -47,6 +47,9 @@ struct AttnArgs {
   // query element (row m, column n) is the sum over s < q_S of the slabs, in order, and `q` is not read
   const float* q_part;
   int q_S, q_tiles_n;
+  // decode only, may be null: the generate call's "some query is still undecided" word (common.h StreamK::live); 0 = every
+  // query is done (generation_utils.py:836-838), the launch exits at once — its output is never read
+  const int32_t* live;
 };
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 

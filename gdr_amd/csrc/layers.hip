@@ -468,6 +468,7 @@ int launch_layernorm_dev(const float* x, const float* w, const float* b, float* 
 // the 4 waves then walks query rows: lane j scores keys j and j+64, softmax by wave shuffles, PV with lane = d.
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (a.live && *a.live == 0) return;  // uniform: every query of the generate call is done
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int dk = a.dk, dks = dk + 4, c4 = dk >> 2;
   const int Lk = a.Lk, Lkp = (Lk + 3) & ~3;
@@ -1017,6 +1018,7 @@ static int launch_attention_mfma16(const AttnArgs& a, hipStream_t stream) {
 template <int NT>  // 16-key tiles: ceil(Lk / 16), 1..8
 __global__ __launch_bounds__(512) void attention_cross_mfma16_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (a.live && *a.live == 0) return;  // uniform: every query of the generate call is done
   constexpr int DK = 64, DS = DK + 4, LP = 16 * NT;
   const int Lk = a.Lk, Lq = a.Lq;
   float* Ks = smem;
@@ -1169,6 +1171,7 @@ __global__ __launch_bounds__(256) void attention_decode_rows_kernel(const AttnAr
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + wave;
   if (item >= a.B * a.H) return;
+  if (a.live && *a.live == 0) return;  // every query of the generate call is done
   const int b = item / a.H, h = item % a.H;
   if (a.b_count_dev && b >= (int)*a.b_count_dev) return;  // only the first *b_count_dev batch entries are live
   const int dk = a.dk, c4 = dk >> 2, Lk = a.Lk, kb = b / a.kv_group;
