@@ -10,3 +10,11 @@ B=2048 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/gen_b2048" 
 cd "$ROOT"
 find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
 find "$OUT" -name "*.db" -delete
+# MFMA-busy of the bf16 precision mode's kernels (the C2 step with bf16 linears / bf16-MFMA attention / bf16 similarity)
+cd /tmp
+B16="python3 $ROOT/bench.py --dtype bf16 --no-cpu-baseline --no-recall --no-stages --steps 2 --warmup 1"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_mfma_bf16" -- $B16 > "$OUT/pmc_mfma_bf16.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_bf16" -- $B16 > "$OUT/stats_bf16.log" 2>&1
+cd "$ROOT"
+find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
+find "$OUT" -name "*.db" -delete

@@ -174,3 +174,22 @@ if m:
     print(open(f"profiles/{tag}_generate_mfma_busy.md").read())
 print(open(f"profiles/{tag}_mfma_busy.md").read())
 print(open(f"profiles/{tag}_bench_pmc_hbm.md").read()[-3000:])
+
+# ---------------------------------------------------------------------------------------------- the bf16 precision mode's kernels
+copy("stats_bf16/*/*kernel_stats.csv", f"{tag}_bench_bf16_kernel_stats.csv")
+m = counters("pmc_mfma_bf16/*/*counter_collection.csv")
+if m:
+    with open(f"profiles/{tag}_bf16_mfma_busy.md", "w") as o:
+        o.write(f"# {tag} — MFMA utilisation of the bf16 precision mode's kernels (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES on "
+                "`bench.py --dtype bf16 --no-cpu-baseline --no-recall --no-stages --steps 2 --warmup 1`)\n\n" + NORM +
+                "bf16 MFMA peak: 2.5 PFLOP/s dense.  `grid` = threads.\n\n"
+                "| kernel | grid | launches | avg us | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES | busy cycles / duration (GHz) | MFMA busy |\n|---|---|---|---|---|---|---|---|\n")
+        for k in sorted(m, key=lambda k: -sum(m[k]["dur_ns"])):
+            if not any(s_ in k[0] for s_ in ("gemm_nt", "attention_mfma")):
+                continue
+            dur = avg(m[k]["dur_ns"])
+            busy = avg(m[k]["SQ_VALU_MFMA_BUSY_CYCLES"])
+            sqc = avg(m[k]["SQ_BUSY_CYCLES"]) / 32.0
+            o.write(f"| `{short(k[0])[:56]}` | {k[1]} | {len(m[k]['dur_ns'])} | {dur / 1e3:.1f} | {busy:.3e} | {avg(m[k]['SQ_BUSY_CYCLES']):.3e} | "
+                    f"{sqc / dur:.2f} | {busy / (1024 * sqc) if sqc else 0.0:.3f} |\n")
+    print(open(f"profiles/{tag}_bf16_mfma_busy.md").read())
