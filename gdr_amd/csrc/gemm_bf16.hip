@@ -499,174 +499,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
   }
 }
 #pragma clang diagnostic pop
-// The same 256 x 256 schedule as a PERSISTENT kernel (round-3 lab, adopted in round 4 for the wide bf16-OUTPUT linears — qkv and the FFN's
-// first linear of a big batch): workgroup b takes tiles b, b + G, ... and runs their K-tiles as one flattened stream — the prefetch
-// of a tile's last two K-tiles already stages the next tile's first two, and the epilogue's stores (half the bytes with a bf16 output)
-// drain under the next tile's MFMAs.  32-bit operand offsets + SGPR bases (global_load_lds ... saddr) keep two tiles' pointers affordable;
-// the live tile count comes from the device-side row count.  Same k order per output element: bit-identical to the other forms.
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-#define GLDS16S(off_, base_, lds_) \
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_), "v"(off_), "s"(base_) : "memory", "m0")
-
-__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256p_kernel(const Bf16GemmArgs g) {
-  extern __shared__ __attribute__((aligned(1024))) char smem256[];
-  unsigned bid = blockIdx.x;
-  {
-    const unsigned nblk = gridDim.x, q_ = nblk >> 3, r_ = nblk & 7u, xcd_ = bid & 7u, j_ = bid >> 3;
-    bid = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + j_;
-  }
-  const int G = (int)gridDim.x;
-  const int64_t Mv = g.m_dev ? *g.m_dev : g.M;   // live rows (device-side count of a packed batch)
-  const int tiles_n = (g.N + 255) / 256;
-  const int total_tiles = (int)((Mv + 255) / 256) * tiles_n;
-  int tile = (int)bid;
-  if (tile >= total_tiles) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wr = wave >> 2, wc = wave & 3, r16 = lane & 15, q4 = lane >> 4;
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem256));
-  const int srow = lane >> 3, schunk = lane & 7;
-  unsigned a_lo[2], a_hi[2], b_lo[2], b_hi[2];  // byte offsets from g.A / g.W of this thread's two DMA pieces per half-tile
-#define SET_A(dst_, t_, h_)                                                          \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                    \
-    const int lr = (wave * 2 + i) * 8 + srow;                                        \
-    int64_t ra = (int64_t)((t_) / tiles_n) * 256 + (lr >> 6) * 128 + (h_)*64 + (lr & 63); \
-    ra = ra < Mv ? ra : Mv - 1;                                                      \
-    dst_[i] = (unsigned)((ra * g.lda) * 2 + ((schunk ^ ((lr >> 1) & 7)) << 4));      \
-  }
-#define SET_B(dst_, t_, h_)                                                          \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                    \
-    const int lr = (wave * 2 + i) * 8 + srow;                                        \
-    int rb = ((t_) % tiles_n) * 256 + (lr >> 5) * 64 + (h_)*32 + (lr & 31);          \
-    rb = rb < g.N ? rb : g.N - 1;                                                    \
-    dst_[i] = (unsigned)(((int64_t)rb * g.ldw) * 2 + ((schunk ^ ((lr >> 1) & 7)) << 4)); \
-  }
-  SET_A(a_lo, tile, 0) SET_A(a_hi, tile, 1) SET_B(b_lo, tile, 0) SET_B(b_hi, tile, 1)
-  const unsigned st_dst = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 2048;
-#define STAGE_S(off_, base_, half_off_, buf_, kt_)                                                \
-  {                                                                                               \
-    const unsigned koff_ = (unsigned)(kt_) * 128u;                                                \
-    GLDS16S(off_[0] + koff_, base_, st_dst + (buf_)*BUF_BYTES + (half_off_));                     \
-    GLDS16S(off_[1] + koff_, base_, st_dst + (buf_)*BUF_BYTES + (half_off_) + 1024);              \
-  }
-  const int sw = (r16 >> 1) & 7;
-  const int c0 = (q4 ^ sw) << 4;
-  const char* const fa_base = smem256 + (wr * 64 + r16) * 128 + c0;
-  const char* const fb_base = smem256 + (wc * 32 + r16) * 128 + c0;
-  float4 fa[4][2], fbl[2][2], fbh[2][2];
-  f32x4b acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4b){0.f, 0.f, 0.f, 0.f};
-  const int nk = g.K >> 6;  // even
-  STAGE_S(b_lo, g.W, OFF_B_LO, 0, 0)
-  STAGE_S(a_lo, g.A, OFF_A_LO, 0, 0)
-  STAGE_S(b_hi, g.W, OFF_B_HI, 0, 0)
-  STAGE_S(a_hi, g.A, OFF_A_HI, 0, 0)
-  STAGE_S(b_lo, g.W, OFF_B_LO, 1, 1)
-  STAGE_S(a_lo, g.A, OFF_A_LO, 1, 1)
-  STAGE_S(b_hi, g.W, OFF_B_HI, 1, 1)
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  BAR()
-  if (wr == 1) BAR()
-  // one K-tile = four phases; BUF is its buffer, KA the K-tile whose A_hi phase 1 stages (into the other buffer), K2 the K-tile
-  // whose B_lo / A_lo / B_hi phases 2-4 stage (into this buffer)
-#define KTILE(BUF, KA, K2)                                    \
-  READ_B(fbl, BUF, OFF_B_LO)                                  \
-  __builtin_amdgcn_sched_barrier(0);                          \
-  READ_A(BUF, OFF_A_LO)                                       \
-  STAGE_S(a_hi, g.A, OFF_A_HI, (BUF) ^ 1, KA)                 \
-  asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");          \
-  BAR()                                                       \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
-  __builtin_amdgcn_sched_barrier(0);                          \
-  MFMA_Q(0, 0, fbl)                                           \
-  BAR()                                                       \
-  READ_B(fbh, BUF, OFF_B_HI)                                  \
-  STAGE_S(b_lo, g.W, OFF_B_LO, BUF, K2)                       \
-  BAR()                                                       \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
-  __builtin_amdgcn_sched_barrier(0);                          \
-  MFMA_Q(0, 1, fbh)                                           \
-  BAR()                                                       \
-  READ_A(BUF, OFF_A_HI)                                       \
-  STAGE_S(a_lo, g.A, OFF_A_LO, BUF, K2)                       \
-  BAR()                                                       \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
-  __builtin_amdgcn_sched_barrier(0);                          \
-  MFMA_Q(1, 1, fbh)                                           \
-  BAR()                                                       \
-  STAGE_S(b_hi, g.W, OFF_B_HI, BUF, K2)                       \
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            \
-  BAR()                                                       \
-  MFMA_Q(1, 0, fbl)                                           \
-  BAR()
-  for (;;) {
-    const int nxt = tile + G < total_tiles ? tile + G : tile;  // no successor: the stream re-stages this tile's first K-tiles (never read)
-    for (int kt = 0; kt < nk; kt += 2) {
-      const bool last = kt + 2 == nk;
-      if (last) {  // phases 2-4 of this K-tile stage the successor's K-tile 0
-        SET_A(a_lo, nxt, 0) SET_B(b_lo, nxt, 0) SET_B(b_hi, nxt, 1)
-      }
-      KTILE(0, kt + 1, last ? 0 : kt + 2)
-      if (last) {  // phase 1 of the odd K-tile stages the successor's A_hi of K-tile 0
-        SET_A(a_hi, nxt, 1)
-      }
-      KTILE(1, last ? 0 : kt + 2, last ? 1 : kt + 3)
-    }
-    // ---- epilogue: row m = m0 + wr*128 + mi*16 + r16, columns n0 + wc*64 + ni*16 + 4*q4 + 0..3
-    {
-      const int64_t m0 = (int64_t)(tile / tiles_n) * 256;
-      const int n0 = (tile % tiles_n) * 256;
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) {
-        const int64_t m = m0 + wr * 128 + mi * 16 + r16;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int n = n0 + wc * 64 + ni * 16 + 4 * q4;
-          float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-          acc[mi][ni] = (f32x4b){0.f, 0.f, 0.f, 0.f};
-          if (m >= Mv || n >= g.N) continue;
-          if (g.has_bias) {
-            const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
-            v[0] += b.x, v[1] += b.y, v[2] += b.z, v[3] += b.w;
-          }
-          if (g.has_residual) {
-            const float4 r = *reinterpret_cast<const float4*>(g.residual + m * g.ldr + n);
-            v[0] += r.x, v[1] += r.y, v[2] += r.z, v[3] += r.w;
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (g.act == 1) v[j] = fmaxf(v[j], 0.f);
-            if (g.act == 2) v[j] = gelu_erf_b(v[j]);
-          }
-          if (g.out_bf16) {
-            union {
-              __bf16 h[4];
-              uint2 u;
-            } o;
-            o.h[0] = (__bf16)v[0], o.h[1] = (__bf16)v[1], o.h[2] = (__bf16)v[2], o.h[3] = (__bf16)v[3];
-            *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(g.C) + m * g.ldc + n) = o.u;
-          } else {
-            *reinterpret_cast<float4*>(g.C + m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-          }
-        }
-      }
-    }
-    if (nxt == tile) break;
-    tile = nxt;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (wr == 0) BAR()
-}
-
-#pragma clang diagnostic pop
-#undef GLDS16S
-#undef SET_A
-#undef SET_B
-#undef STAGE_S
-#undef KTILE
 #undef GLDS16
 #undef STAGE
 #undef READ_A
@@ -700,16 +532,6 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
     if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_nt_bf16_tile256_kernel), 2 * BUF_BYTES, "linear_bf16")) return rc__;
     hipLaunchKernelGGL(gemm_nt_bf16_tile256_kernel, dim3((unsigned)b256), dim3(512), 2 * BUF_BYTES, stream, g);
     GDR_CHECK_LAUNCH("gemm_nt_bf16_tile256_kernel");
-    return 0;
-  }
-  // wide bf16-output linears of a big batch: the persistent form of the 256^2 tile (its gain in the lab: qkv 65.6 -> 56.3 us, wi
-  // 87.8 -> 82.6 us at 12 308 rows)
-  if (out_bf16 && N >= 2048 && M >= 8192 && K % 128 == 0 && N % 4 == 0 && (ldc & 3) == 0 && !has_residual &&
-      M * lda * 2 < 0xffffffffLL && (int64_t)N * ldw * 2 < 0xffffffffLL) {
-    if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_nt_bf16_tile256p_kernel), 2 * BUF_BYTES, "linear_bf16")) return rc__;
-    const int64_t t256 = ((M + 255) / 256) * (int64_t)((N + 255) / 256);
-    hipLaunchKernelGGL(gemm_nt_bf16_tile256p_kernel, dim3((unsigned)(t256 < 256 ? t256 : 256)), dim3(512), 2 * BUF_BYTES, stream, g);
-    GDR_CHECK_LAUNCH("gemm_nt_bf16_tile256p_kernel");
     return 0;
   }
   // fewer than 2 tiles of 128 rows per CU: 64-row tiles (same k order per output element: bit-identical results)
