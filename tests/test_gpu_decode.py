@@ -138,14 +138,14 @@ def test_generate_with_wide_heads_takes_the_generic_decode_attention(dev):
     assert np.array_equal(dec.cpu().numpy(), rd.numpy())
 
 
-@pytest.mark.parametrize("B,R,L", [(520, 3, 40), (130, 20, 23)])
+@pytest.mark.parametrize("B,R,L", [(520, 3, 40), (130, 20, 23), (16, 100, 12)])
 def test_generate_many_queries_takes_the_mfma_cross_attention_vs_oracle(dev, B, R, L):
     """With finished q rows (the bf16 mode, or more than 1 536 beam rows in fp32: below that the attention sums the q
     projection's split-K slabs itself in the generic kernel) the beam rows' cross-attention over the encoder states
     (T5Attention, modeling_t5.py:316-421) runs as attention_cross_mfma16_kernel — S^T = K.Q^T and P.V on MFMA, a wave per 16
     beam rows: same scores, bias, mask and softmax as the generic lane-per-key kernel, another summation order.  t5-base widths
     (12 heads, d_kv = 64) with two encoder / decoder blocks so that the CPU oracle stays cheap; ragged lengths (masked keys),
-    one and two 16-row tiles, key counts that are not multiples of 16."""
+    one, two and seven 16-row tiles (infer.sh's 100 beams: 1 600 beam rows), key counts that are not multiples of 16."""
     from gdr_amd.modeling import GDRModel
     from oracle import beam_ref
     cfg = GDRConfig.base()
