@@ -61,7 +61,8 @@ def _run(**env):
 
 def test_decode_scheduling_switches_do_not_change_generate():
     base = _run()
-    n_exits, done_step = base.pop("early_exits"), base.pop("last_done_step")
+    base.pop("early_exits")            # the host half races with the GPU by design: not asserted (the device half below is)
+    done_step = base.pop("last_done_step")
     # the device half of `if all(done): break` is deterministic: beams constrained to the 30 000-doc corpus' trie (docids of
     # depth 3) are all finished — EOS forced — by step depth + 2, and the kernel that sees the last query finish records it
     assert 0 < done_step <= 3 + 2, done_step
@@ -70,7 +71,6 @@ def test_decode_scheduling_switches_do_not_change_generate():
     full = _run(GDR_DECODE_EARLY_EXIT="0")
     assert full.pop("early_exits") == 0 and full.pop("last_done_step") == 0
     assert full == base, "leaving the step loop when every query is done must not change any output"
-    assert n_exits >= 0
     # GDR_DECODE_DEDUP0=0 runs step 0 on all B*R identical beam rows instead of one row per query: the same numbers from
     # launches of another shape (other split-K factors), i.e. fp32 summation order only
     # GDR_DECODE_SLAB_Q=0 reduces the cross-attention q projection in a launch of its own; the attention then gets finished q
