@@ -250,7 +250,7 @@ def inference(args):
                                      num_return_sequences=R, early_stopping=False, decode_embedding=args.decode_embedding,
                                      decode_vocab_size=args.output_vocab_size * args.max_output_length + 2)
             dec = codec.dec_2d(codec.decode_token(args, outs.cpu().numpy()), R)
-            for j, pred in enumerate(dec):                       # main.py:227-238
+            for j, pred in enumerate(dec[:hi - lo]):             # main.py:227-238 (a padded short batch: its real rows only)
                 inf_result_cache.append([texts[lo + j], ",".join(pred), data["gt_cluster"][lo + j], 1])
     torch.cuda.synchronize()
     t_model = time.perf_counter() - t0

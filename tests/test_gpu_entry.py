@@ -138,7 +138,8 @@ def test_main_eval_sharded_two_stage_under_one_rank_rccl_equals_unsharded(tmp_pa
     assert open(a + ".docs.tsv").read() == open(b + ".docs.tsv").read() and len(_read_tsv(a + ".docs.tsv")) == 70
 
 
-def test_main_eval_n_gpu_2_ranks_sharing_one_gpu_equals_the_one_process_run(tmp_path):
+@pytest.mark.parametrize("two_stage", [1, 0])
+def test_main_eval_n_gpu_2_ranks_sharing_one_gpu_equals_the_one_process_run(tmp_path, two_stage):
     """`--n_gpu 2` with REAL compute on both ranks: the launcher starts two rank processes that share this box's one GPU
     (`--dist_backend gloo`: RCCL refuses two ranks on one device; gloo stages the same collectives through the host).  Rank r holds
     rows [lo, hi) of the corpus (cluster-aligned), decodes spans r, r + 2, ... (10 queries in batches of 4: three spans — rank 1 runs
@@ -148,14 +149,17 @@ def test_main_eval_n_gpu_2_ranks_sharing_one_gpu_equals_the_one_process_run(tmp_
     1574-1637; per-GPU launch: bert_NQ.sh:5-12)."""
     a, b = str(tmp_path / "a.tsv"), str(tmp_path / "b.tsv")
     argv = INFER_SH + ["--infer_ckpt", "", "--num_return_sequences", "10", "--eval_batch_size", "4", "--corpus_rows", "30000",
-                       "--n_queries", "10", "--constrain_tree", "1"]
+                       "--n_queries", "10", "--constrain_tree", "1", "--is_train_encoder", str(two_stage)]
     argv2 = [x for x in argv]
     argv2[argv2.index("--n_gpu") + 1] = "2"
     out = _run_main(argv2 + ["--dist_backend", "gloo", "--res1_save_path", a])
     assert "2 GPU(s)" in out and "GDR_RESULT " in out
     _run_main(argv + ["--res1_save_path", b])
     assert open(a).read() == open(b).read() and len(_read_tsv(a)) == 10
-    assert open(a + ".docs.tsv").read() == open(b + ".docs.tsv").read() and len(_read_tsv(a + ".docs.tsv")) == 70
+    if two_stage:
+        assert open(a + ".docs.tsv").read() == open(b + ".docs.tsv").read() and len(_read_tsv(a + ".docs.tsv")) == 70
+    else:            # --is_train_encoder 0: stage 1 only (main.py:171-238) — data-parallel generate(), rows reassembled in span order
+        assert not os.path.exists(a + ".docs.tsv")
 
 
 def test_main_eval_missing_checkpoint_is_an_error(tmp_path):
