@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDR_HIP_LIB") or os.path.join(_HERE, "libgdr_hip.so")   # override: A/B builds in the lab
 
 GDR_OK, GDR_EINVAL, GDR_ENOSPC, GDR_EHIP = 0, -1, -2, -3
-ABI_VERSION = 5                  # what this binding was written against (gdr_abi_version(), csrc/common.hip)
+ABI_VERSION = 6                  # what this binding was written against (gdr_abi_version(), csrc/common.hip)
 RERANK_POSITIONS = 1
 SIM_EXHAUSTIVE = 1
 SIM_NO_STREAM = 2
@@ -94,6 +94,7 @@ SIGNATURES = {
     "gdr_linear_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "gdr_linear_f32_splitk": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "gdr_l2_normalize": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
+    "gdr_t5_layer_norm": (_i, [_vp, _vp, _vp, _i64, _i, _f, _vp]),
     "gdr_t5_encoder_workspace_bytes": (_sz, [C.POINTER(GdrT5Dims), _i, _i]),
     "gdr_t5_encoder_forward": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "gdr_t5_encoder_ragged_workspace_bytes": (_sz, [C.POINTER(GdrT5Dims), _i, _i]),

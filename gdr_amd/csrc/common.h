@@ -130,4 +130,54 @@ int launch_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, hipStream_t
 bool sim_stream_supported(int B, int d, bool bf16);
 int launch_sim_stream(const float* D, int64_t N, const float* Q, int B, int d, const SimEpilogue& ep, hipStream_t stream);
 
+// Sums / maxima over the 64 lanes as the xor butterfly 32, 16, 8, 4, 2, 1 (every lane ends with the total).  The four steps
+// inside a row of 16 lanes are DPP row rotations: after the xor-16 step the values have period 16, so "rotate by 8" pairs lane i
+// with lane i ^ 8 exactly; the values then have period 8 inside the row, so "rotate by 4" meets the partner "xor 4" would
+// (a + b in the same order up to commutation), and so on down — the result is the xor butterfly's, bit for bit, at one
+// VALU instruction per step instead of an LDS permute and its address arithmetic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {  // == v += shfl_xor(v, 8), 4, 2, 1 — same pairs, same bits
+  v += dpp_row<0x128>(v);
+  v += dpp_row<0x124>(v);
+  v += dpp_row<0x122>(v);
+  v += dpp_row<0x121>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_row<0x128>(v));
+  v = fmaxf(v, dpp_row<0x124>(v));
+  v = fmaxf(v, dpp_row<0x122>(v));
+  v = fmaxf(v, dpp_row<0x121>(v));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __shfl_xor(v, 32);
+  v += __shfl_xor(v, 16);
+  return row16_sum(v);
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 32));
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return row16_max(v);
+}
+// x / b for many x and one b > 0 (a norm's denominator): r = RN(1 / b) once — the hardware reciprocal and one Newton step —,
+// then per element q = x * r, the exact residual e = x - b * q (one fma) and q + e * r: the correctly rounded quotient
+// (Markstein: a faithful q corrected with the correctly rounded reciprocal), i.e. the bits of the IEEE division the reference's
+// `x / torch.sqrt(variance + eps)` (modeling_t5.py:167) produces, at 3 VALU instructions instead of the ~11 of a full
+// division.  Finite operands in the normal range only (a row with an inf / nan is garbage in the reference too).
+struct RowDivisor {
+  float b, r;
+  __device__ __forceinline__ explicit RowDivisor(float b_) : b(b_) {
+    const float y = __builtin_amdgcn_rcpf(b_);
+    r = fmaf(fmaf(-b_, y, 1.0f), y, y);
+  }
+  __device__ __forceinline__ float operator()(float x) const {
+    const float q = x * r;
+    return fmaf(fmaf(-b, q, x), r, q);
+  }
+};
+
 }  // namespace gdr

@@ -121,4 +121,4 @@ extern "C" const char* gdr_last_error(void) { return gdr::g_err; }
 // 4: gdr_t5_generate_early_exits added (gdr_t5_generate leaves its step loop when every query is done);
 //    GdrPrefixTable.complete_levels
 // 5: gdr_rerank_wire_pack / _unpack / gdr_rerank_positions_to_ids (the sharded two-stage path's exchange row)
-extern "C" int gdr_abi_version(void) { return 5; }
+extern "C" int gdr_abi_version(void) { return 6; }

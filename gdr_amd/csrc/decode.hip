@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void head_logits_kernel(const float* __restric
     acc = fmaf(hv.z * scale, av.z + ev.z, acc);
     acc = fmaf(hv.w * scale, av.w + ev.w, acc);
   }
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  acc = wave_sum(acc);
   if (lane == 0) logits[item] = acc;
 }
 
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void head_logits_table_kernel(const float* __r
       acc = fmaf(hv.w * scale, av.w + ev.w, acc);
     }
   }
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  acc = wave_sum(acc);
   if (lane == 0) logits[item] = acc;
   (void)n_table;
 }
@@ -303,14 +303,13 @@ __global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const float* __restr
     xr[c] = v;
     ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  const float denom = sqrtf(ss / (float)(d4 * 4) + eps);
+  ss = wave_sum(ss);
+  const RowDivisor over(sqrtf(ss / (float)(d4 * 4) + eps));  // x / denom, bit for bit (common.h)
   float4* yr = reinterpret_cast<float4*>(nx) + (int64_t)row * d4;
   const float4* wr = reinterpret_cast<const float4*>(w);
   for (int c = lane; c < d4; c += 64) {
     const float4 v = src[c], g = wr[c];
-    yr[c] = make_float4(g.x * (v.x / denom), g.y * (v.y / denom), g.z * (v.z / denom), g.w * (v.w / denom));
+    yr[c] = make_float4(g.x * over(v.x), g.y * over(v.y), g.z * over(v.z), g.w * over(v.w));
   }
 }
 
@@ -380,10 +379,10 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(BeamBufs bb, BeamDims b
     const float* lg = lg_s + j * V1;
     float mx = -INFINITY;
     for (int c = lane; c < V1; c += 64) mx = fmaxf(mx, lg[c]);
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max(mx);
     float sm = 0.f;
     for (int c = lane; c < V1; c += 64) sm += expf(lg[c] - mx);
-    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+    sm = wave_sum(sm);
     if (lane == 0) {
       lse_max[j] = mx;
       lse_log[j] = logf(sm);

@@ -258,8 +258,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_row_kernel(const float
     *reinterpret_cast<float4*>(C + m * ldc + n) = v;
   }
   auto block_sum = [&](float x) {  // every thread gets the sum over the workgroup (fixed order: lanes by butterfly, waves 0..3)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    x = wave_sum(x);
     __syncthreads();  // the previous reduction's reads are done
     if ((tid & 63) == 0) red[wave] = x;
     __syncthreads();
@@ -268,11 +267,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_row_kernel(const float
   float* yr = ne.Y + m * ne.ldy;
   if (ne.kind == 1) {
     const float ss = block_sum(on ? v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w : 0.f);
-    const float denom = sqrtf(ss / (float)N + ne.eps);
+    const RowDivisor over(sqrtf(ss / (float)N + ne.eps));  // x / denom, bit for bit (common.h)
     if (on) {
       const float4 g = reinterpret_cast<const float4*>(ne.w1)[tid];
-      *reinterpret_cast<float4*>(yr + 4 * tid) = make_float4(g.x * (v.x / denom), g.y * (v.y / denom), g.z * (v.z / denom),
-                                                             g.w * (v.w / denom));
+      *reinterpret_cast<float4*>(yr + 4 * tid) = make_float4(g.x * over(v.x), g.y * over(v.y), g.z * over(v.z), g.w * over(v.w));
     }
     return;
   }

@@ -31,17 +31,6 @@ BucketLut make_bucket_lut(int nb, int max_distance) {
   return l;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-
 // ------------------------------------------------------------------------------------------ embed
 __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids,
                                                     int64_t rows, int d4, int vocab, float* __restrict__ out) {
@@ -256,7 +245,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     }
   }
   ss = wave_sum(ss);
-  const float denom = sqrtf(ss / (float)(d4 * 4) + eps);
+  const RowDivisor over(sqrtf(ss / (float)(d4 * 4) + eps));
   float4* yr = reinterpret_cast<float4*>(y) + row * d4;
   float4* pr = (pooled && row % pool_every == 0) ? reinterpret_cast<float4*>(pooled) + (row / pool_every) * d4
                                                   : nullptr;
@@ -264,7 +253,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   auto emit = [&](int c, const float4 v) {
     const float4 g = wr[c];
     float4 o;
-    o.x = g.x * (v.x / denom), o.y = g.y * (v.y / denom), o.z = g.z * (v.z / denom), o.w = g.w * (v.w / denom);
+    o.x = g.x * over(v.x), o.y = g.y * over(v.y), o.z = g.z * over(v.z), o.w = g.w * over(v.w);
     if (BF16OUT) {
       (reinterpret_cast<uint2*>(y) + row * d4)[c] = pack_bf16x4(o.x, o.y, o.z, o.w);
     } else {
@@ -1212,67 +1201,10 @@ __global__ __launch_bounds__(256) void attention_decode_rows_kernel(const AttnAr
   auto row_of = [&](int j) -> int64_t {
     return a.kv_rows ? (int64_t)a.kv_rows[(int64_t)b * Lk + j] : (int64_t)kb * a.k_bstride + j;
   };
-  // Short key lists (a decode step: Lk <= max_length, ancestors reached through kv_rows): every memory operand of the wave is
-  // requested up front — lane j fetches the row index of key j, a shuffle hands it to the lanes that read that row, and all
-  // K AND V rows (V does not depend on the scores) are in flight together — instead of index -> K row -> ... -> index -> V row as
-  // four dependent round trips per RPI keys.  The arithmetic below is unchanged (same order: bit-identical results).
-  constexpr int MAXIT = LPR == 16 ? 4 : 6;  // 16 / 12 keys: a decode step has <= max_length (10); 64 VGPRs of operands at 8
-                                            // iterations cost three waves per SIMD of occupancy for nothing
-  const bool pre = Lk <= MAXIT * RPI;
-  float4 kreg[MAXIT], vreg[MAXIT];
-  if (pre) {
-    int myrow = 0;
-    if (lane < Lk) myrow = (int)row_of(lane);
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      const int j = it * RPI + g;
-      const int rj = __shfl(myrow, j < Lk ? j : 0);
-      kreg[it] = make_float4(0.f, 0.f, 0.f, 0.f), vreg[it] = kreg[it];
-      if (j < Lk && col_ok) {
-        kreg[it] = *reinterpret_cast<const float4*>(a.k + (int64_t)rj * a.ldk + h * dk + 4 * c);
-        vreg[it] = *reinterpret_cast<const float4*>(a.v + (int64_t)rj * a.ldv + h * dk + 4 * c);
-      }
-    }
-  }
-  // ---- scores: key j = j0 + g, its row read by the LPR lanes of group g
+  // ---- scores: key j = j0 + g, its row read by the LPR lanes of group g (short key lists — a decode step — take
+  // attention_decode_short_kernel below)
   float mx = -INFINITY;
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    const int j0 = it * RPI;
-    if (!pre || j0 >= Lk) break;
-    const int j = j0 + g;
-    float part = 0.f;
-    if (j < Lk && col_ok) {
-      const float4 kk = kreg[it];
-      part = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
-    }
-#pragma unroll
-    for (int off = LPR >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off);
-    if (j < Lk) {
-      float add = 0.f;
-      if (a.rel_bias) {
-        int n = i_abs - j, bucket = 0;
-        if (a.bidirectional) {
-          if (n < 0) {
-            bucket = half;
-            n = -n;
-          }
-        } else if (n < 0) {
-          n = 0;
-        }
-        bucket += a.lut.v[n < 127 ? n : 127];
-        add = a.rel_bias[bucket * a.H + h];
-      }
-      bool allowed = true;
-      if (a.causal) allowed = j <= i_abs;
-      if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)kb * a.mask_bstride + j] != 0);
-      if (!allowed) add += masked;
-      const float sj = part + add;
-      if (c == 0) S[j] = sj;
-      mx = fmaxf(mx, sj);
-    }
-  }
-  for (int j0 = 0; j0 < Lk && !pre; j0 += RPI) {
+  for (int j0 = 0; j0 < Lk; j0 += RPI) {
     const int j = j0 + g;
     float part = 0.f;
     if (j < Lk && col_ok) {
@@ -1318,17 +1250,8 @@ __global__ __launch_bounds__(256) void attention_decode_rows_kernel(const AttnAr
   __builtin_amdgcn_wave_barrier();
   // ---- O = P·V: group g takes keys j0 + g, lane (g, c) accumulates columns 4c..4c+3; then the groups are summed
   float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    const int j = it * RPI + g;
-    if (pre && j < Lk && col_ok) {
-      const float4 vv = vreg[it];
-      const float pj = S[j];
-      o.x = fmaf(pj, vv.x, o.x), o.y = fmaf(pj, vv.y, o.y), o.z = fmaf(pj, vv.z, o.z), o.w = fmaf(pj, vv.w, o.w);
-    }
-  }
 #pragma unroll 4
-  for (int j0 = 0; j0 < Lk && !pre; j0 += RPI) {
+  for (int j0 = 0; j0 < Lk; j0 += RPI) {
     const int j = j0 + g;
     if (j < Lk && col_ok) {
       const float4 vv = *reinterpret_cast<const float4*>(a.v + row_of(j) * a.ldv + h * dk + 4 * c);
@@ -1342,6 +1265,118 @@ __global__ __launch_bounds__(256) void attention_decode_rows_kernel(const AttnAr
   }
   if (g == 0 && col_ok) {
     const int64_t off = (int64_t)b * a.o_bstride * a.ldo + h * dk + 4 * c;
+    if (a.out_bf16)  // the context only feeds the next bf16-mode linear: emit its operand directly (same RNE as the cast kernel)
+      *reinterpret_cast<uint2*>(static_cast<__bf16*>(a.out_bf16) + off) = pack_bf16x4(o.x, o.y, o.z, o.w);
+    else
+      *reinterpret_cast<float4*>(a.out + off) = o;
+  }
+}
+
+// Short key lists (a decode step: Lk <= 16 resp. 12 keys, the ancestors reached through kv_rows): the form above spends its
+// time in the vector ALU, not in memory (rocprofv3 counters at 15 360 rows x 12 heads, profiles/r04_decode_attention_pmc.txt:
+// 375 VALU instructions per wave = 3/4 of the SIMDs' issue cycles, 69 % of wave time parked, HBM at ~2 of 8 TB/s) — 64-bit index multiplies, LDS-permute butterflies and a
+// relative-position bias looked up by every lane for every key.  Same arithmetic per (row, head), in the same order (bit-
+// identical output), with the bookkeeping cut down: every memory operand of the wave is requested up front (lane j fetches
+// the row index of key j, a shuffle hands it to the lanes that read that row; V does not depend on the scores); row offsets
+// are one 32 x 32 -> 64-bit multiply-add; the sum over the LPR lanes of a key is four DPP row rotations (the xor butterfly's
+// pairs exactly: after the xor-8 step the values have period 8 inside a row, so "rotate by 4" meets the same partner as
+// "xor 4", and so on down); bias and mask are added where lane <-> key (once per key, not once per lane per key); max and
+// sum of the <= 16 scores stay inside DPP row 0.
+template <int LPR>
+__global__ __launch_bounds__(256) void attention_decode_short_kernel(const AttnArgs a) {
+  constexpr int RPI = 64 / LPR;
+  constexpr int MAXIT = LPR == 16 ? 4 : 6;  // 16 / 12 keys
+  __shared__ float strip[4][16];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform: b, h and every
+                                                                                          // offset made of them live on the scalar unit
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= a.B * a.H) return;
+  if (a.live && *a.live == 0) return;  // every query of the generate call is done
+  const int b = item / a.H, h = item % a.H;
+  if (a.b_count_dev && b >= (int)*a.b_count_dev) return;
+  const int dk = a.dk, Lk = a.Lk, kb = b / a.kv_group;
+  const int g = lane / LPR, c = lane % LPR;
+  const bool col_ok = c < (dk >> 2);
+  const int ldk = (int)a.ldk, ldv = (int)a.ldv;
+  const int col = h * dk + 4 * c;
+  float* S = strip[wave];
+  int myrow = 0;
+  if (lane < Lk) myrow = a.kv_rows ? a.kv_rows[(int64_t)b * Lk + lane] : kb * (int)a.k_bstride + lane;
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col_ok) q = *reinterpret_cast<const float4*>(a.q + (int64_t)b * a.q_bstride * a.ldq + col);
+  // bias + mask of key j, by lane j
+  float add = 0.f;
+  if (lane < Lk) {
+    const int j = lane, i_abs = a.q_pos0;
+    if (a.rel_bias) {
+      int n = i_abs - j, bucket = 0;
+      if (a.bidirectional) {
+        if (n < 0) {
+          bucket = a.num_buckets >> 1;
+          n = -n;
+        }
+      } else if (n < 0) {
+        n = 0;
+      }
+      bucket += a.lut.v[n < 127 ? n : 127];
+      add = a.rel_bias[bucket * a.H + h];
+    }
+    bool allowed = true;
+    if (a.causal) allowed = j <= i_abs;
+    if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)kb * a.mask_bstride + j] != 0);
+    if (!allowed) add += a.causal_neg_inf ? -INFINITY : -1e9f;
+  }
+  float4 kreg[MAXIT], vreg[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int j = it * RPI + g;
+    const int rj = __shfl(myrow, j < Lk ? j : 0);
+    if (j < Lk && col_ok) {  // (read below under the same condition only)
+      kreg[it] = *reinterpret_cast<const float4*>(a.k + ((int64_t)rj * ldk + col));
+      vreg[it] = *reinterpret_cast<const float4*>(a.v + ((int64_t)rj * ldv + col));
+    }
+  }
+  q.x *= a.scale, q.y *= a.scale, q.z *= a.scale, q.w *= a.scale;
+  // ---- q·k of key j = it * RPI + g, summed over the LPR lanes of group g
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int j = it * RPI + g;
+    if (it * RPI >= Lk) break;
+    float part = 0.f;
+    if (j < Lk && col_ok) {
+      const float4 kk = kreg[it];
+      part = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
+    }
+    if (LPR == 32) part += __shfl_xor(part, 16);
+    part = row16_sum(part);
+    if (c == 0 && j < Lk) S[j] = part;
+  }
+  __builtin_amdgcn_wave_barrier();  // the strip is private to this wave: LDS operations of one wave complete in order
+  // ---- softmax, lane <-> key (all keys sit in DPP row 0)
+  const float sj = lane < Lk ? S[lane] + add : -INFINITY;
+  const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row16_max(sj))));
+  const float p0 = lane < Lk ? expf(sj - mx) : 0.f;
+  const float inv = 1.0f / __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row16_sum(p0))));
+  __builtin_amdgcn_wave_barrier();
+  if (lane < Lk) S[lane] = p0 * inv;
+  __builtin_amdgcn_wave_barrier();
+  // ---- O = P·V: group g takes keys it * RPI + g, lane (g, c) accumulates columns 4c..4c+3; then the groups are summed
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int j = it * RPI + g;
+    if (j < Lk && col_ok) {
+      const float4 vv = vreg[it];
+      const float pj = S[j];
+      o.x = fmaf(pj, vv.x, o.x), o.y = fmaf(pj, vv.y, o.y), o.z = fmaf(pj, vv.z, o.z), o.w = fmaf(pj, vv.w, o.w);
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    o.x += __shfl_xor(o.x, off), o.y += __shfl_xor(o.y, off), o.z += __shfl_xor(o.z, off), o.w += __shfl_xor(o.w, off);
+  }
+  if (g == 0 && col_ok) {
+    const int64_t off = (int64_t)b * a.o_bstride * a.ldo + col;
     if (a.out_bf16)  // the context only feeds the next bf16-mode linear: emit its operand directly (same RNE as the cast kernel)
       *reinterpret_cast<uint2*>(static_cast<__bf16*>(a.out_bf16) + off) = pack_bf16x4(o.x, o.y, o.z, o.w);
     else
@@ -1366,6 +1401,15 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
                 "attention: a device-side batch count needs the Lq = 1 row-group form (dk <= 128, ldo %% 4 == 0; dk=%d ldo=%lld)", a.dk,
                 (long long)a.ldo);
   if (a.Lq == 1 && a.dk <= 128 && a.ldo % 4 == 0) {
+    if (a.Lk <= (a.dk <= 64 ? 16 : 12)) {  // a decode step's key list
+      const dim3 grids((unsigned)((a.B * a.H + 3) / 4));
+      if (a.dk <= 64)
+        hipLaunchKernelGGL(attention_decode_short_kernel<16>, grids, dim3(256), 0, stream, a);
+      else
+        hipLaunchKernelGGL(attention_decode_short_kernel<32>, grids, dim3(256), 0, stream, a);
+      GDR_CHECK_LAUNCH("attention_decode_short_kernel");
+      return GDR_OK;
+    }
     const dim3 grid((unsigned)((a.B * a.H + 3) / 4));
     if (a.dk <= 64)
       hipLaunchKernelGGL(attention_decode_rows_kernel<16>, grid, dim3(256), 0, stream, a);
@@ -1456,6 +1500,12 @@ extern "C" int gdr_t5_relative_bucket_table(int bidirectional, int num_buckets, 
       out_host[i * klen + j] = bucket + lut.v[n < 127 ? n : 127];
     }
   return GDR_OK;
+}
+
+extern "C" int gdr_t5_layer_norm(const float* x, const float* w, float* y, int64_t rows, int d, float eps, void* stream_) {
+  using namespace gdr;
+  GDR_CHECK_ARG(x && w && y && rows >= 0 && d > 0 && d % 4 == 0, "t5_layer_norm: bad arguments (d %% 4 == 0)");
+  return launch_rmsnorm(x, w, y, rows, d, eps, nullptr, 1, static_cast<hipStream_t>(stream_));
 }
 
 extern "C" int gdr_l2_normalize(const float* x, float* y, int64_t rows, int d, float eps, void* stream_) {

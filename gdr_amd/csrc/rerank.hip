@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void rerank_dot_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float a = acc[i];
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    a = wave_sum(a);
     if (lane == 0 && c0 + i < ncand)
       sim[(int64_t)b * max_cand + c0 + i] = !on[i] ? -INFINITY : (func == 0 ? tanhf(a) : 1.0f / (1.0f + expf(-a)));
   }
@@ -168,14 +168,14 @@ __global__ __launch_bounds__(1024) void rerank_select_kernel(const float* __rest
     const float* bs = beam_scores + (int64_t)b * R;
     float mx = -INFINITY;
     for (int j = lane; j < R; j += 64) mx = fmaxf(mx, bs[j]);
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max(mx);
     float sm = 0.f;
     for (int j = lane; j < R; j += 64) {
       const float e = expf(bs[j] - mx);
       prob[j] = e;
       sm += e;
     }
-    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+    sm = wave_sum(sm);
     for (int j = lane; j < R; j += 64) prob[j] = prob[j] / sm;
   }
   __syncthreads();

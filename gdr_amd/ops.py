@@ -72,6 +72,18 @@ def l2_normalize(x, eps=1e-12):
     return out
 
 
+def t5_layer_norm(x, weight, eps=1e-6):
+    """T5LayerNorm (modeling_t5.py:164-171): weight * (x / sqrt(mean(x^2) + eps)) over the last dim, fp32 — gdr_t5_layer_norm."""
+    _need_cuda(x, weight)
+    x, weight = _f32c(x), _f32c(weight)
+    d = x.shape[-1]
+    if weight.numel() != d:
+        raise _ffi.GdrError(f"t5_layer_norm: weight has {weight.numel()} elements, rows have {d}")
+    out = torch.empty_like(x)
+    check(lib().gdr_t5_layer_norm(ptr(x), ptr(weight), ptr(out), x.numel() // d, d, float(eps), stream_ptr()), "gdr_t5_layer_norm")
+    return out
+
+
 class Workspace:
     """Grow-only device scratch (256-byte aligned by the caching allocator), one buffer per HIP stream: calls that are in
     flight on different streams (GDRRetriever.validation_steps, two generate() calls) never share scratch."""

@@ -88,6 +88,12 @@ int gdr_linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t l
 int gdr_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                     int K, int epilogue, const float* bias, const float* residual, int64_t ldr, void* stream);
 
+/* T5LayerNorm (modeling_t5.py:164-171): y = w * (x / sqrt(mean(x^2) + eps)) per row, fp32 — the norm every T5 block of the
+ * path applies, as an operator of its own.  The quotient is the IEEE division's, bit for bit (the kernels divide a row by its
+ * one denominator with a correctly rounded reciprocal and one exact-residual correction per element).  x, y fp32 [rows, d],
+ * d % 4 == 0; y may alias x. */
+int gdr_t5_layer_norm(const float* x, const float* w, float* y, int64_t rows, int d, float eps, void* stream);
+
 /* y[r] = x[r] / max(||x[r]||_2, eps) — `torch.nn.functional.normalize(rep, dim=-1)` of DensePooler (dense.py:24-25;
  * torch's eps is 1e-12).  x, y fp32 [rows, d]; y may alias x. */
 int gdr_l2_normalize(const float* x, float* y, int64_t rows, int d, float eps, void* stream);

@@ -227,6 +227,33 @@ def test_l2_normalize_vs_torch(dev):
     assert torch.equal(got[5], torch.zeros(768))
 
 
+@pytest.mark.parametrize("d", [768, 64, 1024, 2052])
+def test_t5_layer_norm_divides_like_the_reference_bit_for_bit(dev, d):
+    """T5LayerNorm is `weight * (x / sqrt(mean(x^2) + eps))` (modeling_t5.py:164-171): a true division per element.  The kernels
+    divide a row by its one denominator in three instructions per element (correctly rounded reciprocal, q = x * r, exact
+    residual, one correction — common.h RowDivisor) and claim the IEEE quotient's bits.  Checked where the expected bits do not
+    depend on a summation order: rows of integers (every x^2 and every partial sum exact in fp32), scaled per row by a power of
+    two, so that sum / d, + eps, sqrt and the division are each ONE correctly rounded fp32 operation — exactly what numpy's
+    float32 arithmetic computes.  200 000 rows = 200 000 different denominators; d = 2052 takes the kernel's second form
+    (rows wider than its registers)."""
+    from gdr_amd import ops
+    rng = np.random.default_rng(17 + d)
+    rows = 200000 if d <= 1024 else 20000
+    hi = int(np.sqrt((1 << 24) / d))                                   # d * hi^2 < 2^24: the sum of squares stays exact
+    xi = rng.integers(-hi, hi + 1, size=(rows, d)).astype(np.float32)
+    scale = np.exp2(rng.integers(-6, 7, size=(rows, 1))).astype(np.float32)
+    x = xi * scale                                                      # exact (power of two)
+    w = rng.standard_normal(d).astype(np.float32)
+    eps = np.float32(1e-6)
+    ss = (xi.astype(np.int64) ** 2).sum(1, keepdims=True).astype(np.float32) * (scale * scale)   # exact, any order
+    denom = np.sqrt(ss / np.float32(d) + eps, dtype=np.float32)
+    want = w[None, :] * (x / denom)
+    got = ops.t5_layer_norm(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), float(eps)).cpu().numpy()
+    assert got.dtype == np.float32 and want.dtype == np.float32
+    bad = np.flatnonzero((got.view(np.uint32) != want.view(np.uint32)).any(1))
+    assert bad.size == 0, f"{bad.size} of {rows} rows differ from the IEEE expression, first: row {bad[0]}"
+
+
 def test_one_oversized_cluster_does_not_break_the_step(dev):
     """The device candidate blocks are `num_beams x largest cluster of the corpus` wide.  One outlier cluster (here 1 000 docs
     at 10 beams: 10 000 > the rerank's 8 192-candidate cap) must not make every step fail when the clusters actually decoded

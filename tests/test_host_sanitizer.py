@@ -53,6 +53,8 @@ assert E(l.gdr_topk_merge(None, None, 2, 2, 2, None, None, None))
 assert E(l.gdr_topk_pack(None, None, None, 2, 2, None, None))
 assert E(l.gdr_topk_merge_packed(FAKE, 0, 2, 2, FAKE, FAKE, None, None))
 assert E(l.gdr_l2_normalize(None, None, 2, 8, 1e-12, None))
+assert E(l.gdr_t5_layer_norm(None, None, None, 2, 8, 1e-6, None))
+assert E(l.gdr_t5_layer_norm(FAKE, FAKE, FAKE, 2, 6, 1e-6, None))       # d % 4 != 0
 al = (C.c_float * 2)(0.0, 1.0)
 assert E(l.gdr_rerank_topk(FAKE, FAKE, 768, FAKE, FAKE, FAKE, 4, 10, FAKE, 2, 10, 0, FAKE, FAKE, 9000, 0, 0, 100, 0, FAKE, 1 << 20, None))
 assert E(l.gdr_rerank_topk(FAKE, FAKE, 768, FAKE, FAKE, FAKE, 4, 10, FAKE, 2, 10, 0, FAKE, FAKE, 120, 0, 0, 100, 0, FAKE, 16, None))  # ENOSPC

@@ -1,4 +1,4 @@
-"""rocprofv3 target: docid beam decode alone (encoder + gdr_t5_generate), B=64 beams=10, 4 calls.
+"""rocprofv3 target: docid beam decode alone (encoder + gdr_t5_generate), B=64 beams=10, 4 calls (env B / BEAMS / CALLS; DTYPE=bf16).
 Post-process the kernel trace with tools/trace_busy.py to see GPU-busy vs wall span (launch-bound or not)."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -11,6 +11,7 @@ B, R = int(os.environ.get("B", 64)), int(os.environ.get("BEAMS", 10))
 cfg = GDRConfig.base()
 names = synth.make_cluster_ids(320000, cluster_size=12, V=30)[0]
 model = GDRModel(cfg, synth.make_state_dict(cfg, seed=1234), dev, ragged=True,
+                 dtype=torch.bfloat16 if os.environ.get("DTYPE") == "bf16" else torch.float32,
                  prefix_trie=None if os.environ.get("NO_PREFIX_TABLE") else codec.Trie.from_docids(names, 30))
 ids, mask = synth.make_tokens(B, L=40, seed=11)
 ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
