@@ -119,6 +119,9 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
                             const NormEpilogue* ne = nullptr,  // with ne: returns 2 if the fused form does not apply
                             SlabRef* slabs = nullptr,          // with slabs (no epilogue allowed): the reduction is left to the caller
                             const int32_t* live = nullptr);    // StreamK::live
+int launch_linear_bf16_headdot(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, const int64_t* m_dev, int N, int K,
+                               const float* h, int64_t ldh, const int32_t* rows_map, const float* E, int dot_d, float scale,
+                               float* partial, hipStream_t stream);
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, int out_bf16, hipStream_t stream, const int64_t* m_dev = nullptr);

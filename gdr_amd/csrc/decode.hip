@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void head_logits_table_kernel(const float* __r
                                                                 const int32_t* __restrict__ node,
                                                                 const int32_t* __restrict__ miss_index, int n_table,
                                                                 int rows, int V1, int d, float scale,
-                                                                float* __restrict__ logits, const int32_t* __restrict__ live) {
+                                                                float* __restrict__ logits, const int32_t* __restrict__ live,
+                                                                const float* __restrict__ partial = nullptr) {
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= (int64_t)rows * V1) return;
   if (live && *live == 0) return;  // every query is done: these logits are never ranked
@@ -202,6 +203,10 @@ __global__ __launch_bounds__(256) void head_logits_table_kernel(const float* __r
       acc = fmaf(hv.z * scale, wv.z, acc);
       acc = fmaf(hv.w * scale, wv.w, acc);
     }
+  } else if (partial) {
+    // the head GEMM's epilogue already took the dot (launch_linear_bf16_headdot): d / 64 partial sums per (row, c), added in a fixed tree
+    const int slots = d >> 6;
+    if (lane < slots) acc = partial[((size_t)mi * V1 + c) * slots + lane];
   } else {
     const float4* a4 = reinterpret_cast<const float4*>(A_c + ((size_t)mi * V1 + c) * d);
     const float4* e4 = reinterpret_cast<const float4*>(E + (size_t)c * d);
@@ -1404,7 +1409,18 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       if (l < dm.num_layers) GDR_TRY(dec_layer(l));
       if (l < w->adaptor_layers && !adaptor_idle) GDR_TRY(ptab ? ad_layer_tab(l) : ad_layer_plain(l));
     }
-    if (ptab && !adaptor_idle)  // the head GEMM of the compacted rows belongs to the adaptor chain (it needs nothing from the decoder stack)
+    // bf16 mode from ~1 000 beam rows on: the head GEMM waits for the decoder stack and takes the dot with its hidden state in its own
+    // epilogue (launch_linear_bf16_headdot) instead of writing rows x (V+1) x d floats for head_logits to read back (1.46 GB per step at
+    // 15 360 rows).  At these sizes both chains fill the chip, so the adaptor chain gives up nothing by ending one GEMM earlier
+    // (generate() 512 x 30 beams 44.5 -> 41.8 ms, 2 048 x 10 62.4 -> 58.9, 256 x 10 14.43 -> 14.15, 64 x 30 12.64 -> 12.5; below
+    // HEAD_DOT_ROWS the GEMM stays on the adaptor chain, beside the decoder stack).  Same products, another fp32 summation tree.
+    constexpr int HEAD_DOT_ROWS = 1024;
+    static const bool head_dot_on = [] {
+      const char* e = getenv("GDR_DECODE_FUSE_NORM");  // the A/B knob of the other fused consumer (0 = every linear writes its output and
+      return e ? atoi(e) != 0 : true;                  // its consumer runs as a launch of its own); the fp32 norm fusion is off in bf16 mode
+    }();
+    const bool fuse_head = bf16 && ptab && !adaptor_idle && head_dot_on && rows_s >= HEAD_DOT_ROWS && d % 128 == 0;
+    if (ptab && !adaptor_idle && !fuse_head)  // the head GEMM of the compacted rows belongs to the adaptor chain (it needs nothing from the decoder stack)
       GDR_TRY(LIN2D(xa, d, w_at(w->head_w, (size_t)s * V1 * d * d, bf16), d, A, (int64_t)V1 * d, V1 * d, d, GDR_EPI_NONE, nullptr,
                     nullptr, 0));
 #undef LIN2D
@@ -1428,9 +1444,26 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
                          1.0f / sqrtf((float)d), bb.logits, bb.live_gate);
       GDR_CHECK_LAUNCH("head_logits_kernel");
     } else {
+      const float* partial = nullptr;
+      if (fuse_head) {
+        const void* a16 = (img2.buf && img2.src == xa) ? img2.buf : nullptr;  // the last adaptor norm's bf16 image of xa
+        if (!a16) {
+          GDR_TRY(launch_cast_f32_bf16(xa, abf2, (int64_t)rows_s * d, stream));
+          a16 = abf2;
+        }
+        const int rc_ = launch_linear_bf16_headdot(a16, d, hw, d, rows_s, nm, V1 * d, d, hl, d, bb.miss_rows, he, d, 1.0f / sqrtf((float)d), A,
+                                                   stream);
+        if (rc_ < 0) return rc_;
+        if (rc_ == 0)
+          partial = A;
+        else  // shape not served: the plain form, now behind the join
+          GDR_TRY(dec_linear(bf16, abf2, xa, d, hw, d, A, (int64_t)V1 * d, rows_s, nm, V1 * d, d, GDR_EPI_NONE, nullptr, nullptr, 0, skw2,
+                             stream, &sk2, &img2));
+      }
       const int64_t items = (int64_t)rows_s * V1;
       hipLaunchKernelGGL(head_logits_table_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, hl, A, he, ptab->W,
-                         bb.node[cur], bb.miss_index, ptab->n_table, rows_s, V1, d, 1.0f / sqrtf((float)d), bb.logits, bb.live_gate);
+                         bb.node[cur], bb.miss_index, ptab->n_table, rows_s, V1, d, 1.0f / sqrtf((float)d), bb.logits, bb.live_gate,
+                         partial);
       GDR_CHECK_LAUNCH("head_logits_table_kernel");
     }
     GDR_TRY(beam_step(bb, bd, s, cur, step_scores, step_tokens, stream, s == 0 && dedup0));

@@ -29,6 +29,16 @@ struct Bf16GemmArgs {
   int has_bias, has_residual, act;  // act: 0 none, 1 relu, 2 gelu
   int out_bf16;
   const int64_t* m_dev;  // linear only, may be null: live row count on the device (<= M); tiles past it exit at once
+  // EPI 3 (the decode head, see launch_linear_bf16_headdot): nothing is stored; per output row m and vocabulary entry c = n / dot_d
+  // the tile leaves  sum_i (h[dot_rows[m]][i] * dot_scale) * (acc[m][c*dot_d + i] + dot_e[c][i])  over its 64 columns per wave in
+  // dot_out[(m * (N / dot_d) + c) * (dot_d / 64) + (n % dot_d) / 64]
+  const float* dot_h;
+  int64_t dot_ldh;
+  const int32_t* dot_rows;
+  const float* dot_e;
+  float* dot_out;
+  float dot_scale;
+  int dot_d;
   // similarity epilogues (EPI 1 sample / 2 filter): A = queries [B,d] (lane role), W = docs [N,d] (register role);
   // tiles_n then counts QUERY tiles (fastest in the grid: the workgroups that share a doc tile are neighbours)
   SimEpilogue sim;
@@ -39,16 +49,17 @@ __device__ __forceinline__ float gelu_erf_b(float x) { return 0.5f * x * (1.0f +
 // BM = rows of A per tile: 128, or 64 for the linears of a few thousand rows (the decode legs of config C5: 1 920 beam rows x
 // N = 768 are 90 tiles of 128 x 128 on 256 CUs; 64-row tiles double the workgroups — the W operand is re-read twice as often,
 // which L2 absorbs at these sizes — and halve the accumulators, 32 x 64 per wave).  The similarity forms use 128.
-template <int EPI, int BM = 128>  // EPI: 0 linear, 1 similarity sample, 2 similarity filter
+template <int EPI, int BM = 128>  // EPI: 0 linear, 1 similarity sample, 2 similarity filter, 3 linear whose output is only dotted with h
 __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16GemmArgs g) {
-  static_assert(BM == 128 || (BM == 64 && EPI == 0), "64-row tiles serve the linear form only");
+  constexpr bool LIN = EPI == 0 || EPI == 3;
+  static_assert(BM == 128 || (BM == 64 && LIN), "64-row tiles serve the linear forms only");
   constexpr int MI = BM / 32;   // 16-row accumulator blocks per wave along M: 4 or 2
   constexpr int AI = BM / 32;   // A staging instructions per wave (8 rows each): 4 or 2
   __shared__ __attribute__((aligned(1024))) char smem[BM * 128 + 128 * 128];  // As [BM rows][128 B], Bs [128 rows][128 B]
   char* const As = smem;
   char* const Bs = smem + BM * 128;
   unsigned bid = blockIdx.x;
-  const int64_t Mv = (EPI == 0 && g.m_dev) ? *g.m_dev : g.M;
+  const int64_t Mv = (LIN && g.m_dev) ? *g.m_dev : g.M;
   {
     // The XCD-aware remap hands every XCD a CONTIGUOUS range of logical tiles.  With a device-side row count the grid is sized
     // for the padded batch and the tiles past the live rows are the LAST logical ones: remapped over the whole grid they all
@@ -57,7 +68,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     // hardware blocks past it exit — the hardware deals consecutive block ids round-robin over the XCDs, so the live ones
     // are spread evenly.
     unsigned nblk = gridDim.x;
-    if (EPI == 0 && g.m_dev) {
+    if (LIN && g.m_dev) {
       const int64_t live = ((Mv + BM - 1) / BM) * (int64_t)g.tiles_n;
       if (live < (int64_t)nblk) {
         if ((int64_t)bid >= live) return;  // uniform
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
   }
   int64_t m0, slot_base = 0;
   int64_t n0;
-  if (EPI == 0) {
+  if (LIN) {
     m0 = (int64_t)(bid / (unsigned)g.tiles_n) * BM;
     n0 = (int64_t)(bid % (unsigned)g.tiles_n) * 128;
   } else {
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     }
     n0 = dt * 128;
   }
-  if (EPI == 0 && m0 >= Mv) return;  // uniform (cannot happen after the live-count remap; kept as the bound it documents)
+  if (LIN && m0 >= Mv) return;  // uniform (cannot happen after the live-count remap; kept as the bound it documents)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int r16 = lane & 15, q4 = lane >> 4;
@@ -219,6 +230,32 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
               ++pos;
             }
       }
+    }
+    return;
+  }
+  if (EPI == 3) {
+    // ---- head dot: the lane's 4 x 4 columns of each of its rows, then the four lanes (lane >> 4) that share the row ----
+    const int c = (int)(n0 / g.dot_d), i0 = (int)(n0 % g.dot_d) + wn * 64;  // a tile lies inside one vocabulary entry (dot_d % 128 == 0)
+    const float* er = g.dot_e + (int64_t)c * g.dot_d + i0 + 4 * q4;
+    const int slots = g.dot_d >> 6;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int64_t m = m0 + wm * (BM / 2) + mi * 16 + r16;
+      const int64_t mc = m < Mv ? m : Mv - 1;
+      const float* hr = g.dot_h + (int64_t)g.dot_rows[mc] * g.dot_ldh + i0 + 4 * q4;
+      float part = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const float4 hv = *reinterpret_cast<const float4*>(hr + ni * 16);
+        const float4 ev = *reinterpret_cast<const float4*>(er + ni * 16);
+        part = fmaf(hv.x * g.dot_scale, acc[mi][ni][0] + ev.x, part);
+        part = fmaf(hv.y * g.dot_scale, acc[mi][ni][1] + ev.y, part);
+        part = fmaf(hv.z * g.dot_scale, acc[mi][ni][2] + ev.z, part);
+        part = fmaf(hv.w * g.dot_scale, acc[mi][ni][3] + ev.w, part);
+      }
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      if (q4 == 0 && m < Mv) g.dot_out[(m * (int64_t)(g.N / g.dot_d) + c) * slots + (i0 >> 6)] = part;
     }
     return;
   }
@@ -545,6 +582,34 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
   }
   hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 128>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
   GDR_CHECK_LAUNCH("gemm_nt_bf16_glds_kernel");
+  return 0;
+}
+
+// The decode head in the bf16 precision mode (modeling_t5.py:1634-1646): per row the product with head_w is a [V+1, d] matrix that is
+// only ever dotted with the row's hidden state, logits[c] = sum_i (h[i] * d^-0.5) * (A[c*d + i] + E[c][i]).  With thousands of rows that
+// matrix is 1.46 GB per step at 15 360 rows — written by the GEMM, read once by head_logits.  Here the GEMM's epilogue takes the dot
+// itself: each wave leaves the sum over its 64 columns (d / 64 partials per (row, c), 23 MB instead of 1.46 GB), and the logits kernel adds
+// them in a fixed order.  A, W bf16 as in the linear; h fp32 rows reached through rows_map (the compacted row's original row).
+// Returns 1 if the shape is not served (the caller runs the linear + the plain dot).
+int launch_linear_bf16_headdot(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, const int64_t* m_dev, int N, int K,
+                               const float* h, int64_t ldh, const int32_t* rows_map, const float* E, int dot_d, float scale,
+                               float* partial, hipStream_t stream) {
+  if (K % 64 != 0 || lda % 8 != 0 || ldw % 8 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return 1;
+  if (dot_d % 128 != 0 || N % dot_d != 0 || ldh % 4 != 0 || ((uintptr_t)h & 15) || ((uintptr_t)E & 15) || !rows_map || !partial) return 1;
+  Bf16GemmArgs g{};
+  g.A = static_cast<const char*>(A), g.W = static_cast<const char*>(W);
+  g.lda = lda, g.ldw = ldw, g.M = M, g.N = N, g.Nrows = N, g.K = K;
+  g.tiles_n = N / 128;
+  g.m_dev = m_dev;
+  g.dot_h = h, g.dot_ldh = ldh, g.dot_rows = rows_map, g.dot_e = E, g.dot_out = partial, g.dot_scale = scale, g.dot_d = dot_d;
+  int64_t blocks = ((M + 127) / 128) * g.tiles_n;
+  if (blocks <= 0) return 0;
+  if (blocks > 0x7fffffffLL) {
+    set_error("linear_bf16(head dot): grid too large");
+    return GDR_EINVAL;
+  }
+  hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<3, 128>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  GDR_CHECK_LAUNCH("gemm_nt_bf16_glds_kernel(head dot)");
   return 0;
 }
 

@@ -122,3 +122,54 @@ def test_latency_mode_filter_lists_local_full_and_direct_agree():
     assert all(v["status"] == 0 for v in base.values())
     assert run("16") == base
     assert run("0") == base
+
+
+BF16_CHILD = r"""
+import json, sys, torch
+sys.path.insert(0, sys.argv[1])
+from gdr_amd import codec, synth
+from gdr_amd.config import GDRConfig
+from gdr_amd.modeling import GDRModel
+torch.set_grad_enabled(False)
+dev = torch.device("cuda:0")
+cfg = GDRConfig.base()
+names = synth.make_cluster_ids(30000, cluster_size=12, V=30)[0]
+model = GDRModel(cfg, synth.make_state_dict(cfg, seed=1234), dev, ragged=True, prefix_trie=codec.Trie.from_docids(names, 30),
+                 dtype=torch.bfloat16)
+out = {}
+for B, R in ((512, 10), (140, 30), (64, 10)):          # 5 120 / 4 200 beam rows take the fused head, 640 rows the plain one
+    ids, mask = synth.make_tokens(B, L=40, seed=31 + B)
+    ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    (dec, scores), _ = model.generate(ids, attention_mask=mask, max_length=10, num_beams=R, length_penalty=0.8,
+                                      num_return_sequences=R, output_scores=True)
+    out[f"{B}x{R}"] = {"ids": dec.cpu().tolist(), "scores": [float(s) for s in scores]}
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_bf16_head_dot_in_the_gemm_epilogue_equals_the_plain_form():
+    """bf16 mode, >= 1 024 beam rows: the head GEMM's epilogue dots its tile with the row's hidden state
+    (launch_linear_bf16_headdot; 12 partial sums per (row, vocabulary entry)) instead of writing rows x 31 x 768 floats for
+    head_logits to read back.  Same products, another fp32 summation tree: against GDR_DECODE_FUSE_NORM=0 (every linear writes
+    its output and the consumer runs as its own launch — in bf16 mode that switch governs this fusion only) the hypothesis
+    scores agree to 1e-4 and a hypothesis may only trade places with one whose score is that close.  The 640-row shape runs
+    the plain form either way: identical."""
+    def run(**env):
+        r = subprocess.run([sys.executable, "-c", BF16_CHILD, ROOT], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
+    fused, plain = run(), run(GDR_DECODE_FUSE_NORM="0")
+    assert fused["64x10"] == plain["64x10"]
+    moved = 0
+    for key in ("512x10", "140x30"):
+        sa, sb = np.asarray(plain[key]["scores"]), np.asarray(fused[key]["scores"])
+        live = sa > -1e7
+        np.testing.assert_allclose(sb[live], sa[live], rtol=1e-4, atol=1e-4, err_msg=key)
+        ia, ib = np.asarray(plain[key]["ids"]), np.asarray(fused[key]["ids"])
+        same = (ia == ib).all(axis=1)
+        for r in np.nonzero(~same & live)[0]:
+            assert abs(sa[r] - sb[r]) <= 1e-4 * max(1.0, abs(sa[r])), f"{key} row {r}"
+        assert same[live].mean() > 0.97, f"{key}: {same[live].mean():.3f} of the live hypotheses identical"
+        moved += int((sa != sb).sum())
+    assert moved > 0, "the fused head did not run (scores bit-identical to the plain form at >= 1 024 rows)"
