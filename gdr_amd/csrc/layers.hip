@@ -677,36 +677,38 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
       } else {
         const float* q32 = a.q + qr * a.ldq + h * DK + 4 * (lq >> 4);
 #pragma unroll
-        for (int jj = 0; jj < DK / 16; ++jj) {
-          float4 t = *reinterpret_cast<const float4*>(q32 + 16 * jj);
-          t.x *= a.scale, t.y *= a.scale, t.z *= a.scale, t.w *= a.scale;
-          qv[jj] = t;
-        }
+        for (int jj = 0; jj < DK / 16; ++jj) qv[jj] = *reinterpret_cast<const float4*>(q32 + 16 * jj);  // scaled behind the barrier
       }
     }
   }
-  for (int e = tid; e < 2 * LP; e += NTHR) {
-    float v = 0.f;
-    if (a.rel_bias) {
-      int n = e - (LP - 1), bucket = 0;
-      if (a.bidirectional) {
-        if (n < 0) {
-          bucket = a.num_buckets >> 1;
-          n = -n;
-        }
-      } else if (n < 0) {
-        n = 0;
+  // Everything this workgroup reads is requested before anything is consumed.  Written as loops of "load, convert, store to LDS"
+  // the prologue compiled into a chain of eight dependent round trips (q waited for at once for its scale, bucket table ->
+  // bias, mask, then the K / V staging loop one iteration at a time) in front of ~1 us of arithmetic: 44 us per launch for
+  // 6 144 (sequence, head) pairs at 12 308 rows.  Same values into the same LDS cells — results are bit-identical.
+  int rb_bucket = -1;  // this thread's cell of the relative-position bias table (2*LP <= NTHR * 2: two cells at most)
+  int rb_lutoff[2];
+  unsigned char rb_lut[2] = {0, 0};
+  int rb_base[2] = {0, 0};
+  constexpr int RBI = (2 * LP + NTHR - 1) / NTHR;  // 1 (2*LP = 32*NT <= 64*NT)
+  static_assert(RBI == 1, "one bias cell per thread");
+  if (a.rel_bias && tid < 2 * LP) {
+    int n = tid - (LP - 1), bucket = 0;
+    if (a.bidirectional) {
+      if (n < 0) {
+        bucket = a.num_buckets >> 1;
+        n = -n;
       }
-      bucket += a.lut.v[n < 127 ? n : 127];
-      v = a.rel_bias[bucket * a.H + h];
+    } else if (n < 0) {
+      n = 0;
     }
-    RelB[e] = v;
+    rb_base[0] = bucket;
+    rb_lutoff[0] = n < 127 ? n : 127;
+    rb_lut[0] = a.lut.v[rb_lutoff[0]];  // (a load from the kernel arguments: the first of the two dependent ones)
+    rb_bucket = 0;
   }
-  for (int j = tid; j < LP; j += NTHR) {
-    float v = -INFINITY;
-    if (j < L) v = (a.key_mask && a.key_mask[(int64_t)b * a.mask_bstride + j] == 0) ? (a.causal_neg_inf ? -INFINITY : -1e9f) : 0.f;
-    Mk[j] = v;
-  }
+  int64_t mk_raw = 1;
+  const bool mk_mine = tid < LP && tid < L && a.key_mask;
+  if (mk_mine) mk_raw = a.key_mask[(int64_t)b * a.mask_bstride + tid];
   if (a.qkv_bf16) {
     // bf16 q / k / v (the qkv linear of the bf16 precision mode emits them so): 16-byte loads of 8 elements, widened to
     // fp32 in the LDS image — the MFMAs below are unchanged (products of bf16 values are exact in fp32)
@@ -729,15 +731,49 @@ __global__ __launch_bounds__(64 * NT) void attention_mfma16_kernel(const AttnArg
       *reinterpret_cast<float4*>(Vs + r * DS + 8 * c + 4) = hi;
     }
   } else {
-  for (int e = tid; e < L * (DK / 4); e += NTHR) {
-    const int r = e >> 4, c = e & 15;
-    const float4 k = *reinterpret_cast<const float4*>(a.k + (krow0 + r) * a.ldk + h * DK + 4 * c);
-    const float4 v = *reinterpret_cast<const float4*>(a.v + (krow0 + r) * a.ldv + h * DK + 4 * c);
-    *reinterpret_cast<float4*>(Ks + r * DS + 4 * c) = k;
-    *reinterpret_cast<float4*>(Vs + r * DS + 4 * c) = v;
+    constexpr int KI = (LP * (DK / 4) + NTHR - 1) / NTHR;  // 4 for every NT
+    float4 kst[KI], vst[KI];
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {  // unconditional loads (the address is clamped to the sequence's last element): the staging
+      const int e = min(tid + it * NTHR, L * (DK / 4) - 1);  // registers stay registers and all 2 * KI requests go out back to back
+      const int r = e >> 4, c = e & 15;
+      kst[it] = *reinterpret_cast<const float4*>(a.k + (krow0 + r) * a.ldk + h * DK + 4 * c);
+      vst[it] = *reinterpret_cast<const float4*>(a.v + (krow0 + r) * a.ldv + h * DK + 4 * c);
+    }
+    // nothing above may sink below this line, nothing below may rise above it: the compiler otherwise moves every load next to
+    // its LDS store again (one round trip per staging iteration)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    // the bias cell: the second of its two dependent loads goes out while K / V are still arriving (the bucket byte was
+    // requested before them, so waiting for it leaves them in flight)
+    float rb_val = 0.f;
+    if (rb_bucket >= 0) rb_val = a.rel_bias[(rb_base[0] + rb_lut[0]) * a.H + h];
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+      asm volatile("" : "+v"(kst[it].x), "+v"(kst[it].y), "+v"(kst[it].z), "+v"(kst[it].w));
+      asm volatile("" : "+v"(vst[it].x), "+v"(vst[it].y), "+v"(vst[it].z), "+v"(vst[it].w));
+    }
+    asm volatile("" : "+v"(mk_raw));
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+      const int e = tid + it * NTHR;
+      if (e < L * (DK / 4)) {
+        const int r = e >> 4, c = e & 15;
+        *reinterpret_cast<float4*>(Ks + r * DS + 4 * c) = kst[it];
+        *reinterpret_cast<float4*>(Vs + r * DS + 4 * c) = vst[it];
+      }
+    }
+    if (tid < 2 * LP) RelB[tid] = rb_val;
   }
-  }
+  if (a.qkv_bf16 && tid < 2 * LP) RelB[tid] = rb_bucket >= 0 ? a.rel_bias[(rb_base[0] + rb_lut[0]) * a.H + h] : 0.f;
+  if (tid < LP) Mk[tid] = tid < L ? ((mk_mine && mk_raw == 0) ? (a.causal_neg_inf ? -INFINITY : -1e9f) : 0.f) : -INFINITY;
   __syncthreads();
+  if (!a.qkv_bf16) {
+#pragma unroll
+    for (int jj = 0; jj < DK / 16; ++jj) qv[jj].x *= a.scale, qv[jj].y *= a.scale, qv[jj].z *= a.scale, qv[jj].w *= a.scale;
+  }
 
   const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, q4 = lane >> 4;
   if (16 * w >= L) return;  // ragged: a query tile past this sequence's end (no barrier follows)
