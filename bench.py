@@ -48,6 +48,36 @@ sys.path.insert(0, REPO)
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA (no sparsity)
 HBM_PEAK_GBS = 8000.0
+LINE_LIMIT = 4096                 # the round driver keeps the last 8 KB of stdout: the headline line must fit with room to spare
+
+
+def sig(x, n=5):
+    """Every float of a JSON-able object rounded to n significant digits (the line is read by people and by the driver)."""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [sig(v, n) for v in x]
+    return x
+
+
+def emit(result, detail=None):
+    """Rank 0's output: the full detail object on a `#stages` line (and in bench_stages.json next to this script), then THE one
+    JSON line — headline, roofline, cpu_baseline, recall / parity and a dozen stage scalars — which must stay under LINE_LIMIT."""
+    if detail:
+        text = json.dumps(sig(detail))
+        try:
+            with open(os.path.join(REPO, "bench_stages.json"), "w") as f:
+                f.write(text + "\n")
+        except OSError:
+            pass
+        print("#stages " + text)
+    line = json.dumps(sig(result))
+    if len(line) > LINE_LIMIT:
+        raise SystemExit(f"bench: the JSON line is {len(line)} bytes (> {LINE_LIMIT}): move detail to the #stages line")
+    print(line)
+    sys.stdout.flush()
 
 
 def parse():
@@ -84,7 +114,11 @@ def parse():
                          "all-to-all that hands each rank the lists of its own queries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
-    ap.add_argument("--no-stages", action="store_true", help="skip the `stages` object (other stages of the path, N = 1)")
+    ap.add_argument("--no-parity", action="store_true", help="c3 / c5: skip the oracle check of the step's output")
+    ap.add_argument("--no-stages", action="store_true", help="skip the stages (other stages of the path, N = 1)")
+    ap.add_argument("--sweep", action="store_true",
+                    help="stages: also run the two-stage path at 128 / 256 / 1024 / 2048 queries per batch (where the decode chain stops "
+                         "being launch-bound); off by default so that the default run stays near 40 s")
     a = ap.parse_args()
     if a.batch is None:
         a.batch = 64 if a.workload == "c3" else 512
@@ -146,8 +180,8 @@ def cpu_baseline(sd, cfg, ids, mask, D, k, budget_s=25.0):
         ts.append(time.perf_counter() - t0)
     med = sorted(ts)[2]
     return {"value": n / med, "unit": "queries/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
-            "sample": f"{n} of the step's queries through the whole path (encoder fp32 + Q.D^T top-{k} over "
-                      f"all {D.shape[0]} docs), torch-CPU oracle, warm-up + median of 5 ({med:.2f} s each)"}
+            "sample": f"{n} of the step's queries, whole path (fp32 encoder + Q.D^T top-{k} over all {D.shape[0]} docs), "
+                      f"torch-CPU oracle, median of 5 ({med:.2f} s each)"}
 
 
 def cpu_baseline_two_stage(sd, cfg, ids, mask, D, lookup, R, alphas, n=2, reps=1, budget_s=40.0):
@@ -181,9 +215,8 @@ def cpu_baseline_two_stage(sd, cfg, ids, mask, D, lookup, R, alphas, n=2, reps=1
     gen_s, tot_s = sorted(ts, key=lambda t: t[1])[len(ts) // 2]
     return {"value": n / tot_s, "unit": "queries/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
             "generate_s": gen_s, "total_s": tot_s, "rerank_ran": bool(ran[0]),
-            "sample": f"{n} quer{'y' if n == 1 else 'ies'} x {R} beams through the whole two-stage path in the reference's formulation "
-                      f"(use_cache=False recompute, full 302-column head, then in-cluster rerank over {len(alphas)} alphas), "
-                      f"torch-CPU oracle, median of {len(ts)} call(s) ({tot_s:.1f} s each, generate {gen_s:.1f} s)"}
+            "sample": f"{n} quer{'y' if n == 1 else 'ies'} x {R} beams, two-stage path as the reference runs it (use_cache=False, full "
+                      f"302-col head, rerank over {len(alphas)} alphas), torch-CPU oracle, median of {len(ts)} ({tot_s:.1f} s each)"}
 
 
 def recall_at(idx, gold, ks=(1, 10, 100)):
@@ -280,9 +313,9 @@ def stages(dev, cfg, D, D_dev, a):
                                  kary=30, position=1, score_rate=[0, 0.5, 1, 1.5, 2, 2.5, 3], loss_func="tanh")
     gen, cpu_two = {}, {}
     ids_np, mask_np = {}, {}
-    # C3 at infer.sh's eval batch, one query x 100 beams, C2's batch, and the batch sweep that shows where the decode chain stops
-    # being launch-bound (a reduced --corpus, as the contract test runs, skips the sweep)
-    sweep = ((64, 10), (1, 100), (512, 10)) + (((128, 10), (256, 10), (1024, 10), (2048, 10)) if N >= 300000 else ())
+    # C3 at infer.sh's eval batch, one query x 100 beams, C2's batch; --sweep: the batch sizes that show where the decode chain
+    # stops being launch-bound
+    sweep = ((64, 10), (1, 100), (512, 10)) + (((128, 10), (256, 10), (1024, 10), (2048, 10)) if a.sweep else ())
     for B, R in sweep:
         ids, mask = synth.make_tokens(B, L=40, seed=11)
         ids_np[(B, R)], mask_np[(B, R)] = ids, mask
@@ -309,9 +342,6 @@ def stages(dev, cfg, D, D_dev, a):
             "frac_of_floor": floor / (t - t_enc), "decode_tflops": flops / (t - t_enc) / 1e12,
             "decode_gflop_executed": flops_exec / 1e9, "decode_floor_executed_ms": floor_exec * 1e3,
             "frac_of_floor_executed": floor_exec / (t - t_enc), "decode_tflops_executed": flops_exec / (t - t_enc) / 1e12,
-            "note": "frac_of_floor prices the REFERENCE-EQUIVALENT work (every row, every step, adaptor + head included) — the "
-                    "gain of the exact eliminations shows up in it; frac_of_floor_executed prices only what the kernels "
-                    "really run (step-0 de-duplication and table hits subtracted) — the kernel-quality number",
             "decode_weight_stream_gbs": wbytes / (t - t_enc) / 1e9}
         (dec, _), _ = g()
         a_r = types.SimpleNamespace(**{**vars(args), "num_return_sequences": R})
@@ -340,9 +370,7 @@ def stages(dev, cfg, D, D_dev, a):
         out.setdefault("rerank", {})[f"B{B}_cand{ncand // B}"] = {
             "ms": t2 * 1e3, "queries_per_s": B / t2, "candidates": ncand, "gathered_mb": gbytes / 1e6,
             "gather_gbs": gbytes / t2 / 1e9, "frac_of_hbm_peak": gbytes / t2 / 1e9 / HBM_PEAK_GBS,
-            "note": "cluster lookup + dot + per-alpha select (3 launches, 20 calls back to back per timing); a gather of "
-                    f"{gbytes / 1e6:.1f} MB is {gbytes / (HBM_PEAK_GBS * 1e9) * 1e6:.1f} us at the HBM peak — the stage is launch-bound, not "
-                    "bandwidth-bound, at these sizes"}
+            "gather_us_at_hbm_peak": gbytes / (HBM_PEAK_GBS * 1e9) * 1e6}
         nb, depth = (16, 4) if B == 1 else (8, 2) if B <= 64 else (4, 2) if B <= 1024 else (3, 2)   # a stream of batches, `depth` in flight (GDRRetriever.validation_steps)
         tp = timed(lambda: list(retr.validation_steps(iter([batch] * nb), depth=depth)), reps=3, warm=1) / nb
         if B >= 512:           # the grow-only per-stream scratch of a big batch (tens of GB at 2 048 queries) must not pile up
@@ -358,17 +386,22 @@ def stages(dev, cfg, D, D_dev, a):
         out[skey] = {
             "batch": B, "beams": R, "ms": t3 * 1e3, "queries_per_s": B / t3, "pipelined_depth": depth,
             "pipelined_ms_per_batch": tp * 1e3, "pipelined_queries_per_s": B / tp,
-            "generate_ms": t * 1e3, "after_generate_ms": (t3 - t) * 1e3,
-            "note": "encoder -> beam decode -> device cluster lookup -> in-cluster rerank over 7 alphas -> host formatting; `ms` = one batch start to finish, "
-                    "`pipelined_*` = a stream of batches with `pipelined_depth` in flight on separate HIP streams while the "
-                    "host post-processes the previous one"}
+            "generate_ms": t * 1e3, "after_generate_ms": (t3 - t) * 1e3}
     for skey, cb in cpu_two.items():
         out[skey]["cpu_baseline"] = cb
-    best = max((v for kname, v in out.items() if kname.startswith("c3_two_stage")), key=lambda v: v["pipelined_queries_per_s"])
+    out["rerank"]["note"] = ("cluster lookup + dot + per-alpha select (3 launches, 20 calls back to back per timing): launch-bound, not "
+                             "bandwidth-bound, at these sizes (compare ms with gather_us_at_hbm_peak)")
+    out["c3_two_stage_note"] = ("encoder -> beam decode -> device cluster lookup -> in-cluster rerank over 7 alphas -> host formatting; `ms` = one "
+                                "batch start to finish, `pipelined_*` = a stream of batches with `pipelined_depth` in flight on separate HIP "
+                                "streams while the host post-processes the previous one")
+    best = max((v for kname, v in out.items() if kname.startswith("c3_two_stage") and isinstance(v, dict)), key=lambda v: v["pipelined_queries_per_s"])
     out["c3_best_sustained"] = {"batch": best["batch"], "beams": best["beams"], "queries_per_s": best["pipelined_queries_per_s"],
                                 "frac_of_floor_executed": gen[f"B{best['batch']}_beam{best['beams']}"]["frac_of_floor_executed"]}
     out["generate"] = gen
     out["generate"]["mflop_per_row_step"] = {"decoder": mf_dec, "adaptor": mf_adp, "head": mf_head}
+    out["generate"]["note"] = ("frac_of_floor prices the REFERENCE-EQUIVALENT work (every row, every step, adaptor + head included) — the "
+                               "gain of the exact eliminations shows up in it; frac_of_floor_executed prices only what the kernels "
+                               "really run (step-0 de-duplication and table hits subtracted) — the kernel-quality number")
     # ---- the trie-constrained mode (opt-in, generation_utils_previous.py:714-729): every hypothesis is a
     # docid of the corpus, so every beam has ended two steps after the deepest leaf and the call leaves its step loop there
     # (`if all(done): break`, generation_utils.py:836-838) — what a trained model does without the constraint, and what the
@@ -441,6 +474,117 @@ def stages(dev, cfg, D, D_dev, a):
     return out
 
 
+def two_stage_parity(retr, batch, mask_np, sd, cfg, look, args, D_dev, bf16, tree, nq1, nq2):
+    """The oracle check of a --workload c3 / c5 line (N = 1): the step the line times, held against the CPU oracle on a bounded
+    sample of its queries, with the rules the -m gpu tests use (oracle/parity_rules.py).
+      stage 1 (first nq1 queries): beam hypotheses as token rows.  fp32: oracle generate() on the same tokens — ranks exact
+        outside 1e-4 tolerance ties, scores within 1e-4.  bf16 (C5): the oracle's emulation of the decode path's rounding points
+        (t5_ref.bf16_linears) on the GPU's own encoder states; the score gap on shared hypotheses is MEASURED (<= 5e-3) and is the
+        absolute tie tolerance of hypothesis_lists_match; an id outside the emulation's list must be explained by a tie at a
+        cut of the emulation's own search.
+      stage 2 (first nq2 queries): oracle rerank on the candidate rows as the GPU holds them (bf16 rows widened exactly) and the
+        GPU's stage-1 order and scores: values within 1e-4, ids exact outside 1e-4 ties, for every alpha.
+    Returns the `parity` object; violations are counted, the caller exits non-zero on any."""
+    from oracle import beam_ref, codec_ref, retrieval_ref, t5_ref, parity_rules as pr
+    from gdr_amd import ops
+    R, V, TOL = args.num_return_sequences, args.output_vocab_size, 1e-4
+    state = retr._step_launch(batch)
+    out = retr._step_finish(state)
+    B = batch["source_ids"].shape[0]
+    nq1, nq2 = min(nq1, B), min(nq2, B)
+    got_scores = np.array(out["inf_result_batch_prob"], np.float64).reshape(B, R)
+    outs, _ = ops.finish_generate_output(state["ids"], state["lens"], state["scores"], args.max_output_length)
+    outs = outs.cpu().numpy().reshape(B, R, -1)
+
+    def canon(row):                     # START, tokens, [EOS, PAD...] -> the hypothesis without its padding
+        row = [int(t) for t in row]
+        return tuple(row[:2 + row[1:].index(1)]) if 1 in row[1:] else tuple(row)
+
+    got_rows = [[canon(r) for r in outs[q]] for q in range(nq1)]
+    ids_t, mask_t = batch["source_ids"][:nq1].cpu(), torch.from_numpy(mask_np[:nq1])
+    trace, ptrace = [], []
+    if bf16:
+        idx = torch.arange(nq1).view(-1, 1).repeat(1, R).view(-1)
+        enc_x, mask_x = state["enc_h"][:nq1].float().cpu().index_select(0, idx), mask_t.index_select(0, idx)
+
+        def step(seq):
+            with t5_ref.bf16_linears():
+                return t5_ref.decode_logits(sd, cfg, seq, enc_x, mask_x, restricted=True)
+
+        rd, rs = beam_ref.beam_search(step, nq1, R, cfg.decode_vocab_size, args.max_output_length, args.length_penalty, R,
+                                      decode_tree=tree, trace=trace, prefix_trace=ptrace)
+    else:
+        (rd, rs), _ = beam_ref.generate(sd, cfg, ids_t, mask_t, R, max_length=args.max_output_length,
+                                        length_penalty=args.length_penalty, restricted_head=True, decode_tree=tree)
+    ref_rows = [[canon(r) for r in rd.numpy().reshape(nq1, R, -1)[q]] for q in range(nq1)]
+    rs2 = np.array(rs, np.float64).reshape(nq1, R)
+    gap, shared, moved, foreign, bad1 = 0.0, 0, 0, 0, 0
+    for q in range(nq1):
+        where = {x: i for i, x in enumerate(ref_rows[q])}
+        hits = [abs(got_scores[q, p] - rs2[q, where[x]]) for p, x in enumerate(got_rows[q]) if x in where]
+        gap, shared = max([gap] + hits), shared + len(hits)
+    tie = max(gap, 2e-4) if bf16 else TOL
+    for q in range(nq1):
+        try:
+            if bf16:
+                assert gap <= 5e-3, f"score gap {gap:.2e} on shared hypotheses"
+                m, f, _sz = pr.hypothesis_lists_match(
+                    ref_rows[q], rs2[q], got_rows[q], tie,
+                    explain_foreign=lambda row, q=q: pr.beam_cut_explains_absence(trace, ptrace, q, R, cfg.decode_vocab_size, list(row), tie,
+                                                                                  lp=args.length_penalty, final_cut=rs2[q, -1]))
+                moved, foreign = moved + m, foreign + f
+            else:
+                moved += pr.ranked_lists_match(ref_rows[q], rs2[q], got_rows[q], TOL)
+                np.testing.assert_allclose(got_scores[q], rs2[q], rtol=TOL, atol=TOL)
+        except AssertionError as e:
+            bad1 += 1
+            print(f"bench parity: stage 1, query {q}: {str(e)[:300]}", file=sys.stderr)
+    if bf16 and shared < 0.95 * nq1 * R:
+        bad1 += 1
+    # ---- stage 2: the oracle rerank on the rows the GPU gathered, in the GPU's stage-1 order
+    q_emb = state["enc_h"][:nq2, 0].float().cpu()
+    cand = [[int(m) for s_ in out["clusters"][b] for m in look[s_]] for b in range(nq2)]
+    num = [[len(look[s_]) for s_ in out["clusters"][b]] for b in range(nq2)]
+    flat = torch.tensor(sorted({m for c in cand for m in c}), dtype=torch.long)
+    rows = D_dev[flat.to(D_dev.device)].float().cpu()
+    remap = {int(m): j for j, m in enumerate(flat.tolist())}
+    bad2, permuted = 0, 0
+    for b in range(nq2):
+        if len(cand[b]) < R:
+            continue                                            # topk(R) raises in the reference on fewer candidates
+        ref = retrieval_ref.rerank(q_emb[b:b + 1], rows, [[remap[m] for m in cand[b]]], [num[b]],
+                                   [got_scores[b].astype(np.float32).tolist()], args.score_rate, R)[0]
+        try:
+            for ai in range(len(args.score_rate)):
+                ref_ids = [str(int(flat[j])) for j in ref[ai][1].tolist()]
+                permuted += pr.ranked_lists_match(ref_ids, ref[ai][0].numpy(), out["doc_ids"][b][ai], TOL)
+                np.testing.assert_allclose(out["rerank_values"][b, ai].cpu().numpy(), ref[ai][0].numpy(), rtol=TOL, atol=TOL)
+        except AssertionError as e:
+            bad2 += 1
+            print(f"bench parity: stage 2, query {b}: {str(e)[:300]}", file=sys.stderr)
+    return {"stage1_queries": nq1, "stage1_ids_shared": shared, "stage1_ids_total": nq1 * R, "stage1_moved_inside_ties": moved,
+            "stage1_foreign_explained_by_a_cut_tie": foreign, "stage1_rows_violating": bad1, "score_gap": gap,
+            "stage2_queries": nq2, "stage2_permuted_slots_inside_ties": permuted, "stage2_rows_violating": bad2,
+            "against": ("oracle bf16 emulation on the GPU's encoder states; tie tolerance = the measured gap" if bf16 else
+                        "oracle generate() + rerank, fp32, tol 1e-4")}
+
+
+def stages_summary(st):
+    """A dozen scalars of the stages for the headline line (the full object goes to the #stages line)."""
+    g, sim = st["generate"], st["similarity_topk_f32"]
+    return {"c3_B64_beam10_qps": st["c3_two_stage"]["queries_per_s"],
+            "c3_best_sustained_qps": st["c3_best_sustained"]["queries_per_s"],
+            "B64_beam10_decode_ms": g["B64_beam10"]["decode_ms"],
+            "B64_beam10_frac_of_floor_executed": g["B64_beam10"]["frac_of_floor_executed"],
+            "B1_beam100_decode_ms": g["B1_beam100"]["decode_ms"],
+            "c3_constrained_B64_qps": st["generate_trie_constrained"]["B64_beam10"]["two_stage_queries_per_s"],
+            "bf16_c2_qps": st["bf16_mode_c2_step"]["queries_per_s"],
+            "bf16_B64_beam30_generate_ms": st["bf16_mode_generate_B64_beam30"]["generate_ms"],
+            "sim_B1_ms": sim["B1"]["ms"], "sim_B32_ms": sim["B32"]["ms"],
+            "sim_B32_frac_of_hbm_peak": sim["B32"]["frac_of_hbm_peak"],
+            "doc_tower_frac_of_f32_mfma_peak": st["doc_tower_bert_base_L128"]["frac_of_f32_mfma_peak"]}
+
+
 def fence(dist):
     torch.cuda.synchronize()
     if dist.is_initialized():
@@ -456,8 +600,9 @@ def launch_self(a):
     tail = [x for x in sys.argv[1:] if x != "--launcher"]
 
     def relay(line):
-        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
-        (sys.stdout if line.startswith("{") else sys.stderr).flush()
+        dst = sys.stdout if line.startswith(("{", "#stages ")) else sys.stderr
+        dst.write(line)
+        dst.flush()
 
     rc, _ = launch.spawn_ranks(a.gpus, tail, script=os.path.abspath(__file__), relay=relay)
     raise SystemExit(rc)
@@ -569,35 +714,44 @@ def two_stage_main(a):
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"{tag}: two-stage GDR, {B} q/GPU, beam {R}, {a.corpus}x{cfg.d_model} {'bf16' if bf16 else 'fp32'} corpus",
-                       "note": "a step = one batch per GPU through validation_step_i: ragged t5-base encoder -> docid beam decode "
-                               f"(beam {R}, 9 steps, prefix table) -> device cluster lookup -> in-cluster rerank over 7 alphas "
-                               f"(top-{R}) -> host formatting; {max(1, a.depth)} batches in flight"
-                               + ("; beams constrained to the corpus' docid trie" if a.constrained else
-                                  "; unconstrained beams of random weights run all 9 steps, every decoded string is mapped to a real 12-doc cluster")
-                               + (f"; corpus row-sharded {world} ways, stage 2 = one all-gather of queries + candidate blocks, per-shard "
-                                  "scoring, one all-to-all of the packed lists, merge" if sharded is not None else ""),
                        "dist_backend": a.backend if dist.is_initialized() else None,
                        "batch_per_gpu": B, "global_batch": B * world, "beams": R, "seq_len": 40, "corpus_rows": a.corpus,
                        "dim": cfg.d_model, "k": R, "alphas": 7, "candidates_per_query": n_cand, "pipeline_depth": max(1, a.depth),
-                       "corpus_resident_in_hbm": True, "docid_depth": id_depth},
+                       "docid_depth": id_depth},
             "roofline": {"bound": "mfma",
-                         "kernel": ("every linear of the step (encoder, decoder, adaptor, head): gdr::gemm_nt_bf16_glds_kernel" if bf16 else
-                                    "every linear of the step (encoder, decoder, adaptor, head): gdr::gemm_nt_f32_small_kernel (64x64 "
-                                    "tiles, the decode rows) + gdr::gemm_nt_f32 persistent / stream-K (encoder)"),
+                         "kernel": ("every linear of the step (encoder, decoder, adaptor, head): gdr::gemm_nt_bf16_*" if bf16 else
+                                    "every linear of the step: gdr::gemm_nt_f32_small_kernel (decode rows) + persistent / stream-K (encoder)"),
                          "achieved": lin_tf, "peak": peak, "unit": "TFLOP/s", "frac": lin_tf / peak, "traffic": None,
                          "launches_per_step": int(n_l[0]) / n_prof, "avg_launch_ms": ms_l[0] / max(1, int(n_l[0])),
-                         "linear_ms_per_step": ms_l[0] / n_prof, "source": f"profiled replay of {n_prof} step(s) after the timed region "
-                         "(hipEvent pairs on the launch streams; summed durations of two overlapping chains can exceed the step's wall time)",
-                         "events_lost": int(lost)},
+                         "linear_ms_per_step": ms_l[0] / n_prof, "events_lost": int(lost)},
             "kernels": {"attention_ms_per_step": ms_l[3] / n_prof, "rerank_dot_ms_per_step": ms_l[6] / n_prof,
                         "rerank_select_ms_per_step": ms_l[5] / n_prof, "splitk_reduce_ms_per_step": ms_l[7] / n_prof},
-            "cpu_baseline": None, "recall": None, "stages": None,
+            "cpu_baseline": None, "parity": None, "recall": None,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        detail = {"config_note": "a step = one batch per GPU through validation_step_i: ragged t5-base encoder -> docid beam decode "
+                  f"(beam {R}, 9 steps, prefix table) -> device cluster lookup -> in-cluster rerank over 7 alphas "
+                  f"(top-{R}) -> host formatting; {max(1, a.depth)} batches in flight; corpus resident in HBM"
+                  + ("; beams constrained to the corpus' docid trie" if a.constrained else
+                     "; unconstrained beams of random weights run all 9 steps, every decoded string is mapped to a real 12-doc cluster")
+                  + (f"; corpus row-sharded {world} ways, stage 2 = one all-gather of queries + candidate blocks, per-shard "
+                     "scoring, one all-to-all of the packed lists, merge" if sharded is not None else ""),
+                  "roofline_source": f"profiled replay of {n_prof} step(s) after the timed region (hipEvent pairs on the launch streams; "
+                                     "summed durations of two overlapping chains can exceed the step's wall time)"}
+        violations = 0
+        if world == 1 and not a.no_cpu_baseline and not a.no_parity:
+            tree = None
+            if a.constrained:
+                from oracle import beam_ref, codec_ref
+                tree = beam_ref.build_trie([codec_ref.encode_single_newid(s_, kary=30) for s_ in names])
+            result["parity"] = two_stage_parity(retr, batch, mask_all, sd, cfg, look, args, D_dev, bf16, tree,
+                                                nq1=2 if R > 10 else 4, nq2=64)
+            violations = result["parity"]["stage1_rows_violating"] + result["parity"]["stage2_rows_violating"]
+        if world == 1 and not a.no_cpu_baseline and not violations:
             result["cpu_baseline"] = cpu_baseline_two_stage(sd, cfg, ids_all, mask_all, D, look, R, args.score_rate,
                                                             n=1 if R > 10 else 2, reps=1 if R > 10 else 3)
-        print(json.dumps(result))
-        sys.stdout.flush()
+        emit(result, detail)
+        if violations:
+            raise SystemExit(f"bench: {violations} queries of the step differ from the CPU oracle outside the parity rule")
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -702,40 +856,38 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": ("C2" if world == 1 else "C4-layout") + ("/ragged" if ragged else "/padded") + ("/bf16" if bf16 else "") +
                        f": t5-base encoder {a.batch} q/GPU + Q.D^T top-{a.k}, {a.corpus}x{cfg.d_model} corpus",
-                       "note": f"t5-base encoder on {a.batch} queries/GPU (L=40) + fused Q.D^T top-{a.k} over a "
-                       f"{a.corpus}x{cfg.d_model} {'bf16' if bf16 else 'fp32'} corpus" +
-                       (" [C5 precision mode: bf16 linear operands, fp32 accumulate]" if bf16 else "") +
-                       (f" [ragged encoder: the {live_rows} non-PAD token rows of {a.batch * 40} are computed, last block "
-                        "on the CLS rows only; pooled output bit-identical to the padded form]" if ragged else
-                        " [padded encoder: all batch x 40 rows]") +
-                       ("" if world == 1 else f" row-sharded {world} ways, all-gather of queries, " +
-                        ("one all-gather of the packed per-shard top-k, merge of all queries on every rank" if a.replicated_merge
-                         else "one all-to-all of the packed per-shard top-k on a side stream under the next batch's encoder, "
-                              "local merge")),
                        "dist_backend": a.backend if dist.is_initialized() else None,
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 40,
-                       "corpus_rows": a.corpus, "dim": cfg.d_model, "k": a.k, "corpus_resident_in_hbm": True,
+                       "corpus_rows": a.corpus, "dim": cfg.d_model, "k": a.k,
                        "encoder_rows": "ragged" if ragged else "padded", "live_token_rows_per_gpu": live_rows},
             "roofline": {"bound": "mfma",
-                         "kernel": ("gdr::gemm_nt_bf16_glds_kernel (bf16 operands, LDS-DMA staging; every encoder linear)"
-                                    if bf16 else "gdr::gemm_nt_f32_persistent_kernel / gdr::gemm_nt_f32_streamk_kernel (every "
-                                    "encoder linear: the same 128x128 MFMA K-step stream, dealt as whole tiles or — where "
-                                    "whole tiles quantise badly — as equal K-step ranges with exact accumulator hand-off"
-                                    + ("; the last block's three CLS-row linears run on the 64x64-tile kernel; all are "
-                                       "included in launches / flops / time)" if ragged else ")")),
+                         "kernel": ("gdr::gemm_nt_bf16 (glds / persist256): every encoder linear" if bf16 else
+                                    "gdr::gemm_nt_f32_persistent_kernel / gemm_nt_f32_streamk_kernel: every encoder linear"),
                          "achieved": lin["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": lin["tflops"] / peak,
                          "traffic": None if bf16 else traffic,
-                         "traffic_source": None if (bf16 or traffic is None) else "profiles/traffic.json (static: rocprofv3 --pmc FETCH_SIZE / "
-                                           "WRITE_SIZE passes of this command, see profiles/r04_bench_pmc_hbm.md; not re-measured in this run)",
+                         "traffic_source": None if (bf16 or traffic is None) else "static: profiles/traffic.json (rocprofv3 --pmc passes of this command)",
                          "launches": lin["launches"], "avg_launch_ms": lin["avg_ms"],
                          "algorithmic_gflop_per_launch": lin["gflop_per_launch"], "share_of_step": lin["share_of_step"]},
-            "kernels": {"sim_sample_gemm": smp, "sim_filter_gemm": flt, "attention": att, "splitk_reduce": red},
         }
+        detail = {"config_note": f"t5-base encoder on {a.batch} queries/GPU (L=40) + fused Q.D^T top-{a.k} over a "
+                  f"{a.corpus}x{cfg.d_model} {'bf16' if bf16 else 'fp32'} corpus, resident in HBM" +
+                  (" [C5 precision mode: bf16 linear operands, fp32 accumulate]" if bf16 else "") +
+                  (f" [ragged encoder: the {live_rows} non-PAD token rows of {a.batch * 40} are computed, last block "
+                   "on the CLS rows only; pooled output bit-identical to the padded form]" if ragged else
+                   " [padded encoder: all batch x 40 rows]") +
+                  ("" if world == 1 else f" row-sharded {world} ways, all-gather of queries, " +
+                   ("one all-gather of the packed per-shard top-k, merge of all queries on every rank" if a.replicated_merge
+                    else "one all-to-all of the packed per-shard top-k on a side stream under the next batch's encoder, "
+                         "local merge")),
+                  "roofline_note": "the same 128x128 MFMA K-step stream dealt as whole tiles or, where whole tiles quantise badly, as "
+                                   "equal K-step ranges with exact accumulator hand-off; the last block's three CLS-row linears (64x64-tile "
+                                   "kernel) are included in launches / flops / time",
+                  "kernels": {"sim_sample_gemm": smp, "sim_filter_gemm": flt, "attention": att, "splitk_reduce": red}}
         if flt:
             # similarity as a whole (both GEMM passes): flops and the corpus bytes it must stream once
             sim_ms = (ms_l[1] + ms_l[2]) / a.steps
             rows = hi - lo
-            result["kernels"]["sim_total"] = {
+            detail["kernels"]["sim_total"] = {
                 "ms_per_step": sim_ms, "tflops": (w_l[1] + w_l[2]) / a.steps / (sim_ms * 1e-3) / 1e12,
                 "frac_of_mfma_peak": (w_l[1] + w_l[2]) / a.steps / (sim_ms * 1e-3) / 1e12 / peak,
                 "corpus_stream_gbs": rows * cfg.d_model * (2 if bf16 else 4) / (sim_ms * 1e-3) / 1e9,
@@ -743,6 +895,7 @@ def main():
         # The CPU leg (rank 0, N = 1 only): the oracle timed on the host cores, and — the metric's second half —
         # Recall@{1,10,100} of the GPU top-k against the oracle's on the same synthetic queries, with every one of the
         # rows held to the top-k parity rule.  Nothing outside this leg touches oracle/.
+        result["cpu_baseline"] = None
         result["recall"] = None
         if world == 1 and not a.no_cpu_baseline:
             if not a.no_recall:
@@ -756,21 +909,19 @@ def main():
                 result["recall"] = {"k": [1, 10, 100], "gpu": recall_at(gi.cpu().numpy(), gold),
                                     "cpu_oracle": recall_at(ci.numpy(), gold), "rows": a.batch,
                                     "topk_ids_identical_rows": identical, "permuted_slots": permuted,
-                                    "rows_violating_tie_rule": bad,
-                                    "rule": "values within 1e-4; ids exact outside groups of reference scores closer than 2e-4 "
-                                            "(relative), same id set inside such a group"}
+                                    "rows_violating_tie_rule": bad}
+                detail["recall_rule"] = ("values within 1e-4; ids exact outside groups of reference scores closer than 2e-4 "
+                                         "(relative), same id set inside such a group")
                 if bad:
-                    print(json.dumps(result))
+                    emit(result, detail)
                     raise SystemExit(f"bench: {bad} rows differ from the CPU oracle outside tolerance-tie groups")
             result["cpu_baseline"] = cpu_baseline(sd, cfg, ids_all, mask_all, D, a.k)
-        else:
-            result["cpu_baseline"] = None
-        result["stages"] = None
+        result["stages_summary"] = None
         if world == 1 and not a.no_stages and not bf16:
             del enc
-            result["stages"] = stages(dev, cfg, D, D_dev, a)
-        print(json.dumps(result))
-        sys.stdout.flush()
+            detail["stages"] = stages(dev, cfg, D, D_dev, a)
+            result["stages_summary"] = stages_summary(detail["stages"])
+        emit(result, detail)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -7,10 +7,12 @@ process and relays its output: the parent itself must not have initialised the G
 replaces itself with another program — on this pool an exec from a process that holds the GPU takes the machine down.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
 import threading
+import time
 
 
 def under_launcher():
@@ -24,6 +26,26 @@ def free_port():
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+def descendants(pid):
+    """PIDs of every live descendant of `pid` (children, grandchildren, ...) from /proc/<pid>/stat's parent field."""
+    kids = {}
+    for name in os.listdir("/proc"):
+        if not name.isdigit():
+            continue
+        try:
+            with open(f"/proc/{name}/stat") as f:
+                ppid = int(f.read().rsplit(")", 1)[1].split()[1])
+        except (OSError, ValueError, IndexError):
+            continue
+        kids.setdefault(ppid, []).append(int(name))
+    out, todo = [], [pid]
+    while todo:
+        for c in kids.get(todo.pop(), []):
+            out.append(c)
+            todo.append(c)
+    return out
 
 
 def spawn_ranks(n, argv, script=None, module=None, env=None, relay=True, timeout=None):
@@ -44,10 +66,31 @@ def spawn_ranks(n, argv, script=None, module=None, env=None, relay=True, timeout
     e.setdefault("OMP_NUM_THREADS", "1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "GROUP_RANK", "LOCAL_WORLD_SIZE"):
         e.pop(k, None)                                   # the children get their own
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=e, text=True, bufsize=1)
+    # torch.distributed.run puts every rank into a session of its own, so neither a SIGKILL to the launcher nor one to its process
+    # group reaches them: the ranks would live on as orphans that hold the GPUs AND the inherited stdout pipe, and the read loop
+    # below would never end.  stop() therefore walks the launcher's process tree and kills exactly those PIDs.
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=e, text=True, bufsize=1, start_new_session=True)
     lines = []
+
+    def stop(grace=5.0):
+        """SIGTERM to the launcher (torch.distributed.run forwards it to its workers), then SIGKILL to every process of its tree
+        (collected before and after the grace period: a rank re-parented to init is no longer findable through its parent)."""
+        tree = set(descendants(proc.pid))
+        try:
+            proc.terminate()
+            t_end = time.monotonic() + grace
+            while proc.poll() is None and time.monotonic() < t_end:
+                time.sleep(0.05)
+                tree.update(descendants(proc.pid))
+        finally:
+            for pid in sorted(tree | {proc.pid}):
+                try:
+                    os.kill(pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
     # the read loop below only ends when the ranks close their stdout: a watchdog enforces `timeout` on a hung launch
-    watchdog = threading.Timer(timeout, proc.kill) if timeout else None
+    watchdog = threading.Timer(timeout, stop) if timeout else None
     if watchdog:
         watchdog.daemon = True
         watchdog.start()
@@ -61,7 +104,7 @@ def spawn_ranks(n, argv, script=None, module=None, env=None, relay=True, timeout
                 sys.stdout.flush()
         rc = proc.wait()
     except BaseException:
-        proc.kill()
+        stop()
         proc.wait()
         raise
     finally:

@@ -11,37 +11,58 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*extra):
+def _run(*extra, with_detail=False):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64",
-                          "--corpus", "30000", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--corpus", "30000", *extra], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    all_lines = out.stdout.splitlines()
+    lines = [l for l in all_lines if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line on stdout"
-    return json.loads(lines[0])
+    assert all_lines[-1] == lines[0], "the JSON line is the LAST line of stdout"
+    # the round driver keeps the last 8 KB of stdout: the headline must fit with room to spare (round 4's line was 20 KB and was lost)
+    assert len(lines[0]) <= 4096, len(lines[0])
+    j = json.loads(lines[0])
+    if not with_detail:
+        return j
+    det = [l for l in all_lines if l.startswith("#stages ")]
+    assert len(det) == 1
+    return j, json.loads(det[0][len("#stages "):])
 
 
 def test_bench_line_contract_fp32():
-    j = _run()
+    """The DEFAULT stage list (exactly what `python bench.py` runs, on a reduced corpus): the line's shape and length are those of
+    the full-size run — the stage keys do not depend on --corpus."""
+    j, det = _run(with_detail=True)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "recall", "stages_summary"):
         assert key in j, key
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True
     assert j["dtype"] == "f32" and j["data"] == "synthetic" and j["scaling"] == "weak" and j["vs_baseline"] is None
     assert "workload" in j["config"] and "model" not in j["config"]
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1 and len(r["kernel"]) <= 120
+    for key in ("traffic", "traffic_source", "launches", "avg_launch_ms", "algorithmic_gflop_per_launch", "share_of_step"):
+        assert key in r, key
     c = j["cpu_baseline"]
-    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    assert j["value"] > 0 and abs(j["value"] - 64 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and 0 < len(c["sample"]) <= 160
+    assert j["value"] > 0 and abs(j["value"] - 64 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
     rec = j["recall"]
     assert rec["gpu"] == rec["cpu_oracle"], "Recall@{1,10,100} parity with the CPU oracle"
     assert rec["rows_violating_tie_rule"] == 0 and rec["topk_ids_identical_rows"] + 8 >= rec["rows"]
     assert j["config"]["encoder_rows"] == "ragged" and j["config"]["workload"].startswith("C2/ragged")
-    assert len(j["config"]["workload"]) <= 100 and "ragged encoder" in j["config"]["note"]
+    assert len(j["config"]["workload"]) <= 100 and "ragged encoder" in det["config_note"]
     assert "static" in r["traffic_source"] or r["traffic"] is None
     assert c["cpu_model"]
-    st = j["stages"]                                   # the other stages of the path, measured after the timed region
+    ss = j["stages_summary"]                           # a dozen scalars of the other stages; the full object is on the #stages line
+    assert len(ss) <= 12 and all(isinstance(v, (int, float)) and v > 0 for v in ss.values()), ss
+    for key in ("c3_B64_beam10_qps", "B64_beam10_decode_ms", "B64_beam10_frac_of_floor_executed", "B1_beam100_decode_ms",
+                "c3_best_sustained_qps", "bf16_c2_qps", "bf16_B64_beam30_generate_ms", "sim_B32_ms", "sim_B32_frac_of_hbm_peak",
+                "doc_tower_frac_of_f32_mfma_peak"):
+        assert key in ss, key
+    assert os.path.exists(os.path.join(ROOT, "bench_stages.json"))
+    st = det["stages"]                                 # the other stages of the path, measured after the timed region
+    assert abs(ss["B64_beam10_decode_ms"] - st["generate"]["B64_beam10"]["decode_ms"]) < 1e-6
     lat = st["similarity_topk_f32"]["B32"]
     assert lat["bound"] == "hbm" and 0 < lat["frac_of_hbm_peak"] < 1
     for key in ("B64_beam10", "B1_beam100"):
@@ -55,20 +76,22 @@ def test_bench_line_contract_fp32():
         assert 0 < cb["generate_s"] <= cb["total_s"]
     assert st["c3_best_sustained"]["queries_per_s"] >= st["c3_two_stage"]["pipelined_queries_per_s"]
     assert st["prefix_table"]["nodes"] > 1
-    rr = st["rerank"]
+    rr = {k: v for k, v in st["rerank"].items() if k != "note"}
     assert any(k.startswith("B64_cand") for k in rr) and any(k.startswith("B1_cand") for k in rr)
     assert all(0 < v["frac_of_hbm_peak"] < 1 and v["candidates"] > 0 for v in rr.values())
     assert st["c3_two_stage"]["after_generate_ms"] < st["c3_two_stage"]["ms"]
     con = st["generate_trie_constrained"]["B64_beam10"]        # constrained beams end early: the call must be shorter
     assert 0 < con["decode_ms"] < st["generate"]["B64_beam10"]["decode_ms"] and con["two_stage_queries_per_s"] > 0
     assert st["c3_two_stage_B512"]["queries_per_s"] > st["c3_two_stage"]["queries_per_s"] > 0
+    assert "c3_two_stage_B2048" not in st, "the batch sweep is behind --sweep"
     assert 0 < st["doc_tower_bert_base_L128"]["frac_of_f32_mfma_peak"] < 1
+    assert len(json.dumps(det).split("frac_of_floor prices")) == 2, "the long note is printed once"
 
 
 def test_bench_padded_encoder_form_gives_the_same_recall():
     a, b = _run("--encoder", "padded", "--no-stages"), _run("--no-stages")
     assert a["config"]["encoder_rows"] == "padded" and b["config"]["encoder_rows"] == "ragged"
-    assert a["recall"] == b["recall"] and a["stages"] is None
+    assert a["recall"] == b["recall"] and a["stages_summary"] is None
 
 
 def test_bench_line_contract_bf16_mode():
@@ -83,7 +106,7 @@ def test_bench_two_stage_workloads_and_the_self_launch():
     j = _run("--workload", "c3", "--gpus", "1", "--launcher", "--batch", "8", "--no-cpu-baseline")
     assert j["config"]["workload"].startswith("C3/sharded") and len(j["config"]["workload"]) <= 100
     assert j["n_gpus"] == 1 and j["dtype"] == "f32" and j["config"]["beams"] == 10 and j["config"]["candidates_per_query"] == 120
-    assert j["value"] > 0 and abs(j["value"] - 8 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    assert j["value"] > 0 and abs(j["value"] - 8 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
     r = j["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["launches_per_step"] > 100 and r["events_lost"] == 0
     k = _run("--workload", "c5", "--batch", "8")
@@ -91,8 +114,14 @@ def test_bench_two_stage_workloads_and_the_self_launch():
     assert k["roofline"]["peak"] == 2500.0 and k["value"] > 0
     c = k["cpu_baseline"]
     assert c["kind"] == "port" and 0 < c["value"] < k["value"] and 0 < c["generate_s"] <= c["total_s"]
-    u = _run("--workload", "c3", "--batch", "8", "--no-cpu-baseline", "--constrained")
+    p = k["parity"]              # the step's output held against the oracle's bf16 emulation inside the bench line
+    assert p["stage1_rows_violating"] == 0 and p["stage2_rows_violating"] == 0 and p["stage1_queries"] == 2 and p["stage2_queries"] == 8
+    assert p["stage1_ids_shared"] >= 0.95 * p["stage1_ids_total"] and 0 < p["score_gap"] <= 5e-3
+    u = _run("--workload", "c3", "--batch", "8", "--constrained")
     assert u["config"]["workload"].startswith("C3/constrained:") and u["value"] > 0
+    p = u["parity"]
+    assert p["stage1_rows_violating"] == 0 and p["stage2_rows_violating"] == 0 and p["stage1_queries"] == 4
+    assert p["stage1_ids_shared"] >= 0.95 * p["stage1_ids_total"] and p["score_gap"] <= 1e-4
 
 
 def test_bench_gpus_2_on_one_gpu_through_gloo():
@@ -103,7 +132,7 @@ def test_bench_gpus_2_on_one_gpu_through_gloo():
     j = _run("--gpus", "2", "--backend", "gloo", "--no-stages")
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 128 and j["config"]["workload"].startswith("C4-layout")
     assert j["config"]["dist_backend"] == "gloo" and j["value"] > 0 and j["cpu_baseline"] is None
-    assert abs(j["value"] - 128 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    assert abs(j["value"] - 128 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
     k = _run("--gpus", "2", "--backend", "gloo", "--workload", "c3", "--batch", "8")
     assert k["n_gpus"] == 2 and k["config"]["workload"].startswith("C3/sharded") and k["config"]["global_batch"] == 16
     assert k["value"] > 0 and k["config"]["candidates_per_query"] == 120

@@ -515,6 +515,31 @@ def test_sharded_two_stage_retriever_gloo(tmp_path, world):
     assert all(r[0] == 1 and r[1] > 0 for r in rows), rows
 
 
+def test_launcher_timeout_kills_the_whole_rank_group(tmp_path):
+    """A hung launch is bounded by `timeout=` and leaves nobody behind: the launcher and its ranks run in a process group of their
+    own, the watchdog terminates the launcher and then SIGKILLs the group (a SIGKILL to torch.distributed.run alone would orphan
+    the ranks, which keep the GPUs and the stdout pipe: spawn_ranks would never return)."""
+    import time
+    from gdr_amd import launch
+    stub = tmp_path / "hang_stub.py"
+    stub.write_text(
+        "import os, signal, sys, time\n"
+        "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"          # a rank that does not even honour SIGTERM
+        "open(os.path.join(sys.argv[1], 'pid%s' % os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+        "print('[rank] up', flush=True)\n"
+        "time.sleep(600)\n")
+    t0 = time.monotonic()
+    rc, text = launch.spawn_ranks(2, [str(tmp_path)], script=str(stub), relay=False, timeout=6)
+    took = time.monotonic() - t0
+    assert rc != 0 and took < 60, (rc, took)
+    pids = [int(f.read_text()) for f in tmp_path.glob("pid*")]
+    assert len(pids) == 2
+    time.sleep(0.5)
+    for pid in pids:
+        alive = os.path.exists(f"/proc/{pid}") and "Z" not in open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0]
+        assert not alive, f"rank process {pid} survived the launcher's timeout"
+
+
 def test_launcher_spawns_fresh_ranks_and_relays_one_json_line(tmp_path, monkeypatch, capsys):
     """`python bench.py --gpus N` with no RANK in the environment (the driver's multi-GPU command; the reference's analogue of
     one command fanning out over the GPUs is Data_process/NQ_dataset/bert/bert_NQ.sh:5-12): gdr_amd.launch.spawn_ranks starts
