@@ -115,6 +115,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="c3 / c5: skip the oracle check of the step's output")
+    ap.add_argument("--parity-queries", type=int, nargs=2, default=None, metavar=("STAGE1", "STAGE2"),
+                    help="c3 / c5: queries of the step held against the oracle in stage 1 (beam decode; default 4, 2 above beam 10) "
+                         "and stage 2 (rerank; default 64)")
     ap.add_argument("--no-stages", action="store_true", help="skip the stages (other stages of the path, N = 1)")
     ap.add_argument("--sweep", action="store_true",
                     help="stages: also run the two-stage path at 128 / 256 / 1024 / 2048 queries per batch (where the decode chain stops "
@@ -744,7 +747,8 @@ def two_stage_main(a):
                 from oracle import beam_ref, codec_ref
                 tree = beam_ref.build_trie([codec_ref.encode_single_newid(s_, kary=30) for s_ in names])
             result["parity"] = two_stage_parity(retr, batch, mask_all, sd, cfg, look, args, D_dev, bf16, tree,
-                                                nq1=2 if R > 10 else 4, nq2=64)
+                                                nq1=a.parity_queries[0] if a.parity_queries else (2 if R > 10 else 4),
+                                                nq2=a.parity_queries[1] if a.parity_queries else 64)
             violations = result["parity"]["stage1_rows_violating"] + result["parity"]["stage2_rows_violating"]
         if world == 1 and not a.no_cpu_baseline and not violations:
             result["cpu_baseline"] = cpu_baseline_two_stage(sd, cfg, ids_all, mask_all, D, look, R, args.score_rate,

@@ -124,6 +124,19 @@ def test_bench_two_stage_workloads_and_the_self_launch():
     assert p["stage1_ids_shared"] >= 0.95 * p["stage1_ids_total"] and p["score_gap"] <= 1e-4
 
 
+def test_c5_at_the_bench_batch_512_queries_beam_30_vs_oracle():
+    """BASELINE config C5 at the batch the bench line runs — 512 queries x 30 beams = 15 360 beam rows, where the bf16 linears route
+    to their large-batch forms (128- / 256-row tiles, persistent kernels, device-side row counts) — on a 100 000-row bf16 corpus:
+    stage 1 of 4 queries against the oracle's bf16 emulation under hypothesis_lists_match (tie tolerance = the measured score gap),
+    stage 2 of all 512 queries against retrieval_ref.rerank.  The check is the bench line's own `parity` leg (bench.two_stage_parity)."""
+    j = _run("--workload", "c5", "--batch", "512", "--corpus", "100000", "--parity-queries", "4", "512")
+    assert j["config"]["batch_per_gpu"] == 512 and j["config"]["beams"] == 30 and j["dtype"] == "bf16"
+    p = j["parity"]
+    assert p["stage1_queries"] == 4 and p["stage2_queries"] == 512
+    assert p["stage1_rows_violating"] == 0 and p["stage2_rows_violating"] == 0
+    assert p["stage1_ids_shared"] >= 0.95 * p["stage1_ids_total"] and 0 < p["score_gap"] <= 5e-3
+
+
 def test_bench_gpus_2_on_one_gpu_through_gloo():
     """`python bench.py --gpus 2` as the driver types it (no launcher, no RANK in the environment): bench.py starts its two ranks
     itself; `--backend gloo` lets them share this box's one GPU (RCCL refuses that), so the whole N > 1 path runs with real
