@@ -620,7 +620,13 @@ def init_ranks(a):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         a.gpus = world
-    local_rank %= max(1, torch.cuda.device_count())                      # more ranks than GPUs (--backend gloo): they share
+    n_dev = torch.cuda.device_count()                                    # counting devices does not initialise the GPU
+    if a.backend == "nccl" and world > max(1, n_dev):
+        # RCCL refuses two ranks on one device; folding ranks onto the GPUs that exist would print a number that is not a scaling
+        # measurement under the product backend's name
+        raise SystemExit(f"bench: --backend nccl with WORLD_SIZE {world} needs {world} GPUs, this node has {n_dev} "
+                         "(use --backend gloo to let ranks share a GPU: a functional run, not a scaling measurement)")
+    local_rank %= max(1, n_dev)                                          # more ranks than GPUs (--backend gloo): they share
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run

@@ -183,6 +183,17 @@ def check_device_fault(what):
         raise GdrError(f"{what}: " + lib().gdr_last_error().decode("utf-8", "replace"))
 
 
+def clear_device_fault():
+    """Acknowledges a reported device fault (gdr_device_fault_clear).  WHO OWNS THE CLEAR: the caller that saw the GdrError of
+    check_device_fault() and has discarded (or will redo) the step it belongs to — GDRRetriever.validation_steps / main.inference
+    do so after reporting the failed batch; a long-lived process that only logs the error must call this before it goes on,
+    otherwise every later stream-K launch of the process keeps failing with GDR_EHIP.  Returns True if a fault was pending.
+    In a multi-rank job the decision to go on must be collective (dist.all_ranks_ok): a fault is rank-local."""
+    pending = bool(lib().gdr_device_fault_pending())
+    lib().gdr_device_fault_clear()
+    return pending
+
+
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())

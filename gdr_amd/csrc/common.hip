@@ -121,4 +121,7 @@ extern "C" const char* gdr_last_error(void) { return gdr::g_err; }
 // 4: gdr_t5_generate_early_exits added (gdr_t5_generate leaves its step loop when every query is done);
 //    GdrPrefixTable.complete_levels
 // 5: gdr_rerank_wire_pack / _unpack / gdr_rerank_positions_to_ids (the sharded two-stage path's exchange row)
+// 6: gdr_device_fault_pending / _clear / _inject_for_tests (a stream-K hand-off that times out no longer traps: it raises a sticky
+//    process-wide word and every stream-K launch enqueued while it is raised fails with GDR_EHIP); gdr_t5_layer_norm (a2 as an
+//    operator of its own); gdr_t5_generate_last_done_step
 extern "C" int gdr_abi_version(void) { return 6; }

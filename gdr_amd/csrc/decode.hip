@@ -536,6 +536,16 @@ __device__ __forceinline__ void hyp_load(HypLds& H, char* smem, const BeamBufs& 
   wave_sync();
 }
 
+// the same view of the LDS arrays for waves that do not take part in the load (beam_finalize_kernel)
+__device__ __forceinline__ void hyp_load_ptrs(HypLds& H, char* smem, const BeamBufs& bb, const BeamDims& bd, int b) {
+  const int cap = bd.R + 1;
+  H.sc = reinterpret_cast<double*>(smem);
+  H.ln = reinterpret_cast<int32_t*>(H.sc + cap);
+  H.sq = H.ln + cap;
+  H.tk = H.sq + cap;
+  H.n = bb.hyp_cnt[b], H.next = bb.hyp_next[b], H.worst = bb.hyp_worst[b];
+}
+
 __device__ __forceinline__ void hyp_store(const HypLds& H, const BeamBufs& bb, const BeamDims& bd, int b, int lane) {
   const int cap = bd.R + 1, ml = bd.maxlen;
   wave_sync();
@@ -724,31 +734,104 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamBufs bb, BeamDims 
   anc_update_query(bb, bd, b, cur_len, cur, tid);
 }
 
-// :862-919 finalise open beams, pick the nret best per query, lay out tokens / EOS / PAD.  One wave per query.
-__global__ __launch_bounds__(64) void beam_finalize_kernel(BeamBufs bb, BeamDims bd, int final_len, int cur, int max_length,
-                                                           int64_t* out_ids, int32_t* out_len, double* out_scores) {
+// :862-919 finalise open beams, pick the nret best per query, lay out tokens / EOS / PAD.  One workgroup of four waves per query.
+// The R open beams of a query that is not done enter its hypothesis heap one after another in the reference (:863-883).  What that
+// sequence leaves behind is decided by the scores alone except inside ONE tie group: with v = the R-th largest score over the old
+// entries and the R new ones, every entry above v survives (when it is offered the full heap holds something smaller, and nothing
+// can evict it), nothing below v does (a full heap's minimum never decreases), and when the entries equal to v all fit they all
+// survive — the heap ends with R entries and they are the only candidates left.  So the survivors are found by counting (R^2
+// compares spread over 256 lanes instead of R dependent heap updates of one wave: 165 us at 100 beams); only when the tie group AT
+// v is cut by the capacity — equal double-precision scores of different hypotheses — the admission / eviction order matters
+// (strict `>` against the worst score, the oldest of the worst evicted) and the original one-by-one walk runs.  The insertion numbers
+// only ever decide the relative order of equal scores: new entry j takes next + j (offer order).
+__global__ __launch_bounds__(256) void beam_finalize_kernel(BeamBufs bb, BeamDims bd, int final_len, int cur, int max_length,
+                                                            int64_t* out_ids, int32_t* out_len, double* out_scores) {
   extern __shared__ __attribute__((aligned(16))) char bsm[];
-  const int b = blockIdx.x, lane = threadIdx.x;
+  __shared__ int n_fin, cut_tie, n_keep;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int R = bd.R, ml = bd.maxlen;
   HypLds H;
-  hyp_load(H, bsm, bb, bd, b, lane);
+  if (wave == 0) hyp_load(H, bsm, bb, bd, b, lane);
+  else hyp_load_ptrs(H, bsm, bb, bd, b);
   int32_t* order = reinterpret_cast<int32_t*>(bsm + ((hyp_lds_bytes(R, ml) + 15) & ~(size_t)15));  // [nret] entry of rank j
-  if (!bb.done[b]) {
-    // the R open beams enter the heap one after another (:863-883).  Their rows are staged in LDS first: read one by one
-    // from device memory, every add paid a dependent round trip (172 us at 100 beams, rocprofv3; 100 adds)
-    int32_t* rows_s = order + bd.nret;                         // [R][ml]
-    float* sc_s = reinterpret_cast<float*>(rows_s + R * ml);   // [R]
-    for (int e = lane; e < R * ml; e += 64) rows_s[e] = bb.seq[cur][(size_t)b * R * ml + e];
-    for (int j = lane; j < R; j += 64) sc_s[j] = bb.beam_scores[b * R + j];
-    wave_sync();
+  int32_t* rows_s = order + bd.nret;                         // [R][ml] the open beams' rows
+  float* sc_s = reinterpret_cast<float*>(rows_s + R * ml);   // [R]
+  double* all_sc = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(sc_s + R) + 7) & ~(uintptr_t)7);  // [2R + 1] old entries' scores, then the new ones'
+  int32_t* keep = reinterpret_cast<int32_t*>(all_sc + 2 * R + 1);  // [2R + 1] slot of a surviving entry, -1 otherwise
+  if (tid == 0) n_fin = H.n, cut_tie = 0, n_keep = 0;
+  __syncthreads();
+  const bool open = !bb.done[b];  // uniform
+  if (open) {
+    // the rows are staged in LDS first: read one by one from device memory, every add paid a dependent round trip
+    for (int e = tid; e < R * ml; e += 256) rows_s[e] = bb.seq[cur][(size_t)b * R * ml + e];
+    for (int j = tid; j < R; j += 256) sc_s[j] = bb.beam_scores[b * R + j];
+    __syncthreads();
     const double len_pow = pow((double)final_len, bd.lp);
-    for (int j = 0; j < R; ++j) hyp_add(H, bd, rows_s + j * ml, final_len, (double)sc_s[j], lane, len_pow);
+    const int n0 = H.n, T = n0 + R;
+    for (int i = tid; i < T; i += 256) all_sc[i] = i < n0 ? H.sc[i] : (double)sc_s[i - n0] / len_pow;
+    __syncthreads();
+    // survivors by counting; a cut tie group is flagged
+    for (int i = tid; i < T; i += 256) {
+      const double v = all_sc[i];
+      int gt = 0, eq = 0;
+      for (int j = 0; j < T; ++j) {
+        const double w = all_sc[j];
+        gt += w > v ? 1 : 0, eq += w == v ? 1 : 0;
+      }
+      const bool in = gt + eq <= R;               // the whole group of equal scores fits
+      if (!in && gt < R && eq > 1) cut_tie = 1;   // the group at the boundary is cut and holds several entries (benign race: all store 1)
+      // a cut group of ONE entry cannot exist (gt < R and eq == 1 means gt + eq <= R)
+      keep[i] = in ? 1 : 0;
+    }
+    __syncthreads();
+    if (cut_tie) {
+      if (wave == 0) {  // the reference's walk, one add after another
+        for (int j = 0; j < R; ++j) hyp_add(H, bd, rows_s + j * ml, final_len, (double)sc_s[j], lane, len_pow);
+        if (lane == 0) n_fin = H.n;
+      }
+    } else {
+      // compact the survivors into the heap arrays: old entries first (their relative storage order is free), then new ones;
+      // old entries that do not survive leave holes that surviving NEW entries fill
+      if (wave == 0) {
+        // slots: survivors are numbered in index order by ballot prefix sums
+        int base = 0;
+        for (int i0 = 0; i0 < T; i0 += 64) {
+          const int i = i0 + lane;
+          const bool kp = i < T && keep[i] != 0;
+          const unsigned long long m = __ballot(kp);
+          if (i < T) keep[i] = kp ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+          base += __popcll(m);
+        }
+        if (lane == 0) n_fin = base;
+      }
+      __syncthreads();
+      // Move in two steps through registers-free staging: scores / lengths / insertion numbers / tokens of survivors are first
+      // gathered into the tail region (rows_s is reused as scratch for tokens is not possible — it is the source), so the old entries
+      // are moved in ascending slot order by one wave (slot <= index: a survivor never moves up), then new entries are written.
+      if (wave == 0) {
+        for (int i = 0; i < n0; ++i) {  // uniform loop; slot <= i, so the source of a later move is never overwritten earlier
+          const int sl = keep[i];
+          if (sl >= 0 && sl != i) {
+            if (lane == 0) H.sc[sl] = H.sc[i], H.ln[sl] = H.ln[i], H.sq[sl] = H.sq[i];
+            for (int t = lane; t < ml; t += 64) H.tk[(size_t)sl * ml + t] = H.tk[(size_t)i * ml + t];
+            wave_sync();
+          }
+        }
+      }
+      __syncthreads();
+      for (int j = wave; j < R; j += 4) {  // a wave per new entry
+        const int sl = keep[n0 + j];
+        if (sl < 0) continue;
+        if (lane == 0) H.sc[sl] = all_sc[n0 + j], H.ln[sl] = final_len, H.sq[sl] = H.next + j;
+        for (int t = lane; t < final_len; t += 64) H.tk[(size_t)sl * ml + t] = rows_s[j * ml + t];
+      }
+    }
   }
   __syncthreads();
   // sorted(beams, key=score) is stable ascending and pop() takes the last: highest score first, among equal scores the
   // later list entry first.  rank(i) = number of entries that precede i in that order.
-  const int n = H.n;
-  for (int i = lane; i < n; i += 64) {
+  const int n = n_fin;
+  for (int i = tid; i < n; i += 256) {
     const double v = H.sc[i];
     const int q = H.sq[i];
     int rank = 0;
@@ -759,13 +842,13 @@ __global__ __launch_bounds__(64) void beam_finalize_kernel(BeamBufs bb, BeamDims
     if (rank < bd.nret) order[rank] = i;
   }
   __syncthreads();
-  for (int j = lane; j < bd.nret; j += 64) {
+  for (int j = tid; j < bd.nret; j += 256) {
     const size_t o = (size_t)b * bd.nret + j;
     // fewer hypotheses than requested cannot happen when V^depth >= R (the reference would raise)
     out_len[o] = j < n ? H.ln[order[j]] : 0;
     out_scores[o] = j < n ? H.sc[order[j]] : -INFINITY;
   }
-  for (int e = lane; e < bd.nret * max_length; e += 64) {
+  for (int e = tid; e < bd.nret * max_length; e += 256) {
     const int j = e / max_length, t = e - j * max_length;
     int64_t v = PAD_ID;
     if (j < n) {
@@ -822,9 +905,10 @@ static int beam_begin(const BeamBufs& bb, const BeamDims& bd, hipStream_t stream
 
 static int beam_end(const BeamBufs& bb, const BeamDims& bd, int max_length, int cur, int64_t* out_ids,
                     int32_t* out_len, double* out_scores, hipStream_t stream) {
-  const size_t hyp_lds = ((hyp_lds_bytes(bd.R, bd.maxlen) + 15) & ~(size_t)15) + (size_t)bd.R * 4 +
-                         (size_t)bd.R * bd.maxlen * 4 + (size_t)bd.R * 4;  // + the staged beam rows and scores
-  hipLaunchKernelGGL(beam_finalize_kernel, dim3(bd.B), dim3(64), hyp_lds, stream, bb, bd, max_length, cur, max_length, out_ids,
+  const size_t hyp_lds = ((hyp_lds_bytes(bd.R, bd.maxlen) + 15) & ~(size_t)15) + (size_t)bd.nret * 4 +
+                         (size_t)bd.R * bd.maxlen * 4 + (size_t)(bd.R + 2) * 4 +   // + the staged beam rows and scores
+                         (size_t)(2 * bd.R + 2) * 12 + 16;                         // + all scores (double) and survivor slots
+  hipLaunchKernelGGL(beam_finalize_kernel, dim3(bd.B), dim3(256), hyp_lds, stream, bb, bd, max_length, cur, max_length, out_ids,
                      out_len, out_scores);
   GDR_CHECK_LAUNCH("beam_finalize_kernel");
   return GDR_OK;

@@ -332,11 +332,20 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
 constexpr int HALF_BYTES = 128 * 128;                 // one half-tile
 constexpr int OFF_A_LO = 0, OFF_A_HI = HALF_BYTES, OFF_B_LO = 2 * HALF_BYTES, OFF_B_HI = 3 * HALF_BYTES, BUF_BYTES = 4 * HALF_BYTES;
 
+// BN = 256, or 192 (each wave column 48 wide: a "lo" half of two 16-column blocks and a "hi" half of one): the tile WIDTH is chosen
+// per launch so that the tile count quantises well on 256 CUs — 15 360 beam rows x N = 768 are 180 tiles of 256 x 256 (70 % of one
+// round) but 240 of 256 x 192 (94 %); N = 2 304: 540 tiles = 3 rounds at 70 % against 720 = 3 rounds at 94 %.  Same k order.
+template <int BN>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16GemmArgs g) {
+  static_assert(BN == 256 || BN == 192, "tile width");
+  constexpr int WCOLS = BN / 4;           // columns per wave column: 64 or 48
+  constexpr int NBH = BN == 256 ? 2 : 1;  // 16-column blocks in the hi half (the lo half always holds 2)
+  constexpr int NB = 2 + NBH;
+  constexpr int HI_ROWS = 16 * NBH;       // B rows per wave column in the hi half-tile
   extern __shared__ __attribute__((aligned(1024))) char smem256[];
   unsigned bid = blockIdx.x;
   const int64_t Mv = g.m_dev ? *g.m_dev : g.M;
-  const int tiles_n = (g.N + 255) / 256;
+  const int tiles_n = (g.N + BN - 1) / BN;
   {
     // XCD-aware remap over the LIVE tile count (see gemm_nt_bf16_glds_kernel): hardware blocks past it exit
     unsigned nblk = gridDim.x;
@@ -352,14 +361,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
   }
   const int64_t m0 = (int64_t)(bid / (unsigned)tiles_n) * 256;
   if (m0 >= Mv) return;  // uniform
-  const int n0 = (int)(bid % (unsigned)tiles_n) * 256;
+  const int n0 = (int)(bid % (unsigned)tiles_n) * BN;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wr = wave >> 2, wc = wave & 3, r16 = lane & 15, q4 = lane >> 4;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem256));
-  // ---- staging: instruction i of wave w covers local rows (w*2 + i)*8 + (lane>>3) of a half-tile
+  // ---- staging: instruction i of wave w covers local rows (w*2 + i)*8 + (lane>>3) of a half-tile (A, B lo: 128 rows = 2 instructions
+  //      per wave; B hi at BN = 192: 64 rows = 1)
   const int srow = lane >> 3, schunk = lane & 7;
   const char* a_src[2][2];  // [half][instr]
-  const char* b_src[2][2];
+  const char* b_lo_src[2];
+  const char* b_hi_src[NBH];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -368,46 +379,71 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
       const int chunk = schunk ^ ((lr >> 1) & 7);
       int64_t ra = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
       ra = ra < Mv ? ra : Mv - 1;
-      int rb = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
-      rb = rb < g.N ? rb : g.N - 1;
       a_src[h][i] = g.A + (ra * g.lda) * 2 + chunk * 16;
-      b_src[h][i] = g.W + ((int64_t)rb * g.ldw) * 2 + chunk * 16;
     }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = (wave * 2 + i) * 8 + srow;
+    const int chunk = schunk ^ ((lr >> 1) & 7);
+    int rb = n0 + (lr >> 5) * WCOLS + (lr & 31);
+    rb = rb < g.N ? rb : g.N - 1;
+    b_lo_src[i] = g.W + ((int64_t)rb * g.ldw) * 2 + chunk * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < NBH; ++i) {
+    const int lr = NBH == 2 ? (wave * 2 + i) * 8 + srow : wave * 8 + srow;
+    const int chunk = schunk ^ ((lr >> 1) & 7);
+    int rb = n0 + (lr / HI_ROWS) * WCOLS + 32 + (lr % HI_ROWS);
+    rb = rb < g.N ? rb : g.N - 1;
+    b_hi_src[i] = g.W + ((int64_t)rb * g.ldw) * 2 + chunk * 16;
+  }
   const unsigned st_dst = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 2048;  // + i*1024 + half offset + buffer offset
+  const unsigned st_dst1 = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024;  // the one-instruction half-tile (B hi, BN = 192)
 #define STAGE(src_, half_off_, buf_, kt_)                                                   \
   {                                                                                         \
     const int koff_ = (kt_) * 128;                                                          \
     GLDS16(src_[0] + koff_, st_dst + (buf_)*BUF_BYTES + (half_off_));                       \
     GLDS16(src_[1] + koff_, st_dst + (buf_)*BUF_BYTES + (half_off_) + 1024);                \
   }
+#define STAGE_BHI(buf_, kt_)                                                                \
+  {                                                                                         \
+    if (NBH == 2) STAGE(b_hi_src, OFF_B_HI, buf_, kt_)                                      \
+    else GLDS16(b_hi_src[0] + (kt_) * 128, st_dst1 + (buf_)*BUF_BYTES + OFF_B_HI);          \
+  }
   // ---- fragment reads
   const int sw = (r16 >> 1) & 7;
   const int c0 = (q4 ^ sw) << 4;
   const char* const fa_base = smem256 + (wr * 64 + r16) * 128 + c0;
-  const char* const fb_base = smem256 + (wc * 32 + r16) * 128 + c0;
-  float4 fa[4][2], fbl[2][2], fbh[2][2];
+  const char* const fbl_base = smem256 + (wc * 32 + r16) * 128 + c0;
+  const char* const fbh_base = smem256 + (wc * HI_ROWS + r16) * 128 + c0;
+  float4 fa[4][2], fbl[2][2], fbh[NBH][2];
 #define READ_A(buf_, half_off_)                                                                                   \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                 \
     fa[i][0] = *reinterpret_cast<const float4*>(fa_base + (buf_)*BUF_BYTES + (half_off_) + i * 2048);             \
     fa[i][1] = *reinterpret_cast<const float4*>((fa_base + (buf_)*BUF_BYTES + (half_off_) + i * 2048) + 64 - 2 * (c0 & 64)); \
   }
-#define READ_B(fb_, buf_, half_off_)                                                                              \
+#define READ_BL(buf_)                                                                                             \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                 \
-    fb_[j][0] = *reinterpret_cast<const float4*>(fb_base + (buf_)*BUF_BYTES + (half_off_) + j * 2048);            \
-    fb_[j][1] = *reinterpret_cast<const float4*>((fb_base + (buf_)*BUF_BYTES + (half_off_) + j * 2048) + 64 - 2 * (c0 & 64)); \
+    fbl[j][0] = *reinterpret_cast<const float4*>(fbl_base + (buf_)*BUF_BYTES + OFF_B_LO + j * 2048);              \
+    fbl[j][1] = *reinterpret_cast<const float4*>((fbl_base + (buf_)*BUF_BYTES + OFF_B_LO + j * 2048) + 64 - 2 * (c0 & 64)); \
   }
-  f32x4b acc[8][4];
+#define READ_BH(buf_)                                                                                             \
+  _Pragma("unroll") for (int j = 0; j < NBH; ++j) {                                                               \
+    fbh[j][0] = *reinterpret_cast<const float4*>(fbh_base + (buf_)*BUF_BYTES + OFF_B_HI + j * 2048);              \
+    fbh[j][1] = *reinterpret_cast<const float4*>((fbh_base + (buf_)*BUF_BYTES + OFF_B_HI + j * 2048) + 64 - 2 * (c0 & 64)); \
+  }
+  f32x4b acc[8][NB];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4b){0.f, 0.f, 0.f, 0.f};
-#define MFMA_Q(mh_, nh_, fb_)                                                                                      \
+    for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4b){0.f, 0.f, 0.f, 0.f};
+#define MFMA_Q(mh_, nb0_, nbn_, fb_)                                                                               \
   {                                                                                                                \
     __builtin_amdgcn_s_setprio(1);                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < (nbn_); ++j)               \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
-            acc[(mh_)*4 + i][(nh_)*2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                               \
-                __builtin_bit_cast(bf16x8b, fb_[j][kk]), __builtin_bit_cast(bf16x8b, fa[i][kk]), acc[(mh_)*4 + i][(nh_)*2 + j], 0, 0, 0); \
+            acc[(mh_)*4 + i][(nb0_) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                \
+                __builtin_bit_cast(bf16x8b, fb_[j][kk]), __builtin_bit_cast(bf16x8b, fa[i][kk]), acc[(mh_)*4 + i][(nb0_) + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
   }
 #define BAR()                              \
@@ -416,22 +452,25 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
     __builtin_amdgcn_s_barrier();          \
     asm volatile("" ::: "memory");         \
   }
+  // the counted wait of phases 4 / 8 leaves the three youngest half-tiles (B lo, A lo, B hi of the K-tile after next) in flight
+#define WAIT_3HALVES() \
+  { if (NBH == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
   const int nk = g.K >> 6;  // even (launcher)
   // prologue: K-tile 0 whole, K-tile 1 without A_hi
-  STAGE(b_src[0], OFF_B_LO, 0, 0)
+  STAGE(b_lo_src, OFF_B_LO, 0, 0)
   STAGE(a_src[0], OFF_A_LO, 0, 0)
-  STAGE(b_src[1], OFF_B_HI, 0, 0)
+  STAGE_BHI(0, 0)
   STAGE(a_src[1], OFF_A_HI, 0, 0)
-  STAGE(b_src[0], OFF_B_LO, 1, 1)
+  STAGE(b_lo_src, OFF_B_LO, 1, 1)
   STAGE(a_src[0], OFF_A_LO, 1, 1)
-  STAGE(b_src[1], OFF_B_HI, 1, 1)
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  STAGE_BHI(1, 1)
+  WAIT_3HALVES()
   BAR()
   if (wr == 1) BAR()
   for (int kt = 0; kt < nk; kt += 2) {
     const int e2 = kt + 2 < nk ? kt + 2 : nk - 1, o1 = kt + 1, o3 = kt + 3 < nk ? kt + 3 : nk - 1;
     // p1
-    READ_B(fbl, 0, OFF_B_LO)
+    READ_BL(0)
     __builtin_amdgcn_sched_barrier(0);
     READ_A(0, OFF_A_LO)
     STAGE(a_src[1], OFF_A_HI, 1, o1)
@@ -439,15 +478,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
     BAR()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    MFMA_Q(0, 0, fbl)
+    MFMA_Q(0, 0, 2, fbl)
     BAR()
     // p2
-    READ_B(fbh, 0, OFF_B_HI)
-    STAGE(b_src[0], OFF_B_LO, 0, e2)
+    READ_BH(0)
+    STAGE(b_lo_src, OFF_B_LO, 0, e2)
     BAR()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    MFMA_Q(0, 1, fbh)
+    MFMA_Q(0, 2, NBH, fbh)
     BAR()
     // p3
     READ_A(0, OFF_A_HI)
@@ -455,16 +494,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
     BAR()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    MFMA_Q(1, 1, fbh)
+    MFMA_Q(1, 2, NBH, fbh)
     BAR()
     // p4
-    STAGE(b_src[1], OFF_B_HI, 0, e2)
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    STAGE_BHI(0, e2)
+    WAIT_3HALVES()
     BAR()
-    MFMA_Q(1, 0, fbl)
+    MFMA_Q(1, 0, 2, fbl)
     BAR()
     // p5
-    READ_B(fbl, 1, OFF_B_LO)
+    READ_BL(1)
     __builtin_amdgcn_sched_barrier(0);
     READ_A(1, OFF_A_LO)
     STAGE(a_src[1], OFF_A_HI, 0, e2)
@@ -472,15 +511,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
     BAR()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    MFMA_Q(0, 0, fbl)
+    MFMA_Q(0, 0, 2, fbl)
     BAR()
     // p6
-    READ_B(fbh, 1, OFF_B_HI)
-    STAGE(b_src[0], OFF_B_LO, 1, o3)
+    READ_BH(1)
+    STAGE(b_lo_src, OFF_B_LO, 1, o3)
     BAR()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    MFMA_Q(0, 1, fbh)
+    MFMA_Q(0, 2, NBH, fbh)
     BAR()
     // p7
     READ_A(1, OFF_A_HI)
@@ -488,25 +527,25 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
     BAR()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    MFMA_Q(1, 1, fbh)
+    MFMA_Q(1, 2, NBH, fbh)
     BAR()
     // p8
-    STAGE(b_src[1], OFF_B_HI, 1, o3)
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    STAGE_BHI(1, o3)
+    WAIT_3HALVES()
     BAR()
-    MFMA_Q(1, 0, fbl)
+    MFMA_Q(1, 0, 2, fbl)
     BAR()
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (wr == 0) BAR()
-  // ---- epilogue: row m = m0 + wr*128 + mi*16 + r16, columns n0 + wc*64 + ni*16 + 4*q4 + 0..3 (N % 4 == 0, 16-byte rows: launcher)
+  // ---- epilogue: row m = m0 + wr*128 + mi*16 + r16, columns n0 + wc*WCOLS + ni*16 + 4*q4 + 0..3 (N % 4 == 0, 16-byte rows: launcher)
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     const int64_t m = m0 + wr * 128 + mi * 16 + r16;
     if (m >= Mv) continue;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wc * 64 + ni * 16 + 4 * q4;
+    for (int ni = 0; ni < NB; ++ni) {
+      const int n = n0 + wc * WCOLS + ni * 16 + 4 * q4;
       if (n >= g.N) continue;
       float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
       if (g.has_bias) {
@@ -538,10 +577,51 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
 #pragma clang diagnostic pop
 #undef GLDS16
 #undef STAGE
+#undef STAGE_BHI
 #undef READ_A
-#undef READ_B
+#undef READ_BL
+#undef READ_BH
 #undef MFMA_Q
+#undef WAIT_3HALVES
 #undef BAR
+
+// 0: the 128-row forms; 1: 256 x 256 tiles; 2: 256 x 192 tiles.  A cost model in microseconds, fitted to one sweep of the three
+// forms forced over M = 4 096 .. 20 480 x the six call shapes (tools/exp_bf16_linear.py on builds with -DGDR_LAB_BF16_FORCE=0/1/2,
+// profiles/r05_bf16_tile_forms.txt); nk = K / 64:
+//   128 x 128 form (up to 4 workgroups per CU = 1 024 slots):  occ(T) x (17 + 1.6 nk),  occ = T / 1024 from one round on, else
+//                                                              0.35 + 0.65 T / 1024 (a sparse round's tiles run faster)
+//   256-row tiles of width w (one per CU):                     ceil(T / 256) x (fix_w + 1.49 nk w / 256),  fix = 12.1 / 11.5
+//   every form:                                                at least bytes / 3.5 TB/s (operands + output + residual)
+// It picks the measured-fastest form in 26 of the sweep's 30 cases and is within 5 % of it in the rest.
+// (lab forcing: -DGDR_LAB_BF16_FORCE=0/1/2 builds a library that always answers 0 / 1 / 2 where the shape allows)
+static int pick_tile256(int64_t M, int N, int K, int has_residual, int out_bf16) {
+#ifdef GDR_LAB_BF16_FORCE
+  return GDR_LAB_BF16_FORCE;
+#else
+  const double nk = K / 64.0;
+  const double bytes = 2.0 * M * K + 2.0 * N * K + (out_bf16 ? 2.0 : 4.0) * M * N + (has_residual ? 4.0 * M * N : 0.0);
+  const double floor_us = bytes / 3.5e6;
+  const double t128n = (double)((M + 127) / 128) * ((N + 127) / 128);
+  const double occ = t128n >= 1024.0 ? t128n / 1024.0 : 0.35 + 0.65 * t128n / 1024.0;
+  double t128 = occ * (17.0 + 1.6 * nk);
+  t128 = t128 > floor_us ? t128 : floor_us;
+  const int64_t pm = (M + 255) / 256;
+  auto est = [&](int bn, double fix) {
+    const int64_t tiles = pm * ((N + bn - 1) / bn);
+    const double t = (double)((tiles + 255) / 256) * (fix + 1.49 * nk * bn / 256.0);
+    return t > floor_us ? t : floor_us;
+  };
+  const double t256 = est(256, 12.1), t192 = est(192, 11.5);
+  // IN SITU only the deep contractions keep the 256-row tile: alone and replayed back to back (the sweep) the wide K = 768 linears
+  // gain 5-15 % on it, inside the encoder / decode chains they LOSE (bf16 C2 step 117.6 k -> 112.3 k q/s, C5 10 410 -> 10 328 with
+  // every shape routed by the model): a 512-thread workgroup that owns a CU's whole LDS shuts out the other chain's kernels, and
+  // between other launches its operands are no longer L2 / MALL-hot as they are in a replay.  So: K >= 2048 at >= 8 192 rows, the
+  // width by the model.
+  (void)t128;
+  if (K < 2048 || M < 8192) return 0;
+  return t256 < t192 ? 1 : 2;
+#endif
+}
 
 // Returns 1 if the shape is not served here (caller falls back to the generic core), 0 on launch, < 0 on error.
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
@@ -561,15 +641,25 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
     set_error("linear_bf16: grid too large");
     return GDR_EINVAL;
   }
-  // deep contractions of a big batch: the 256^2 tile (see gemm_nt_bf16_tile256_kernel).  NOT the wide bf16-output linears (qkv,
-  // wi: K = 768): as one tile per workgroup their 441 / 588 live tiles quantise badly on 256 CUs and the C2 bf16 step LOST 6 %
-  // (4.39 -> 4.65 ms) when they were routed here; the lab's gain on those shapes came from the persistent form of this tile
-  if (M >= 8192 && K % 128 == 0 && K >= 2048 && N % 4 == 0 && (ldc & 3) == 0 && (!has_residual || (ldr & 3) == 0)) {
-    const int64_t b256 = ((M + 255) / 256) * (int64_t)((N + 255) / 256);
-    if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_nt_bf16_tile256_kernel), 2 * BUF_BYTES, "linear_bf16")) return rc__;
-    hipLaunchKernelGGL(gemm_nt_bf16_tile256_kernel, dim3((unsigned)b256), dim3(512), 2 * BUF_BYTES, stream, g);
-    GDR_CHECK_LAUNCH("gemm_nt_bf16_tile256_kernel");
-    return 0;
+  // The 256-row tile (gemm_nt_bf16_tile256_kernel, 8-phase schedule, one workgroup per CU), 256 or 192 columns wide: twice the flops
+  // per operand byte of the 128^2 kernel, but every CU reaches its prologue / epilogue alone, so it pays where the K loop is long or
+  // where its tile count fills whole rounds of 256 CUs.  The choice is a cost estimate in K-tile units per CU:
+  //   rounds x (K-tiles x width factor + fixed prologue / epilogue cost)      against the 128^2 form's measured ~0.33 of peak.
+  if (M >= 4096 && K % 128 == 0 && N % 4 == 0 && (ldc & 3) == 0 && (!has_residual || (ldr & 3) == 0)) {
+    const int sel = pick_tile256(M, N, K, has_residual, out_bf16);
+    if (sel) {
+      const int bn = sel == 1 ? 256 : 192;
+      const int64_t b256 = ((M + 255) / 256) * (int64_t)((N + bn - 1) / bn);
+      if (sel == 1) {
+        if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_nt_bf16_tile256_kernel<256>), 2 * BUF_BYTES, "linear_bf16")) return rc__;
+        hipLaunchKernelGGL(gemm_nt_bf16_tile256_kernel<256>, dim3((unsigned)b256), dim3(512), 2 * BUF_BYTES, stream, g);
+      } else {
+        if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_nt_bf16_tile256_kernel<192>), 2 * BUF_BYTES, "linear_bf16")) return rc__;
+        hipLaunchKernelGGL(gemm_nt_bf16_tile256_kernel<192>, dim3((unsigned)b256), dim3(512), 2 * BUF_BYTES, stream, g);
+      }
+      GDR_CHECK_LAUNCH("gemm_nt_bf16_tile256_kernel");
+      return 0;
+    }
   }
   // fewer than 2 tiles of 128 rows per CU: 64-row tiles (same k order per output element: bit-identical results)
   // (tools/exp_bf16_linear.py, profiles/r04_bf16_tile_height_sweep.txt: 1 920 rows qkv 21.6 -> 18.2 us, o 18.9 -> 15.2, wi 22.8 ->

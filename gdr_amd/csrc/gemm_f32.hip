@@ -54,7 +54,13 @@ struct GemmArgs {
 // 1.5 % of the linears' time).  Live rows are unaffected: a GEMM row depends on nothing but itself.
 __device__ __forceinline__ int64_t live_rows_padded(const GemmArgs& g) {
   if (!g.m_dev) return g.M;
-  const int64_t up = (*g.m_dev + (BM - 1)) / BM * BM;
+  // the count is the same for every lane, but a plain global load leaves it (and every tile / segment index derived from it) in
+  // VGPRs: read it through the scalar unit's view so that the whole tile bookkeeping lives in SGPRs
+  const int64_t raw = *g.m_dev;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(raw & 0xffffffffll));
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)raw >> 32));
+  const int64_t live = (int64_t)(((unsigned long long)hi << 32) | lo);
+  const int64_t up = (live + (BM - 1)) / BM * BM;
   return up < g.M ? up : g.M;
 }
 

@@ -1325,7 +1325,18 @@ __global__ __launch_bounds__(256) void attention_decode_short_kernel(const AttnA
   __shared__ float strip[4][16];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform: b, h and every
                                                                                           // offset made of them live on the scalar unit
-  const int item = blockIdx.x * 4 + wave;
+  // XCD-aware order (GDR_ATTN_XCD_REMAP): the hardware deals consecutive workgroups round-robin over the 8 XCDs, each with an L2 of
+  // its own.  The R beam rows of a query reach mostly the SAME ancestor K / V rows (their prefixes are shared), and their H
+  // (row, head) items are neighbours in the item order — dealt round-robin, every XCD fetched its own copy of those rows from
+  // HBM / MALL.  With each XCD owning a contiguous range of items a query's rows meet in one L2.
+  unsigned bid = blockIdx.x;
+#ifndef GDR_ATTN_NO_XCD_REMAP
+  {
+    const unsigned nblk = gridDim.x, q_ = nblk >> 3, r_ = nblk & 7u, xcd_ = bid & 7u, j_ = bid >> 3;
+    bid = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + j_;
+  }
+#endif
+  const int item = (int)bid * 4 + wave;
   if (item >= a.B * a.H) return;
   if (a.live && *a.live == 0) return;  // every query of the generate call is done
   const int b = item / a.H, h = item % a.H;
@@ -1420,6 +1431,11 @@ __global__ __launch_bounds__(256) void attention_decode_short_kernel(const AttnA
   }
 }
 
+// Measured and dropped (r05): a workgroup per (query, head) that numbers the DISTINCT (position, row) pairs of the query's R beam rows,
+// stages each of them once in LDS and serves all R rows from there (97 distinct of 270 gathered rows per query at 30 beams,
+// tools/exp_prefix_sharing.py) — bit-identical, but generate() at 512 x 30 beams took 47.9 ms (50.3 with the queries prefetched and a
+// compare-based numbering) against 46.2 ms for the per-row form above: that form is bound by wave slots x the two-deep load chain
+// (kv_rows -> K / V), the shared rows already meet in L2, and the staging adds barriers and a third dependent phase.
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
   GDR_CHECK_ARG(a.dk % 4 == 0 && a.dk >= 4 && a.dk <= 256, "attention: dk=%d unsupported", a.dk);
   GDR_CHECK_ARG(a.Lk >= 1 && a.Lk <= 128, "attention: Lk=%d must be in [1,128]", a.Lk);
@@ -1438,6 +1454,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
                 (long long)a.ldo);
   if (a.Lq == 1 && a.dk <= 128 && a.ldo % 4 == 0) {
     if (a.Lk <= (a.dk <= 64 ? 16 : 12)) {  // a decode step's key list
+      // the beam rows of a query share their ancestors: one workgroup per (query, head) stages the distinct K / V rows once
       const dim3 grids((unsigned)((a.B * a.H + 3) / 4));
       if (a.dk <= 64)
         hipLaunchKernelGGL(attention_decode_short_kernel<16>, grids, dim3(256), 0, stream, a);

@@ -32,7 +32,7 @@ if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     __package__ = "gdr_amd"
 
-from . import codec, launch, synth              # noqa: E402
+from . import _ffi, codec, launch, synth        # noqa: E402
 from .config import GDRConfig                   # noqa: E402
 
 # (flag, type, default[, choices]) — names, types and defaults of main.py:262-396
@@ -238,9 +238,17 @@ def inference(args):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if two_stage:
-        for i, out in enumerate(retr.validation_steps(batches(), depth=max(1, args.pipeline_depth))):
-            if real[i]:
-                outputs.append(trimmed(out, *spans[i]))
+        try:
+            for i, out in enumerate(retr.validation_steps(batches(), depth=max(1, args.pipeline_depth))):
+                if real[i]:
+                    outputs.append(trimmed(out, *spans[i]))
+        except _ffi.GdrError:
+            # a device fault (a stream-K hand-off that timed out) is sticky until acknowledged: this entry point owns the clear —
+            # the run is reported as failed, but a process that catches the error and goes on is not poisoned for good
+            if _ffi.clear_device_fault():
+                print("inference: a device fault was pending; it has been acknowledged (gdr_device_fault_clear) — the step it "
+                      "belongs to is invalid and the run is aborted", file=sys.stderr)
+            raise
     else:
         for (lo, hi), b, is_real in zip(spans, batches(), real):
             if not is_real:

@@ -412,7 +412,9 @@ class GDRRetriever:
             # decode_token -> id_mapping -> candidate lists -> rerank, all enqueued before anything is read back
             # (main_models.py:1398,1441-1443,1574-1637): the host only formats strings afterwards
             _cl, offs, dev_ids, stride = dci.candidates(state["ids"], B, R)
-            max_cand = ops.block_max_cand(offs, R, stride)
+            # the sharded stage 2 takes its bound from the GATHERED offsets (dist.ShardedIndex): a rank-local decision here could
+            # raise on one rank while its peers already sit in the fixed-size all-gather
+            max_cand = ops.block_max_cand(offs, R, stride) if self.sharded is None else 0
             beam_scores = state["scores"].to(torch.float32).view(B, R)          # fp64 -> fp32 as torch.tensor(list) rounds
         outs = scores = None
         if dci is None:

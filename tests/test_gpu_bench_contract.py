@@ -151,6 +151,19 @@ def test_bench_gpus_2_on_one_gpu_through_gloo():
     assert k["value"] > 0 and k["config"]["candidates_per_query"] == 120
 
 
+def test_bench_gpus_8_on_one_gpu_through_gloo():
+    """The driver's SCALE command shape at N = 8 — `python bench.py --gpus 8` — with the ranks sharing this box's one GPU over gloo, so
+    that a run on a real 8-GPU node exercises nothing for the first time except RCCL itself: C4's layout (corpus row-sharded 8 ways,
+    one all-to-all of the packed per-shard top-k) and C5's (8 cluster-aligned shards of a bf16 corpus, beam 30, sharded rerank);
+    exactly one JSON line <= 4 KB with n_gpus 8."""
+    j = _run("--gpus", "8", "--backend", "gloo", "--batch", "16", "--no-stages")
+    assert j["n_gpus"] == 8 and j["config"]["global_batch"] == 128 and j["config"]["workload"].startswith("C4-layout")
+    assert j["config"]["dist_backend"] == "gloo" and j["value"] > 0 and j["scaling"] == "weak"
+    k = _run("--gpus", "8", "--backend", "gloo", "--workload", "c5", "--batch", "4", "--corpus", "100000")
+    assert k["n_gpus"] == 8 and k["config"]["workload"].startswith("C5/sharded") and k["config"]["global_batch"] == 32
+    assert k["dtype"] == "bf16" and k["config"]["beams"] == 30 and k["value"] > 0
+
+
 def test_bench_under_torchrun_one_rank_rccl():
     """The N > 1 code path (process group over RCCL, query all-gather, all-to-all of the per-shard lists, barrier + max
     over ranks) with a 1-rank group — what one GPU can exercise of it."""

@@ -515,6 +515,18 @@ def test_sharded_two_stage_retriever_gloo(tmp_path, world):
     assert all(r[0] == 1 and r[1] > 0 for r in rows), rows
 
 
+def test_bench_refuses_rccl_with_more_ranks_than_gpus():
+    """`--backend nccl` (RCCL, the product backend) with WORLD_SIZE above the node's GPU count must fail loudly instead of folding
+    ranks onto the GPUs that exist: this container has no GPU, so a 2-rank nccl environment is exactly that case.  The refusal
+    happens before anything touches a device."""
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "nccl", "--corpus", "3000"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+    assert out.returncode != 0 and "needs 2 GPUs" in out.stderr, (out.returncode, out.stderr[-500:])
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], "no JSON line from a refused run"
+
+
 def test_launcher_timeout_kills_the_whole_rank_group(tmp_path):
     """A hung launch is bounded by `timeout=` and leaves nobody behind: the launcher and its ranks run in a process group of their
     own, the watchdog terminates the launcher and then SIGKILLs the group (a SIGKILL to torch.distributed.run alone would orphan

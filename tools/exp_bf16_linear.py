@@ -7,7 +7,9 @@ dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 out = {"setting": os.environ.get("GDR_LAB_BF16_BM64_BELOW", "default")}
 for M in (int(x) for x in os.environ.get("MS", "1920,4096,12308,15360,20480").split(",")):
-    for name, N, K, res in (("qkv", 2304, 768, False), ("o", 768, 768, True), ("wi", 3072, 768, False), ("wo", 768, 3072, True)) + \
+    for name, N, K, res in (("qkv", 2304, 768, False), ("o", 768, 768, True), ("wi", 3072, 768, False), ("wo", 768, 3072, True),
+                            ("lin1", 2048, 768, False), ("lin2", 768, 2048, True)) + \
+            ((("head", 23808, 768, False),) if os.environ.get("HEAD") else ()) + \
             ((("o_nores", 768, 768, False), ("wo_nores", 768, 3072, False)) if os.environ.get("NORES") else ()):
         a = ops.to_bf16((torch.randn(M, K, generator=g) * 0.05).to(dev))
         w = ops.to_bf16((torch.randn(N, K, generator=g) * 0.05).to(dev))

@@ -12,10 +12,10 @@ cfg = GDRConfig.base()
 sd = synth.make_state_dict(cfg, seed=1234)
 names = synth.make_cluster_ids(320000, cluster_size=12, V=30)[0]
 trie = codec.Trie.from_docids(names, 30)
-B, R = 64, 30
+B, R = int(os.environ.get("B", 64)), int(os.environ.get("BEAMS", 30))
 ids, mask = synth.make_tokens(B, L=40, seed=11)
 ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
-for label, dt in (("bf16", torch.bfloat16),) if os.environ.get("PROF") == "1" else (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+for label, dt in (("bf16", torch.bfloat16),) if os.environ.get("PROF") == "1" or os.environ.get("ONLY") == "bf16" else (("fp32", torch.float32), ("bf16", torch.bfloat16)):
     model = GDRModel(cfg, sd, dev, ragged=True, prefix_trie=trie, dtype=dt)
     g = lambda: model.generate(ids, attention_mask=mask, max_length=10, num_beams=R, length_penalty=0.8, num_return_sequences=R, output_scores=True)
     for _ in range(2):
