@@ -112,6 +112,10 @@ def parse():
     ap.add_argument("--replicated-merge", action="store_true",
                     help="N > 1: all-gather the per-shard lists and merge all queries on every rank (instead of the "
                          "all-to-all that hands each rank the lists of its own queries)")
+    ap.add_argument("--sim-prefilter", choices=["off", "bf16"], default="off",
+                    help="c2: off (default) = the all-fp32 corpus pass; bf16 = gdr_sim_topk_prefilter: the corpus-wide pass on the bf16 MFMA "
+                         "path over a bf16 image of the corpus, exact fp32 rescoring of the few hundred docs per query inside the proven "
+                         "error band — the same fp32 top-k for every input (tests/test_gpu_prefilter.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="c3 / c5: skip the oracle check of the step's output")
@@ -580,7 +584,6 @@ def stages_summary(st):
             "B64_beam10_decode_ms": g["B64_beam10"]["decode_ms"],
             "B64_beam10_frac_of_floor_executed": g["B64_beam10"]["frac_of_floor_executed"],
             "B1_beam100_decode_ms": g["B1_beam100"]["decode_ms"],
-            "c3_constrained_B64_qps": st["generate_trie_constrained"]["B64_beam10"]["two_stage_queries_per_s"],
             "bf16_c2_qps": st["bf16_mode_c2_step"]["queries_per_s"],
             "bf16_B64_beam30_generate_ms": st["bf16_mode_generate_B64_beam30"]["generate_ms"],
             "sim_B1_ms": sim["B1"]["ms"], "sim_B32_ms": sim["B32"]["ms"],
@@ -787,6 +790,8 @@ def main():
     D_dev = torch.from_numpy(D[lo:hi]).to(dev)
     if bf16:
         D_dev = ops.to_bf16(D_dev)
+    if a.sim_prefilter == "bf16" and not bf16:
+        D_dev = ops.PrefilteredCorpus(D_dev)
     index = ShardedIndex(D_dev, lo, exact=False)     # no host sync in the timed region; the status is checked after it
     ids_all, mask_all = synth.make_tokens(a.batch * world, L=40, seed=11)
     ids = torch.from_numpy(ids_all[rank * a.batch:(rank + 1) * a.batch]).to(dev)
@@ -838,6 +843,27 @@ def main():
     if overflowed:
         raise SystemExit(f"bench: {overflowed} queries overflowed their candidate lists — the step did not compute "
                          "the exact top-k (use exact_on_overflow=True for such data)")
+    # ---- the same step with the corpus-wide pass on the bf16 pre-filter (gdr_sim_topk_prefilter: identical fp32 top-k for every
+    # input, tests/test_gpu_prefilter.py) — timed AFTER the headline region with the same protocol, reported beside it, never as `value`
+    pre = None
+    if world == 1 and not bf16 and a.sim_prefilter == "off" and not a.no_stages:
+        P = ops.PrefilteredCorpus(D_dev)
+        index_p = ShardedIndex(P, lo, exact=False)
+
+        def step_p():
+            _, pooled = enc.forward(ids, mask, want_hidden=False, ragged=ragged, live_rows_hint=live_rows)
+            return index_p.search(pooled, a.k, return_status=True)
+
+        for _ in range(max(1, a.warmup)):
+            step_p()
+        fence(dist)
+        t0p = time.perf_counter()
+        for _ in range(a.steps):
+            outp = step_p()
+        fence(dist)
+        dtp = time.perf_counter() - t0p
+        pre = {"queries_per_s": a.batch * a.steps / dtp, "ms_per_step": dtp / a.steps * 1e3, "flagged_rows": int(outp[2].sum().item()),
+               "extra_hbm_mb": P.D16.numel() * 2 / 1e6}
 
     total_q = a.batch * world * a.steps
     ms_per_step = dt / a.steps * 1e3
@@ -865,6 +891,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": ("C2" if world == 1 else "C4-layout") + ("/ragged" if ragged else "/padded") + ("/bf16" if bf16 else "") +
+                       ("/prefilter" if a.sim_prefilter == "bf16" and not bf16 else "") +
                        f": t5-base encoder {a.batch} q/GPU + Q.D^T top-{a.k}, {a.corpus}x{cfg.d_model} corpus",
                        "dist_backend": a.backend if dist.is_initialized() else None,
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 40,
@@ -899,7 +926,8 @@ def main():
             rows = hi - lo
             detail["kernels"]["sim_total"] = {
                 "ms_per_step": sim_ms, "tflops": (w_l[1] + w_l[2]) / a.steps / (sim_ms * 1e-3) / 1e12,
-                "frac_of_mfma_peak": (w_l[1] + w_l[2]) / a.steps / (sim_ms * 1e-3) / 1e12 / peak,
+                "frac_of_mfma_peak": (w_l[1] + w_l[2]) / a.steps / (sim_ms * 1e-3) / 1e12 /
+                (BF16_MFMA_PEAK_TFLOPS if a.sim_prefilter == "bf16" else peak),       # the corpus-wide passes run on the bf16 path then
                 "corpus_stream_gbs": rows * cfg.d_model * (2 if bf16 else 4) / (sim_ms * 1e-3) / 1e9,
                 "frac_of_hbm_peak": rows * cfg.d_model * (2 if bf16 else 4) / (sim_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # The CPU leg (rank 0, N = 1 only): the oracle timed on the host cores, and — the metric's second half —
@@ -922,6 +950,13 @@ def main():
                                     "rows_violating_tie_rule": bad}
                 detail["recall_rule"] = ("values within 1e-4; ids exact outside groups of reference scores closer than 2e-4 "
                                          "(relative), same id set inside such a group")
+                if pre is not None:   # the pre-filtered path against the same oracle lists, same rule
+                    pv, pi = ops.sim_topk(torch.from_numpy(Q).to(dev), P, a.k)
+                    pid, pperm, pbad = topk_parity(cv.numpy(), ci.numpy(), pv.cpu().numpy(), pi.cpu().numpy())
+                    pre.update({"recall": recall_at(pi.cpu().numpy(), gold), "topk_ids_identical_rows": pid, "permuted_slots": pperm,
+                                "rows_violating_tie_rule": pbad,
+                                "rows_with_the_fp32_path_ids": int((pi == gi).all(dim=1).sum().item())})
+                    bad += pbad
                 if bad:
                     emit(result, detail)
                     raise SystemExit(f"bench: {bad} rows differ from the CPU oracle outside tolerance-tie groups")
@@ -929,8 +964,17 @@ def main():
         result["stages_summary"] = None
         if world == 1 and not a.no_stages and not bf16:
             del enc
+            if pre is not None:
+                del P, index_p
+                torch.cuda.empty_cache()
             detail["stages"] = stages(dev, cfg, D, D_dev, a)
             result["stages_summary"] = stages_summary(detail["stages"])
+            if pre is not None:
+                detail["stages"]["c2_step_bf16_prefilter"] = pre
+                detail["stages"]["c2_step_bf16_prefilter_note"] = (
+                    "the headline step with gdr_sim_topk_prefilter: corpus-wide pass on the bf16 MFMA path over a bf16 image of the "
+                    "corpus, exact fp32 rescoring of the docs inside the proven 2-eps band: the same fp32 top-k for every input")
+                result["stages_summary"]["c2_prefilter_qps"] = pre["queries_per_s"]
         emit(result, detail)
     if dist.is_initialized():
         dist.barrier()

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDR_HIP_LIB") or os.path.join(_HERE, "libgdr_hip.so")   # override: A/B builds in the lab
 
 GDR_OK, GDR_EINVAL, GDR_ENOSPC, GDR_EHIP = 0, -1, -2, -3
-ABI_VERSION = 6                  # what this binding was written against (gdr_abi_version(), csrc/common.hip)
+ABI_VERSION = 7                  # what this binding was written against (gdr_abi_version(), csrc/common.hip)
 RERANK_POSITIONS = 1
 SIM_EXHAUSTIVE = 1
 SIM_NO_STREAM = 2
@@ -105,6 +105,9 @@ SIGNATURES = {
     "gdr_sim_topk_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i]),
     "gdr_sim_topk": (_i, [_vp, _i, _vp, _i64, _i, _i, C.c_int32, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "gdr_sim_topk_bf16": (_i, [_vp, _i, _vp, _i64, _i, _i, C.c_int32, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "gdr_sim_topk_prefilter_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
+    "gdr_sim_topk_prefilter": (_i, [_vp, _i, _vp, _vp, C.c_float, _i64, _i, _i, C.c_int32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gdr_row_norm2_max": (_i, [_vp, _i64, _i, _vp, _vp]),
     "gdr_cast_f32_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "gdr_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "gdr_topk_pack": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),

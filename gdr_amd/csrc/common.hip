@@ -124,4 +124,5 @@ extern "C" const char* gdr_last_error(void) { return gdr::g_err; }
 // 6: gdr_device_fault_pending / _clear / _inject_for_tests (a stream-K hand-off that times out no longer traps: it raises a sticky
 //    process-wide word and every stream-K launch enqueued while it is raised fails with GDR_EHIP); gdr_t5_layer_norm (a2 as an
 //    operator of its own); gdr_t5_generate_last_done_step
-extern "C" int gdr_abi_version(void) { return 6; }
+// 7: gdr_sim_topk_prefilter (+ _workspace_bytes), gdr_row_norm2_max: the fp32 top-k through a bf16 pre-filter
+extern "C" int gdr_abi_version(void) { return 7; }

@@ -147,17 +147,26 @@ __device__ __forceinline__ void block_minmax(uint32_t& lo, uint32_t& hi, uint32_
 // float bits spend two full sweeps (and ~10^4 same-address LDS atomics each) without separating anything.
 
 // ---- step 2: per-query threshold = k-th largest of the sample scores ----------------------------
+// r05 generalisations (the bf16 pre-filter below): cnt_in != null -> the list length is min(cnt_in[q], cap) instead of n_slots
+// (the k-th largest over the WHOLE candidate list); sub != null -> thr[q] = value - sub[q]; set_cnt = 0 leaves cand_cnt alone.
+template <int RC>
 __global__ __launch_bounds__(1024) void sim_threshold_kernel(const float* __restrict__ cand_val, int64_t cap,
-                                                             int n_slots, int k, float* thr, int32_t* cand_cnt) {
+                                                             int n_slots_, int k, float* thr, int32_t* cand_cnt,
+                                                             const int32_t* __restrict__ cnt_in, const float* __restrict__ sub,
+                                                             int set_cnt) {
   __shared__ int hist[256];
   __shared__ int scan[256];
   __shared__ int res[2];
   __shared__ uint32_t red[32];
   const int q = blockIdx.x;
   const float* v = cand_val + (int64_t)q * cap;
+  int n_slots = n_slots_;
+  if (cnt_in) {
+    const int c = cnt_in[q];
+    n_slots = c < (int)cap ? c : (int)cap;
+  }
   // the sample scores are read ONCE: up to RC keys per thread stay in registers across the digit passes (every pass used to
   // re-read them from memory — a dependent L2 round trip per sweep); longer lists fall back to re-reading
-  constexpr int RC = 8;
   const bool cached = n_slots <= RC * (int)blockDim.x;
   uint32_t rk[RC];
 #pragma unroll
@@ -216,8 +225,9 @@ __global__ __launch_bounds__(1024) void sim_threshold_kernel(const float* __rest
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    thr[q] = fkey_inv(nbits ? (prefix >> lsh) + lo : lo);
-    cand_cnt[q] = n_slots;  // survivors of the filter pass are appended behind the sample block
+    const float t = fkey_inv(nbits ? (prefix >> lsh) + lo : lo);
+    thr[q] = sub ? t - sub[q] : t;
+    if (set_cnt) cand_cnt[q] = n_slots;  // survivors of the filter pass are appended behind the sample block
   }
 }
 
@@ -479,8 +489,8 @@ int gdr::sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, in
                        : launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
   if (rc) return rc;
   const int sel_threads = 1024;  // 1024 lanes per query: measured faster than 512 with twice the entries per lane (26.7 vs 37.7 us at 32 queries)
-  hipLaunchKernelGGL(sim_threshold_kernel, dim3(B), dim3(sel_threads), 0, stream, ep.cand_val, p.cap, (int)p.n_slots,
-                     k, thr, ep.cand_cnt);
+  hipLaunchKernelGGL(sim_threshold_kernel<8>, dim3(B), dim3(sel_threads), 0, stream, ep.cand_val, p.cap, (int)p.n_slots,
+                     k, thr, ep.cand_cnt, (const int32_t*)nullptr, (const float*)nullptr, 1);
   GDR_CHECK_LAUNCH("sim_threshold_kernel");
   if (p.stride > 1) {
     ep.mode = 2;
@@ -493,6 +503,238 @@ int gdr::sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, in
                      ep.cand_val, ep.cand_idx, ep.cand_cnt, p.cap, 1, B, k, kpad, idx_offset, (const float*)thr, out_val,
                      out_idx, status, 0, 1);
   GDR_CHECK_LAUNCH("topk_select_kernel");
+  return GDR_OK;
+}
+
+namespace gdr {
+// ------------------------------------------------------------------------------------------------------------------------------
+// fp32 similarity + top-k through a bf16 PRE-FILTER (r05; B > 32): the corpus-wide pass — 2·B·N·d flop, the second largest item of
+// the C2 step — runs on the bf16 MFMA path over a bf16 image of the corpus, and only a few hundred docs per query are scored in
+// fp32.  The result is the top-k of the FP32 scores, exactly, for every input; the bf16 pass only decides which docs get an fp32 score:
+//   * s(doc) = the fp32 score the rescoring computes, s~(doc) = the bf16-operand score (products of bf16 values are exact in fp32,
+//     fp32 accumulate).  With u = 2^-9 (bf16 RNE) and any summation orders:
+//         |s~ - s| <= ||q||·||d||·(2u + u^2 + 2·d·2^-24·1.01) =: eps(q, d) <= eps_q := ||q||·max_doc||d||·(2^-8 + 2^-17 + d·2^-22)
+//   * t~_k = k-th largest s~ over all docs.  The k docs with the largest s~ have s >= t~_k - eps, so T_k (k-th largest s) >= t~_k - eps;
+//     a doc of the true top-k has s >= T_k, hence s~ >= t~_k - 2·eps.  So {s~ >= t~_k - 2 eps_q} contains the true top-k (with every doc
+//     tied at T_k), and the exact select over their fp32 scores (higher score, then lower id — as the fp32 path) is the brute-force result.
+//   * the sample threshold L (k-th largest s~ over the sample) is <= t~_k, so the filter pass keeps s~ >= L - 2 eps_q, a superset.
+// Lists that overflow (the candidate list of the bf16 pass, or more than cap2 docs inside the 2-eps band) are flagged in status[q] like
+// gdr_sim_topk's; ops.sim_topk recomputes such a query on the fp32 path.
+__global__ __launch_bounds__(256) void sim_qprep_kernel(const float* __restrict__ Q, int d, float dnorm_max, __bf16* __restrict__ Q16,
+                                                        float* __restrict__ eps2) {
+  __shared__ float red[4];
+  const int q = blockIdx.x;
+  const float* row = Q + (int64_t)q * d;
+  float ss = 0.f;
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(row + c);
+    ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss))));
+    union {
+      __bf16 h[4];
+      uint2 u;
+    } o;
+    o.h[0] = (__bf16)v.x, o.h[1] = (__bf16)v.y, o.h[2] = (__bf16)v.z, o.h[3] = (__bf16)v.w;
+    *reinterpret_cast<uint2*>(Q16 + (int64_t)q * d + c) = o.u;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float nq = sqrtf(red[0] + red[1] + red[2] + red[3]) * 1.0001f;  // the norm itself is rounded: a hair of slack
+    const float c = 0.00390625f + 7.62939453125e-6f + (float)d * 2.384185791015625e-7f;  // 2^-8 + 2^-17 + d * 2^-22
+    eps2[q] = 2.0f * nq * dnorm_max * c * 1.01f;
+  }
+}
+
+// max over rows of ||D[r]||_2^2 (positive floats order like their bit patterns): one wave per row, atomicMax on the bits
+__global__ __launch_bounds__(256) void row_norm2_max_kernel(const float* __restrict__ D, int64_t N, int d, unsigned* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  float best = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < N; r += (int64_t)gridDim.x * 4) {
+    const float* row = D + r * d;
+    float ss = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(row + c);
+      ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss))));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    best = fmaxf(best, ss);
+  }
+  if (lane == 0) atomicMax(out, __float_as_uint(best));
+}
+
+// every candidate of the bf16 pass with s~ >= thr2[q] (= t~_k - 2 eps_q) -> ids[q][0 .. cnt2[q]); cnt2 > cap2 flags an overflow
+__global__ __launch_bounds__(1024) void prefilter_gather_kernel(const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx,
+                                                                const int32_t* __restrict__ cand_cnt, int64_t cap,
+                                                                const float* __restrict__ thr2, int cap2, int32_t* __restrict__ ids,
+                                                                int32_t* __restrict__ cnt2) {
+  __shared__ int n_sh;
+  const int q = blockIdx.x;
+  if (threadIdx.x == 0) n_sh = 0;
+  __syncthreads();
+  const int c = cand_cnt[q], count = c < (int)cap ? c : (int)cap;
+  const float t = thr2[q];
+  const float* v = cand_val + (int64_t)q * cap;
+  const int32_t* ix = cand_idx + (int64_t)q * cap;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    const int32_t id = ix[i];
+    if (id >= 0 && v[i] >= t) {
+      const int p = atomicAdd(&n_sh, 1);
+      if (p < cap2) ids[(int64_t)q * cap2 + p] = id;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) cnt2[q] = c > (int)cap ? cap2 + 1 : n_sh;  // an overflowed bf16 list cannot vouch for the band: flagged too
+}
+
+// vals[q][i] = fp32 q·D[ids[q][i]] for i < min(cnt2[q], cap2): a wave per candidate, the doc row read once in 16-byte pieces (a row
+// of d floats = d / 256 coalesced 1 KB wave loads), per-lane fmaf chains in k order, a fixed butterfly over the lanes
+__global__ __launch_bounds__(256) void rescore_dot_kernel(const float* __restrict__ Q, const float* __restrict__ D, int d,
+                                                          const int32_t* __restrict__ ids, const int32_t* __restrict__ cnt2, int cap2,
+                                                          int32_t id_base, float* __restrict__ vals) {
+  constexpr int MAXP = 4;  // d <= 1024
+  const int q = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = cnt2[q], count = c < cap2 ? c : cap2;
+  float4 qr[MAXP];
+#pragma unroll
+  for (int t = 0; t < MAXP; ++t) {
+    const int col = lane * 4 + 256 * t;
+    qr[t] = col < d ? *reinterpret_cast<const float4*>(Q + (int64_t)q * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int i0 = (blockIdx.x * 4 + wave) * 2; i0 < count; i0 += gridDim.x * 8) {  // two candidates per wave and trip: both rows in flight
+    const int i1 = i0 + 1 < count ? i0 + 1 : i0;
+    const int64_t r0 = (int64_t)(ids[(int64_t)q * cap2 + i0] - id_base), r1 = (int64_t)(ids[(int64_t)q * cap2 + i1] - id_base);
+    float4 a0[MAXP], a1[MAXP];
+#pragma unroll
+    for (int t = 0; t < MAXP; ++t) {
+      const int col = lane * 4 + 256 * t;
+      a0[t] = col < d ? *reinterpret_cast<const float4*>(D + r0 * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      a1[t] = col < d ? *reinterpret_cast<const float4*>(D + r1 * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXP; ++t) {
+      s0 = fmaf(qr[t].x, a0[t].x, s0), s0 = fmaf(qr[t].y, a0[t].y, s0), s0 = fmaf(qr[t].z, a0[t].z, s0), s0 = fmaf(qr[t].w, a0[t].w, s0);
+      s1 = fmaf(qr[t].x, a1[t].x, s1), s1 = fmaf(qr[t].y, a1[t].y, s1), s1 = fmaf(qr[t].z, a1[t].z, s1), s1 = fmaf(qr[t].w, a1[t].w, s1);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s0 += __shfl_xor(s0, off), s1 += __shfl_xor(s1, off);
+    if (lane == 0) {
+      vals[(int64_t)q * cap2 + i0] = s0;
+      if (i1 != i0) vals[(int64_t)q * cap2 + i1] = s1;
+    }
+  }
+}
+
+static int prefilter_cap2(int k) {
+  int c = 1024;
+  while (c < 4 * k) c <<= 1;
+  return c;
+}
+struct PrefilterPlan {
+  SimPlan p;
+  int cap2;
+  size_t off_q16, off_eps, off_thr2, off_cnt2, off_ids, off_vals, total;
+};
+static PrefilterPlan make_prefilter_plan(int B, int64_t N, int d, int k) {
+  PrefilterPlan pp{};
+  pp.p = make_plan(B, N, k, false);
+  pp.cap2 = prefilter_cap2(k);
+  size_t o = pp.p.total;
+  pp.off_q16 = o, o += align_up((size_t)B * d * 2, 256);
+  pp.off_eps = o, o += align_up((size_t)B * 4, 256);
+  pp.off_thr2 = o, o += align_up((size_t)B * 4, 256);
+  pp.off_cnt2 = o, o += align_up((size_t)B * 4, 256);
+  pp.off_ids = o, o += align_up((size_t)B * pp.cap2 * 4, 256);
+  pp.off_vals = o, o += align_up((size_t)B * pp.cap2 * 4, 256);
+  pp.total = o;
+  return pp;
+}
+}  // namespace gdr
+
+extern "C" size_t gdr_sim_topk_prefilter_workspace_bytes(int B, int64_t N, int d, int k) {
+  if (B <= 0 || N <= 0 || k <= 0 || d <= 0) return 0;
+  return gdr::make_prefilter_plan(B, N, d, k).total;
+}
+
+extern "C" int gdr_row_norm2_max(const float* D, int64_t N, int d, float* out_dev, void* stream_) {
+  using namespace gdr;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GDR_CHECK_ARG(D && out_dev && N > 0 && d > 0 && d % 4 == 0 && ((uintptr_t)D & 15) == 0, "row_norm2_max: bad arguments");
+  if (hipMemsetAsync(out_dev, 0, 4, stream) != hipSuccess) {
+    set_error("row_norm2_max: memset failed");
+    return GDR_EHIP;
+  }
+  const int64_t blocks = (N + 3) / 4;
+  hipLaunchKernelGGL(row_norm2_max_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, D, N, d,
+                     reinterpret_cast<unsigned*>(out_dev));
+  GDR_CHECK_LAUNCH("row_norm2_max_kernel");
+  return GDR_OK;
+}
+
+extern "C" int gdr_sim_topk_prefilter(const float* Q, int B, const float* D, const void* D_bf16, float dnorm_max, int64_t N, int d, int k,
+                                      int32_t idx_offset, float* out_val, int32_t* out_idx, int32_t* status, void* workspace,
+                                      size_t workspace_bytes, void* stream_) {
+  using namespace gdr;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (B == 0) return GDR_OK;
+  GDR_CHECK_ARG(Q && D && D_bf16 && out_val && out_idx && workspace, "sim_topk_prefilter: null pointer");
+  GDR_CHECK_ARG(B > 0 && N > 0 && d > 0 && d % 8 == 0 && d <= 1024, "sim_topk_prefilter: bad shape B=%d N=%lld d=%d (d %% 8 == 0, d <= 1024)", B,
+                (long long)N, d);
+  GDR_CHECK_ARG(k >= 1 && k <= 1024 && k <= N, "sim_topk_prefilter: k=%d must be in [1, min(1024, N)]", k);
+  GDR_CHECK_ARG(N < 0x7fffffffLL - 256, "sim_topk_prefilter: shard too large for int32 doc ids");
+  GDR_CHECK_ARG(dnorm_max > 0.f && dnorm_max < INFINITY, "sim_topk_prefilter: dnorm_max must be the largest row norm of D (> 0, finite)");
+  GDR_CHECK_ARG(((uintptr_t)Q & 15) == 0 && ((uintptr_t)D & 15) == 0 && ((uintptr_t)D_bf16 & 15) == 0 && ((uintptr_t)workspace & 255) == 0,
+                "sim_topk_prefilter: Q, D, D_bf16 must be 16-byte and workspace 256-byte aligned");
+  const PrefilterPlan pp = make_prefilter_plan(B, N, d, k);
+  const SimPlan& p = pp.p;
+  if (workspace_bytes < pp.total) {
+    set_error("sim_topk_prefilter: workspace %zu < required %zu", workspace_bytes, pp.total);
+    return GDR_ENOSPC;
+  }
+  char* ws = static_cast<char*>(workspace);
+  SimEpilogue ep{};
+  ep.cand_val = reinterpret_cast<float*>(ws + p.off_val);
+  ep.cand_idx = reinterpret_cast<int32_t*>(ws + p.off_idx);
+  ep.cand_cnt = reinterpret_cast<int32_t*>(ws + p.off_cnt);
+  float* thr = reinterpret_cast<float*>(ws + p.off_thr);
+  ep.thr = thr, ep.status = nullptr, ep.cap = (int32_t)p.cap, ep.tile_stride = p.stride, ep.mode = 1;
+  __bf16* Q16 = reinterpret_cast<__bf16*>(ws + pp.off_q16);
+  float* eps2 = reinterpret_cast<float*>(ws + pp.off_eps);
+  float* thr2 = reinterpret_cast<float*>(ws + pp.off_thr2);
+  int32_t* cnt2 = reinterpret_cast<int32_t*>(ws + pp.off_cnt2);
+  int32_t* ids2 = reinterpret_cast<int32_t*>(ws + pp.off_ids);
+  float* vals2 = reinterpret_cast<float*>(ws + pp.off_vals);
+  hipLaunchKernelGGL(sim_qprep_kernel, dim3(B), dim3(256), 0, stream, Q, d, dnorm_max, Q16, eps2);
+  GDR_CHECK_LAUNCH("sim_qprep_kernel");
+  int rc = launch_sim_gemm(D_bf16, N, Q16, B, d, ep, true, stream);
+  if (rc) return rc;
+  // L - 2 eps: the filter pass keeps a superset of the band around the (yet unknown) k-th largest bf16 score
+  hipLaunchKernelGGL(sim_threshold_kernel<8>, dim3(B), dim3(1024), 0, stream, ep.cand_val, p.cap, (int)p.n_slots, k, thr, ep.cand_cnt,
+                     (const int32_t*)nullptr, (const float*)eps2, 1);
+  GDR_CHECK_LAUNCH("sim_threshold_kernel");
+  if (p.stride > 1) {
+    ep.mode = 2;
+    rc = launch_sim_gemm(D_bf16, N, Q16, B, d, ep, true, stream);
+    if (rc) return rc;
+  }
+  // t~_k - 2 eps over the whole candidate list, then the docs inside the band
+  hipLaunchKernelGGL(sim_threshold_kernel<16>, dim3(B), dim3(1024), 0, stream, ep.cand_val, p.cap, (int)p.n_slots, k, thr2, ep.cand_cnt,
+                     (const int32_t*)ep.cand_cnt, (const float*)eps2, 0);
+  GDR_CHECK_LAUNCH("sim_threshold_kernel(all candidates)");
+  hipLaunchKernelGGL(prefilter_gather_kernel, dim3(B), dim3(1024), 0, stream, ep.cand_val, ep.cand_idx, ep.cand_cnt, p.cap,
+                     (const float*)thr2, pp.cap2, ids2, cnt2);
+  GDR_CHECK_LAUNCH("prefilter_gather_kernel");
+  hipLaunchKernelGGL(rescore_dot_kernel, dim3(16, B), dim3(256), 0, stream, Q, D, d, (const int32_t*)ids2, (const int32_t*)cnt2, pp.cap2,
+                     (int32_t)0, vals2);
+  GDR_CHECK_LAUNCH("rescore_dot_kernel");
+  const int kpad = next_pow2(k);
+  hipLaunchKernelGGL(topk_select_kernel<false>, dim3(B), dim3(1024), kpad * sizeof(unsigned long long), stream, (const float*)vals2,
+                     (const int32_t*)ids2, (const int32_t*)cnt2, (int64_t)pp.cap2, 1, B, k, kpad, idx_offset, (const float*)nullptr, out_val,
+                     out_idx, status, 0, 1);
+  GDR_CHECK_LAUNCH("topk_select_kernel(prefilter)");
   return GDR_OK;
 }
 

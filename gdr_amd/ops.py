@@ -129,6 +129,11 @@ def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_o
     query whose candidate list overflowed (degenerate corpora with tens of thousands of tied docs) exhaustively, so the
     result is exact for every input.  Latency-critical callers pass exact_on_overflow=False, return_status=True: no sync,
     and the device status tensor (1 = that row is the top-k of a subset) is theirs to act on.  flags: _ffi.SIM_* bits."""
+    prefilter = isinstance(D, PrefilteredCorpus)
+    if prefilter:
+        P, D = D, D.D
+        if Q.shape[0] < PREFILTER_MIN_BATCH or D.shape[1] % 8 or D.shape[1] > 1024 or (flags & _ffi.SIM_EXHAUSTIVE):
+            prefilter = False
     _need_cuda(Q, D)
     if D.dtype == torch.bfloat16:                                    # bf16 corpus: queries are cast on the device
         Q = (Q if Q.dtype == torch.bfloat16 else to_bf16(Q)).contiguous()
@@ -139,7 +144,10 @@ def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_o
         raise _ffi.GdrError(f"sim_topk: dim mismatch {Q.shape} vs {D.shape}")
     if k > D.shape[0]:
         raise RuntimeError("selected index k out of range")          # torch.topk's message
-    vals, idx, status = _sim_topk_raw(Q, D, k, idx_offset, workspace, flags)
+    if prefilter:
+        vals, idx, status = _sim_topk_prefilter_raw(Q, P, k, idx_offset, workspace)
+    else:
+        vals, idx, status = _sim_topk_raw(Q, D, k, idx_offset, workspace, flags)
     if exact_on_overflow:
         bad = torch.nonzero(status).flatten()
         _ffi.check_device_fault("sim_topk")                              # nonzero() synchronised
@@ -150,6 +158,37 @@ def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_o
                 vals[rows], idx[rows] = v2, i2
             status = torch.zeros_like(status)
     return (vals, idx, status) if return_status else (vals, idx)
+
+
+class PrefilteredCorpus:
+    """An fp32 corpus [N,d] with what gdr_sim_topk_prefilter needs beside it: its bf16 image (RNE, +50 % memory) and the largest
+    row norm, both made once on the device.  ops.sim_topk(Q, PrefilteredCorpus(D), k) returns the top-k of the FP32 scores (the
+    bf16 pass only decides which few hundred docs per query get one: include/gdr_hip.h)."""
+
+    def __init__(self, D):
+        _need_cuda(D)
+        self.D = _f32c(D)
+        self.D16 = to_bf16(self.D)
+        m = torch.empty(1, dtype=torch.float32, device=D.device)
+        check(lib().gdr_row_norm2_max(ptr(self.D), self.D.shape[0], self.D.shape[1], ptr(m), stream_ptr()), "gdr_row_norm2_max")
+        self.dnorm_max = float(m.item()) ** 0.5 * (1.0 + 1e-6)       # the squared norm is itself rounded
+        self.shape, self.dtype, self.device = self.D.shape, self.D.dtype, self.D.device
+
+
+PREFILTER_MIN_BATCH = 33          # at B <= 32 the latency-mode stream kernel (HBM-bound, fp32) serves
+
+
+def _sim_topk_prefilter_raw(Q, P, k, idx_offset, workspace):
+    B, d = Q.shape
+    N = P.D.shape[0]
+    need = lib().gdr_sim_topk_prefilter_workspace_bytes(B, N, d, k)
+    ws = (workspace or Workspace(Q.device)).get(need)
+    vals = torch.empty((B, k), dtype=torch.float32, device=Q.device)
+    idx = torch.empty((B, k), dtype=torch.int32, device=Q.device)
+    status = torch.empty((B,), dtype=torch.int32, device=Q.device)
+    check(lib().gdr_sim_topk_prefilter(ptr(Q), B, ptr(P.D), ptr(P.D16), P.dnorm_max, N, d, k, idx_offset, ptr(vals), ptr(idx),
+                                       ptr(status), ptr(ws), ws.numel(), stream_ptr()), "gdr_sim_topk_prefilter")
+    return vals, idx, status
 
 
 def topk_merge(vals, idx):

@@ -204,6 +204,20 @@ int gdr_sim_topk(const float* Q, int B, const float* D, int64_t N, int d, int k,
 int gdr_sim_topk_bf16(const void* Q, int B, const void* D, int64_t N, int d, int k, int32_t idx_offset,
                       float* out_val, int32_t* out_idx, int32_t* status, int flags, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* The same fp32 result through a bf16 PRE-FILTER (r05; replaces the same call site, dense.py:53-54 + topk as at main_models.py:1625):
+ * the corpus-wide pass runs on the bf16 MFMA path over D_bf16 (= gdr_cast_f32_bf16(D), resident beside D), and only the docs whose
+ * bf16-operand score lies within 2*eps_q of the k-th largest one are scored in fp32 (from D) and ranked exactly — with
+ *     eps_q = ||q|| * dnorm_max * (2^-8 + 2^-17 + d * 2^-22)   >=   |bf16-operand score - fp32 score|   for every doc,
+ * that band provably contains the fp32 top-k including every doc tied at the cut (derivation: csrc/sim_topk.hip), so out_val / out_idx
+ * are the top-k of the fp32 scores for every input, ties as in gdr_sim_topk (higher score, then lower id); the values are fp32 dot
+ * products of the same operands in another summation order.  dnorm_max: the largest ||D[r]||_2 (sqrt of gdr_row_norm2_max's result).
+ * status as in gdr_sim_topk (1 = an overflowed list: re-run that query with gdr_sim_topk).  d % 8 == 0, d <= 1024. */
+size_t gdr_sim_topk_prefilter_workspace_bytes(int B, int64_t N, int d, int k);
+int gdr_sim_topk_prefilter(const float* Q, int B, const float* D, const void* D_bf16, float dnorm_max, int64_t N, int d, int k,
+                           int32_t idx_offset, float* out_val, int32_t* out_idx, int32_t* status, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* out_dev[0] = max over rows of ||D[r]||_2^2 (device float; the call zeroes it first).  d % 4 == 0. */
+int gdr_row_norm2_max(const float* D, int64_t N, int d, float* out_dev, void* stream);
 /* fp32 -> bf16, round-to-nearest-even (v_cvt_pk_bf16_f32), n % 4 == 0. */
 int gdr_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, void* stream);
 
