@@ -147,26 +147,19 @@ __device__ __forceinline__ void block_minmax(uint32_t& lo, uint32_t& hi, uint32_
 // float bits spend two full sweeps (and ~10^4 same-address LDS atomics each) without separating anything.
 
 // ---- step 2: per-query threshold = k-th largest of the sample scores ----------------------------
-// r05 generalisations (the bf16 pre-filter below): cnt_in != null -> the list length is min(cnt_in[q], cap) instead of n_slots
-// (the k-th largest over the WHOLE candidate list); sub != null -> thr[q] = value - sub[q]; set_cnt = 0 leaves cand_cnt alone.
-template <int RC>
+// sub != null (the bf16 pre-filter below): thr[q] = value - sub[q]
 __global__ __launch_bounds__(1024) void sim_threshold_kernel(const float* __restrict__ cand_val, int64_t cap,
-                                                             int n_slots_, int k, float* thr, int32_t* cand_cnt,
-                                                             const int32_t* __restrict__ cnt_in, const float* __restrict__ sub,
-                                                             int set_cnt) {
+                                                             int n_slots, int k, float* thr, int32_t* cand_cnt,
+                                                             const float* __restrict__ sub) {
   __shared__ int hist[256];
   __shared__ int scan[256];
   __shared__ int res[2];
   __shared__ uint32_t red[32];
   const int q = blockIdx.x;
   const float* v = cand_val + (int64_t)q * cap;
-  int n_slots = n_slots_;
-  if (cnt_in) {
-    const int c = cnt_in[q];
-    n_slots = c < (int)cap ? c : (int)cap;
-  }
   // the sample scores are read ONCE: up to RC keys per thread stay in registers across the digit passes (every pass used to
   // re-read them from memory — a dependent L2 round trip per sweep); longer lists fall back to re-reading
+  constexpr int RC = 8;
   const bool cached = n_slots <= RC * (int)blockDim.x;
   uint32_t rk[RC];
 #pragma unroll
@@ -227,7 +220,7 @@ __global__ __launch_bounds__(1024) void sim_threshold_kernel(const float* __rest
   if (threadIdx.x == 0) {
     const float t = fkey_inv(nbits ? (prefix >> lsh) + lo : lo);
     thr[q] = sub ? t - sub[q] : t;
-    if (set_cnt) cand_cnt[q] = n_slots;  // survivors of the filter pass are appended behind the sample block
+    cand_cnt[q] = n_slots;  // survivors of the filter pass are appended behind the sample block
   }
 }
 
@@ -489,8 +482,8 @@ int gdr::sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, in
                        : launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
   if (rc) return rc;
   const int sel_threads = 1024;  // 1024 lanes per query: measured faster than 512 with twice the entries per lane (26.7 vs 37.7 us at 32 queries)
-  hipLaunchKernelGGL(sim_threshold_kernel<8>, dim3(B), dim3(sel_threads), 0, stream, ep.cand_val, p.cap, (int)p.n_slots,
-                     k, thr, ep.cand_cnt, (const int32_t*)nullptr, (const float*)nullptr, 1);
+  hipLaunchKernelGGL(sim_threshold_kernel, dim3(B), dim3(sel_threads), 0, stream, ep.cand_val, p.cap, (int)p.n_slots,
+                     k, thr, ep.cand_cnt, (const float*)nullptr);
   GDR_CHECK_LAUNCH("sim_threshold_kernel");
   if (p.stride > 1) {
     ep.mode = 2;
@@ -565,66 +558,184 @@ __global__ __launch_bounds__(256) void row_norm2_max_kernel(const float* __restr
   if (lane == 0) atomicMax(out, __float_as_uint(best));
 }
 
-// every candidate of the bf16 pass with s~ >= thr2[q] (= t~_k - 2 eps_q) -> ids[q][0 .. cnt2[q]); cnt2 > cap2 flags an overflow
-__global__ __launch_bounds__(1024) void prefilter_gather_kernel(const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx,
-                                                                const int32_t* __restrict__ cand_cnt, int64_t cap,
-                                                                const float* __restrict__ thr2, int cap2, int32_t* __restrict__ ids,
-                                                                int32_t* __restrict__ cnt2) {
+// The tail of the pre-filter in ONE launch per call (was four: k-th largest of the whole list, gather of the band, rescoring, exact
+// select — 75 us of kernels plus three launch gaps at 32 queries): a workgroup per query
+//   a. reads its candidate list once (keys cached in registers), radix-selects the k-th largest bf16-operand score t~_k,
+//   b. gathers the ids of the entries inside the band s~ >= t~_k - 2 eps_q into LDS,
+//   c. scores them in fp32 (a wave per candidate pair: the doc row in coalesced 16-byte pieces, q in registers),
+//   d. sorts (fp32 score, ~id) keys in LDS (bitonic, all waves) and writes the first k: higher score, then lower id.
+template <int RC>
+__global__ __launch_bounds__(1024) void prefilter_tail_kernel(const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx,
+                                                              const int32_t* __restrict__ cand_cnt, int64_t cap, int k, int cap2,
+                                                              int cap2p, const float* __restrict__ eps2, const float* __restrict__ Q,
+                                                              const float* __restrict__ D, int d, int32_t idx_offset,
+                                                              float* __restrict__ out_val, int32_t* __restrict__ out_idx,
+                                                              int32_t* __restrict__ status) {
+  __shared__ int hist[256];
+  __shared__ int scan[256];
+  __shared__ int res[2];
+  __shared__ uint32_t red[32];
   __shared__ int n_sh;
-  const int q = blockIdx.x;
-  if (threadIdx.x == 0) n_sh = 0;
-  __syncthreads();
-  const int c = cand_cnt[q], count = c < (int)cap ? c : (int)cap;
-  const float t = thr2[q];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long pkeys[];  // [cap2p]; the ids of the band first live in its upper half
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c_all = cand_cnt[q], count = c_all < (int)cap ? c_all : (int)cap;
   const float* v = cand_val + (int64_t)q * cap;
   const int32_t* ix = cand_idx + (int64_t)q * cap;
-  for (int i = threadIdx.x; i < count; i += blockDim.x) {
-    const int32_t id = ix[i];
-    if (id >= 0 && v[i] >= t) {
-      const int p = atomicAdd(&n_sh, 1);
-      if (p < cap2) ids[(int64_t)q * cap2 + p] = id;
+  const bool cached = count <= RC * 1024;
+  uint32_t rk[RC];
+#pragma unroll
+  for (int u = 0; u < RC; ++u) {
+    const int i = tid + u * 1024;
+    rk[u] = (cached && i < count) ? fkey(v[i]) : 0u;  // fkey(-inf) = 0x007fffff > 0: 0 marks "no entry"
+  }
+  const uint32_t kneg = fkey(-INFINITY);
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < RC; ++u)
+      if (rk[u] > kneg) lo = min(lo, rk[u]), hi = max(hi, rk[u]);
+  } else {
+    for (int i = tid; i < count; i += 1024) {
+      const float x = v[i];
+      if (x > -INFINITY) {
+        const uint32_t key = fkey(x);
+        lo = min(lo, key), hi = max(hi, key);
+      }
+    }
+  }
+  block_minmax(lo, hi, red);
+  if (hi < lo) lo = hi = fkey(-INFINITY);
+  const int nbits = hi > lo ? 32 - __clz(hi - lo) : 0;
+  const int lsh = 32 - nbits;
+  uint32_t prefix = 0;
+  int need = k;
+  for (int pass = 0; 8 * pass < nbits; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    if (cached) {
+#pragma unroll
+      for (int u = 0; u < RC; ++u) {
+        const uint32_t raw = rk[u];
+        const uint32_t key = (raw - lo) << lsh;
+        const bool match = pass == 0 ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+        if (raw != 0u && match && raw >= lo) atomicAdd(&hist[(key >> shift) & 255u], 1);
+      }
+    } else {
+      for (int i = tid; i < count; i += 1024) {
+        const uint32_t raw = fkey(v[i]);
+        const uint32_t key = (raw - lo) << lsh;
+        const bool match = pass == 0 ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+        if (match && raw >= lo) atomicAdd(&hist[(key >> shift) & 255u], 1);
+      }
+    }
+    __syncthreads();
+    int above;
+    const int b = find_bin(hist, scan, need, &above, res);
+    need -= above;
+    prefix |= (uint32_t)b << shift;
+    __syncthreads();
+  }
+  const float band = fkey_inv(nbits ? (prefix >> lsh) + lo : lo) - eps2[q];  // t~_k - 2 eps_q
+  // ---- b. the band's ids
+  int32_t* ids = reinterpret_cast<int32_t*>(pkeys + cap2p / 2);  // [cap2p] ints in the upper half of the key array
+  if (tid == 0) n_sh = 0;
+  __syncthreads();
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < RC; ++u) {
+      const int i = tid + u * 1024;
+      if (rk[u] > kneg && fkey_inv(rk[u]) >= band) {
+        const int32_t id = ix[i];
+        if (id >= 0) {
+          const int p = atomicAdd(&n_sh, 1);
+          if (p < cap2) ids[p] = id;
+        }
+      }
+    }
+  } else {
+    for (int i = tid; i < count; i += 1024) {
+      const int32_t id = ix[i];
+      if (id >= 0 && v[i] >= band) {
+        const int p = atomicAdd(&n_sh, 1);
+        if (p < cap2) ids[p] = id;
+      }
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) cnt2[q] = c > (int)cap ? cap2 + 1 : n_sh;  // an overflowed bf16 list cannot vouch for the band: flagged too
-}
-
-// vals[q][i] = fp32 q·D[ids[q][i]] for i < min(cnt2[q], cap2): a wave per candidate, the doc row read once in 16-byte pieces (a row
-// of d floats = d / 256 coalesced 1 KB wave loads), per-lane fmaf chains in k order, a fixed butterfly over the lanes
-__global__ __launch_bounds__(256) void rescore_dot_kernel(const float* __restrict__ Q, const float* __restrict__ D, int d,
-                                                          const int32_t* __restrict__ ids, const int32_t* __restrict__ cnt2, int cap2,
-                                                          int32_t id_base, float* __restrict__ vals) {
-  constexpr int MAXP = 4;  // d <= 1024
-  const int q = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = cnt2[q], count = c < cap2 ? c : cap2;
-  float4 qr[MAXP];
-#pragma unroll
-  for (int t = 0; t < MAXP; ++t) {
-    const int col = lane * 4 + 256 * t;
-    qr[t] = col < d ? *reinterpret_cast<const float4*>(Q + (int64_t)q * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  for (int i0 = (blockIdx.x * 4 + wave) * 2; i0 < count; i0 += gridDim.x * 8) {  // two candidates per wave and trip: both rows in flight
-    const int i1 = i0 + 1 < count ? i0 + 1 : i0;
-    const int64_t r0 = (int64_t)(ids[(int64_t)q * cap2 + i0] - id_base), r1 = (int64_t)(ids[(int64_t)q * cap2 + i1] - id_base);
-    float4 a0[MAXP], a1[MAXP];
+  const int n_all = n_sh, n2 = n_all < cap2 ? n_all : cap2;
+  if (tid == 0 && status) status[q] = (c_all > (int)cap || n_all > cap2) ? 1 : 0;
+  // ---- c. fp32 scores of the band (the candidate's slot i keeps its id until its key is written: lane 0 of the owning wave does both)
+  {
+    constexpr int MAXP = 4;  // d <= 1024
+    float4 qr[MAXP];
 #pragma unroll
     for (int t = 0; t < MAXP; ++t) {
       const int col = lane * 4 + 256 * t;
-      a0[t] = col < d ? *reinterpret_cast<const float4*>(D + r0 * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-      a1[t] = col < d ? *reinterpret_cast<const float4*>(D + r1 * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      qr[t] = col < d ? *reinterpret_cast<const float4*>(Q + (int64_t)q * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float s0 = 0.f, s1 = 0.f;
+    float* vals = reinterpret_cast<float*>(pkeys);  // [cap2p] floats in the first quarter: disjoint from the ids
+    for (int i0 = wave * 2; i0 < n2; i0 += 32) {
+      const int i1 = i0 + 1 < n2 ? i0 + 1 : i0;
+      const int64_t r0 = ids[i0], r1 = ids[i1];
+      float4 a0[MAXP], a1[MAXP];
 #pragma unroll
-    for (int t = 0; t < MAXP; ++t) {
-      s0 = fmaf(qr[t].x, a0[t].x, s0), s0 = fmaf(qr[t].y, a0[t].y, s0), s0 = fmaf(qr[t].z, a0[t].z, s0), s0 = fmaf(qr[t].w, a0[t].w, s0);
-      s1 = fmaf(qr[t].x, a1[t].x, s1), s1 = fmaf(qr[t].y, a1[t].y, s1), s1 = fmaf(qr[t].z, a1[t].z, s1), s1 = fmaf(qr[t].w, a1[t].w, s1);
-    }
+      for (int t = 0; t < MAXP; ++t) {
+        const int col = lane * 4 + 256 * t;
+        a0[t] = col < d ? *reinterpret_cast<const float4*>(D + r0 * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        a1[t] = col < d ? *reinterpret_cast<const float4*>(D + r1 * d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s0 += __shfl_xor(s0, off), s1 += __shfl_xor(s1, off);
-    if (lane == 0) {
-      vals[(int64_t)q * cap2 + i0] = s0;
-      if (i1 != i0) vals[(int64_t)q * cap2 + i1] = s1;
+      for (int t = 0; t < MAXP; ++t) {
+        s0 = fmaf(qr[t].x, a0[t].x, s0), s0 = fmaf(qr[t].y, a0[t].y, s0), s0 = fmaf(qr[t].z, a0[t].z, s0), s0 = fmaf(qr[t].w, a0[t].w, s0);
+        s1 = fmaf(qr[t].x, a1[t].x, s1), s1 = fmaf(qr[t].y, a1[t].y, s1), s1 = fmaf(qr[t].z, a1[t].z, s1), s1 = fmaf(qr[t].w, a1[t].w, s1);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s0 += __shfl_xor(s0, off), s1 += __shfl_xor(s1, off);
+      if (lane == 0) {
+        vals[i0] = s0;
+        if (i1 != i0) vals[i1] = s1;
+      }
     }
+    __syncthreads();
+    // ---- d. keys, sort, first k.  Keys are built from (vals, ids) through registers: the key array overlays both
+    unsigned long long mykey[4];  // cap2p <= 4096
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * 1024;
+      mykey[u] = 0ull;
+      if (i < n2) mykey[u] = ((unsigned long long)fkey(vals[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)ids[i]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * 1024;
+      if (i < cap2p) pkeys[i] = mykey[u];
+    }
+    __syncthreads();
+  }
+  for (int size = 2; size <= cap2p; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (cap2p >> 1); t += 1024) {
+        const int lo_i = (t / stride) * (stride << 1) + (t % stride), hi_i = lo_i + stride;
+        const bool desc = ((lo_i & size) == 0);
+        const unsigned long long a = pkeys[lo_i], b = pkeys[hi_i];
+        if ((a < b) == desc) pkeys[lo_i] = b, pkeys[hi_i] = a;
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < k; i += 1024) {
+    const unsigned long long key = pkeys[i];
+    float val = -INFINITY;
+    int32_t id = -1;
+    if (i < n2 && key != 0ull) {
+      val = fkey_inv((uint32_t)(key >> 32));
+      id = (int32_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) + idx_offset;
+    }
+    out_val[(int64_t)q * k + i] = val;
+    out_idx[(int64_t)q * k + i] = id;
   }
 }
 
@@ -636,7 +747,7 @@ static int prefilter_cap2(int k) {
 struct PrefilterPlan {
   SimPlan p;
   int cap2;
-  size_t off_q16, off_eps, off_thr2, off_cnt2, off_ids, off_vals, total;
+  size_t off_q16, off_eps, total;
 };
 static PrefilterPlan make_prefilter_plan(int B, int64_t N, int d, int k) {
   PrefilterPlan pp{};
@@ -645,10 +756,6 @@ static PrefilterPlan make_prefilter_plan(int B, int64_t N, int d, int k) {
   size_t o = pp.p.total;
   pp.off_q16 = o, o += align_up((size_t)B * d * 2, 256);
   pp.off_eps = o, o += align_up((size_t)B * 4, 256);
-  pp.off_thr2 = o, o += align_up((size_t)B * 4, 256);
-  pp.off_cnt2 = o, o += align_up((size_t)B * 4, 256);
-  pp.off_ids = o, o += align_up((size_t)B * pp.cap2 * 4, 256);
-  pp.off_vals = o, o += align_up((size_t)B * pp.cap2 * 4, 256);
   pp.total = o;
   return pp;
 }
@@ -703,38 +810,27 @@ extern "C" int gdr_sim_topk_prefilter(const float* Q, int B, const float* D, con
   ep.thr = thr, ep.status = nullptr, ep.cap = (int32_t)p.cap, ep.tile_stride = p.stride, ep.mode = 1;
   __bf16* Q16 = reinterpret_cast<__bf16*>(ws + pp.off_q16);
   float* eps2 = reinterpret_cast<float*>(ws + pp.off_eps);
-  float* thr2 = reinterpret_cast<float*>(ws + pp.off_thr2);
-  int32_t* cnt2 = reinterpret_cast<int32_t*>(ws + pp.off_cnt2);
-  int32_t* ids2 = reinterpret_cast<int32_t*>(ws + pp.off_ids);
-  float* vals2 = reinterpret_cast<float*>(ws + pp.off_vals);
   hipLaunchKernelGGL(sim_qprep_kernel, dim3(B), dim3(256), 0, stream, Q, d, dnorm_max, Q16, eps2);
   GDR_CHECK_LAUNCH("sim_qprep_kernel");
   int rc = launch_sim_gemm(D_bf16, N, Q16, B, d, ep, true, stream);
   if (rc) return rc;
   // L - 2 eps: the filter pass keeps a superset of the band around the (yet unknown) k-th largest bf16 score
-  hipLaunchKernelGGL(sim_threshold_kernel<8>, dim3(B), dim3(1024), 0, stream, ep.cand_val, p.cap, (int)p.n_slots, k, thr, ep.cand_cnt,
-                     (const int32_t*)nullptr, (const float*)eps2, 1);
+  hipLaunchKernelGGL(sim_threshold_kernel, dim3(B), dim3(1024), 0, stream, ep.cand_val, p.cap, (int)p.n_slots, k, thr, ep.cand_cnt,
+                     (const float*)eps2);
   GDR_CHECK_LAUNCH("sim_threshold_kernel");
   if (p.stride > 1) {
     ep.mode = 2;
     rc = launch_sim_gemm(D_bf16, N, Q16, B, d, ep, true, stream);
     if (rc) return rc;
   }
-  // t~_k - 2 eps over the whole candidate list, then the docs inside the band
-  hipLaunchKernelGGL(sim_threshold_kernel<16>, dim3(B), dim3(1024), 0, stream, ep.cand_val, p.cap, (int)p.n_slots, k, thr2, ep.cand_cnt,
-                     (const int32_t*)ep.cand_cnt, (const float*)eps2, 0);
-  GDR_CHECK_LAUNCH("sim_threshold_kernel(all candidates)");
-  hipLaunchKernelGGL(prefilter_gather_kernel, dim3(B), dim3(1024), 0, stream, ep.cand_val, ep.cand_idx, ep.cand_cnt, p.cap,
-                     (const float*)thr2, pp.cap2, ids2, cnt2);
-  GDR_CHECK_LAUNCH("prefilter_gather_kernel");
-  hipLaunchKernelGGL(rescore_dot_kernel, dim3(16, B), dim3(256), 0, stream, Q, D, d, (const int32_t*)ids2, (const int32_t*)cnt2, pp.cap2,
-                     (int32_t)0, vals2);
-  GDR_CHECK_LAUNCH("rescore_dot_kernel");
-  const int kpad = next_pow2(k);
-  hipLaunchKernelGGL(topk_select_kernel<false>, dim3(B), dim3(1024), kpad * sizeof(unsigned long long), stream, (const float*)vals2,
-                     (const int32_t*)ids2, (const int32_t*)cnt2, (int64_t)pp.cap2, 1, B, k, kpad, idx_offset, (const float*)nullptr, out_val,
-                     out_idx, status, 0, 1);
-  GDR_CHECK_LAUNCH("topk_select_kernel(prefilter)");
+  // the tail in one launch: k-th largest bf16-operand score, the band around it, fp32 scores of the band, exact select
+  int cap2p = 1024;
+  while (cap2p < pp.cap2) cap2p <<= 1;
+  if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(prefilter_tail_kernel<16>), cap2p * 8, "sim_topk_prefilter")) return rc__;
+  hipLaunchKernelGGL(prefilter_tail_kernel<16>, dim3(B), dim3(1024), (size_t)cap2p * 8, stream, (const float*)ep.cand_val,
+                     (const int32_t*)ep.cand_idx, (const int32_t*)ep.cand_cnt, p.cap, k, pp.cap2, cap2p, (const float*)eps2, Q, D, d,
+                     idx_offset, out_val, out_idx, status);
+  GDR_CHECK_LAUNCH("prefilter_tail_kernel");
   return GDR_OK;
 }
 
