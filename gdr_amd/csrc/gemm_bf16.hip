@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
       const int c0 = __shfl(mine, r16), c1 = __shfl(mine, r16 + 16), c2 = __shfl(mine, r16 + 32), c3 = __shfl(mine, r16 + 48);
       const int total = c0 + c1 + c2 + c3;
       int base = 0;
-      if (q4 == 0 && total > 0) base = atomicAdd(g.sim.cand_cnt + q, total);
+      if (q4 == 0 && total > 0) base = atomicAdd(g.sim.cand_cnt + (int64_t)q * CNT_STRIDE, total);
       base = __shfl(base, r16);
       int pos = base + (q4 > 0 ? c0 : 0) + (q4 > 1 ? c1 : 0) + (q4 > 2 ? c2 : 0);
       if (mine) {

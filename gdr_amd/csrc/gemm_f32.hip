@@ -349,7 +349,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(const Gemm
         const int mine = __popc(keep[0]) + __popc(keep[1]);
         const int other = __shfl_xor(mine, 32);
         int base = 0;
-        if (h == 0 && mine + other > 0) base = atomicAdd(g.sim.cand_cnt + n, mine + other);
+        if (h == 0 && mine + other > 0) base = atomicAdd(g.sim.cand_cnt + (int64_t)n * CNT_STRIDE, mine + other);
         base = __shfl(base, l31);
         int pos = base + (h ? other : 0);
         if (mine) {

@@ -58,7 +58,7 @@ static SimPlan make_plan(int B, int64_t N, int k, bool exhaustive) {
   size_t o = 0;
   p.off_val = o, o += align_up((size_t)B * p.cap * sizeof(float), 256);
   p.off_idx = o, o += align_up((size_t)B * p.cap * sizeof(int32_t), 256);
-  p.off_cnt = o, o += align_up((size_t)B * sizeof(int32_t), 256);
+  p.off_cnt = o, o += align_up((size_t)B * CNT_STRIDE * sizeof(int32_t), 256);
   p.off_thr = o, o += align_up((size_t)B * sizeof(float), 256);
   p.total = o;
   return p;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(1024) void sim_threshold_kernel(const float* __rest
   if (threadIdx.x == 0) {
     const float t = fkey_inv(nbits ? (prefix >> lsh) + lo : lo);
     thr[q] = sub ? t - sub[q] : t;
-    cand_cnt[q] = n_slots;  // survivors of the filter pass are appended behind the sample block
+    cand_cnt[(int64_t)q * CNT_STRIDE] = n_slots;  // survivors of the filter pass are appended behind the sample block
   }
 }
 
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
       status[q] = any != 0 ? 1 : 0;
     }
   } else {
-    const int c = cnt[q];
+    const int c = cnt[(int64_t)q * CNT_STRIDE];  // the similarity passes' counters (common.h CNT_STRIDE)
     count = c < (int)cap ? c : (int)cap;
     if (status && threadIdx.x == 0) status[q] = c > (int)cap ? 1 : 0;  // list overflowed: result is a subset's top-k
   }
@@ -478,8 +478,7 @@ int gdr::sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, in
   ep.tile_stride = p.stride;
   ep.mode = 1;
   const bool stream_mode = sim_stream_supported(B, d, bf16) && !(flags & GDR_SIM_NO_STREAM);
-  int rc = stream_mode ? launch_sim_stream(static_cast<const float*>(D), N, static_cast<const float*>(Q), B, d, ep, stream)
-                       : launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
+  int rc = stream_mode ? launch_sim_stream(D, N, Q, B, d, ep, bf16, stream) : launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
   if (rc) return rc;
   const int sel_threads = 1024;  // 1024 lanes per query: measured faster than 512 with twice the entries per lane (26.7 vs 37.7 us at 32 queries)
   hipLaunchKernelGGL(sim_threshold_kernel, dim3(B), dim3(sel_threads), 0, stream, ep.cand_val, p.cap, (int)p.n_slots,
@@ -487,8 +486,7 @@ int gdr::sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, in
   GDR_CHECK_LAUNCH("sim_threshold_kernel");
   if (p.stride > 1) {
     ep.mode = 2;
-    rc = stream_mode ? launch_sim_stream(static_cast<const float*>(D), N, static_cast<const float*>(Q), B, d, ep, stream)
-                     : launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
+    rc = stream_mode ? launch_sim_stream(D, N, Q, B, d, ep, bf16, stream) : launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
     if (rc) return rc;
   }
   const int kpad = next_pow2(k);
@@ -578,7 +576,7 @@ __global__ __launch_bounds__(1024) void prefilter_tail_kernel(const float* __res
   __shared__ int n_sh;
   extern __shared__ __attribute__((aligned(16))) unsigned long long pkeys[];  // [cap2p]; the ids of the band first live in its upper half
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c_all = cand_cnt[q], count = c_all < (int)cap ? c_all : (int)cap;
+  const int c_all = cand_cnt[(int64_t)q * CNT_STRIDE], count = c_all < (int)cap ? c_all : (int)cap;
   const float* v = cand_val + (int64_t)q * cap;
   const int32_t* ix = cand_idx + (int64_t)q * cap;
   const bool cached = count <= RC * 1024;
@@ -812,7 +810,8 @@ extern "C" int gdr_sim_topk_prefilter(const float* Q, int B, const float* D, con
   float* eps2 = reinterpret_cast<float*>(ws + pp.off_eps);
   hipLaunchKernelGGL(sim_qprep_kernel, dim3(B), dim3(256), 0, stream, Q, d, dnorm_max, Q16, eps2);
   GDR_CHECK_LAUNCH("sim_qprep_kernel");
-  int rc = launch_sim_gemm(D_bf16, N, Q16, B, d, ep, true, stream);
+  const bool stream_mode = sim_stream_supported(B, d, true);  // B <= 32: the HBM-bound stream over the bf16 image
+  int rc = stream_mode ? launch_sim_stream(D_bf16, N, Q16, B, d, ep, true, stream) : launch_sim_gemm(D_bf16, N, Q16, B, d, ep, true, stream);
   if (rc) return rc;
   // L - 2 eps: the filter pass keeps a superset of the band around the (yet unknown) k-th largest bf16 score
   hipLaunchKernelGGL(sim_threshold_kernel, dim3(B), dim3(1024), 0, stream, ep.cand_val, p.cap, (int)p.n_slots, k, thr, ep.cand_cnt,
@@ -820,7 +819,7 @@ extern "C" int gdr_sim_topk_prefilter(const float* Q, int B, const float* D, con
   GDR_CHECK_LAUNCH("sim_threshold_kernel");
   if (p.stride > 1) {
     ep.mode = 2;
-    rc = launch_sim_gemm(D_bf16, N, Q16, B, d, ep, true, stream);
+    rc = stream_mode ? launch_sim_stream(D_bf16, N, Q16, B, d, ep, true, stream) : launch_sim_gemm(D_bf16, N, Q16, B, d, ep, true, stream);
     if (rc) return rc;
   }
   // the tail in one launch: k-th largest bf16-operand score, the band around it, fp32 scores of the band, exact select

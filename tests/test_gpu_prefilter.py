@@ -117,12 +117,23 @@ def test_prefilter_shapes_and_scales(dev, N, B, k, scale):
     order_insensitive_topk_match(fv, fi, pv, pi, tol)
 
 
-def test_small_batches_keep_the_latency_mode_path(dev):
-    """B <= 32 is HBM-bound: the pre-filter is not used there (ops.PREFILTER_MIN_BATCH) — same bits as the fp32 path."""
+@pytest.mark.parametrize("B", [1, 7, 32])
+def test_latency_mode_bf16_stream_and_prefilter(dev, B):
+    """B <= 32 (latency mode): the corpus-wide pass of the pre-filter is sim_stream_bf16_kernel — the HBM stream over the bf16 image,
+    half the bytes of the fp32 stream.  (a) the bf16-corpus entry point (gdr_sim_topk_bf16) on it equals the oracle on the bf16-rounded
+    operands; (b) the pre-filtered fp32 result equals the all-fp32 path under the top-k rule; ragged N (not a multiple of 128)."""
     from gdr_amd import ops
-    D = synth.make_corpus(60000, 768, seed=2)
-    Q, _ = synth.make_queries(D, 16, seed=3)
+    from oracle import retrieval_ref
+    N, k = 100037, 100
+    D = synth.make_corpus(N, 768, seed=11)
+    Q, _ = synth.make_queries(D, B, seed=12)
     Qd, Dd = torch.from_numpy(Q).to(dev), torch.from_numpy(D).to(dev)
-    a = ops.sim_topk(Qd, Dd, 100)
-    b = ops.sim_topk(Qd, ops.PrefilteredCorpus(Dd), 100)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    D16 = ops.to_bf16(Dd)
+    bv, bi = ops.sim_topk(Qd, D16, k)
+    rv, ri = retrieval_ref.sim_topk(torch.from_numpy(Q).bfloat16().float(), torch.from_numpy(D).bfloat16().float(), k)
+    order_insensitive_topk_match(rv.numpy(), ri.numpy(), bv.cpu().numpy(), bi.cpu().numpy().astype(np.int64), 1e-5)
+    fv, fi = ops.sim_topk(Qd, Dd, k)
+    pv, pi = ops.sim_topk(Qd, ops.PrefilteredCorpus(Dd), k)
+    order_insensitive_topk_match(fv.cpu().numpy(), fi.cpu().numpy().astype(np.int64), pv.cpu().numpy(), pi.cpu().numpy().astype(np.int64), TOL32)
+    ov, oi = retrieval_ref.sim_topk(torch.from_numpy(Q), torch.from_numpy(D), k)
+    order_insensitive_topk_match(ov.numpy(), oi.numpy(), pv.cpu().numpy(), pi.cpu().numpy().astype(np.int64), 1e-4)

@@ -10,7 +10,6 @@ N, d, k = 320000, 768, 100
 Dn = synth.make_corpus(N, d)
 D = torch.from_numpy(Dn).to(dev)
 P = ops.PrefilteredCorpus(D)
-ops.PREFILTER_MIN_BATCH = 1
 for B in (1, 8, 32, 64):
     Qn, _ = synth.make_queries(Dn[:50000], B)
     Q = torch.from_numpy(Qn).to(dev)

@@ -7,7 +7,6 @@ B = int(os.environ.get("B", 32))
 Dn = synth.make_corpus(320000, 768)
 D = torch.from_numpy(Dn).to(dev)
 P = ops.PrefilteredCorpus(D)
-ops.PREFILTER_MIN_BATCH = 1
 Qn, _ = synth.make_queries(Dn[:50000], B); Q = torch.from_numpy(Qn).to(dev)
 ws = ops.Workspace(dev)
 for _ in range(5):
