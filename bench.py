@@ -299,6 +299,21 @@ def stages(dev, cfg, D, D_dev, a):
         e["bound"] = "hbm" if bytes_ / (HBM_PEAK_GBS * 1e9) > flops / (F32_MFMA_PEAK_TFLOPS * 1e12) else "mfma"
         sim[f"B{B}"] = e
     out["similarity_topk_f32"] = sim
+    # the same calls through the bf16 pre-filter (gdr_sim_topk_prefilter: identical fp32 top-k; the corpus-wide pass streams the bf16
+    # image — half the bytes).  frac_of_hbm_peak prices the bytes this form must move (bf16 image + fp32 rescoring rows)
+    P = ops.PrefilteredCorpus(D_dev)
+    simp = {}
+    for B in (1, 32, 512):
+        Qn, _ = synth.make_queries(D[:50000], B, seed=3)
+        Q = torch.from_numpy(Qn).to(dev)
+        t = timed(lambda: ops.sim_topk(Q, P, k, workspace=ws, exact_on_overflow=False), reps=10, warm=3)
+        bytes_ = N * d * 2 + B * d * 4 + B * k * 8
+        simp[f"B{B}"] = {"ms": t * 1e3, "queries_per_s": B / t, "algorithmic_mb": bytes_ / 1e6, "gbs": bytes_ / t / 1e9,
+                         "frac_of_hbm_peak": bytes_ / t / 1e9 / HBM_PEAK_GBS,
+                         "speedup_vs_all_fp32": sim[f"B{B}"]["ms"] / (t * 1e3)}
+    out["similarity_topk_f32_prefilter"] = simp
+    del P
+    torch.cuda.empty_cache()
     # ---- docid beam decode (generate()) and the two-stage path, t5-base with the GDR head
     sd = synth.make_state_dict(cfg, seed=1234)
     names, id_depth, offsets, members = synth.make_cluster_ids(N, cluster_size=12, V=30)
@@ -577,7 +592,7 @@ def two_stage_parity(retr, batch, mask_np, sd, cfg, look, args, D_dev, bf16, tre
 
 
 def stages_summary(st):
-    """A dozen scalars of the stages for the headline line (the full object goes to the #stages line)."""
+    """A dozen-odd scalars of the stages for the headline line (the full object goes to the #stages line)."""
     g, sim = st["generate"], st["similarity_topk_f32"]
     return {"c3_B64_beam10_qps": st["c3_two_stage"]["queries_per_s"],
             "c3_best_sustained_qps": st["c3_best_sustained"]["queries_per_s"],
@@ -588,6 +603,8 @@ def stages_summary(st):
             "bf16_B64_beam30_generate_ms": st["bf16_mode_generate_B64_beam30"]["generate_ms"],
             "sim_B1_ms": sim["B1"]["ms"], "sim_B32_ms": sim["B32"]["ms"],
             "sim_B32_frac_of_hbm_peak": sim["B32"]["frac_of_hbm_peak"],
+            "sim_B1_prefilter_ms": st["similarity_topk_f32_prefilter"]["B1"]["ms"],
+            "sim_B32_prefilter_ms": st["similarity_topk_f32_prefilter"]["B32"]["ms"],
             "doc_tower_frac_of_f32_mfma_peak": st["doc_tower_bert_base_L128"]["frac_of_f32_mfma_peak"]}
 
 
