@@ -1431,6 +1431,108 @@ __global__ __launch_bounds__(256) void attention_decode_short_kernel(const AttnA
   }
 }
 
+// Four heads per wave (r05; d_kv = 64, H % 4 == 0, Lq = 1, <= 16 keys): at thousands of beam rows the form above is bound by its
+// INSTRUCTIONS — a wave per (row, head) runs ~175 vector instructions for 18 multiply-adds per lane (184 000 waves at 15 360 rows: its
+// launch time did not move when its bytes were halved, its loads de-duplicated or its heads batched per wave,
+// profiles/r05_decode_attention_ab.txt).  Here a wave serves FOUR adjacent heads of a row, one per 16-lane DPP row: lane (hg, c) owns
+// columns 4c .. 4c+3 of head 4*h0 + hg, so a key's K (or V) slice of the four heads is ONE contiguous 1 KB wave load (the form above
+// gathers four different rows per load), the row table is read once per four heads, key indices are scalar (readlane), and every
+// reduction (q.k over a head's 16 lanes, softmax max / sum over a head's keys) is the same DPP row operation on all four rows at
+// once.  Per (row, head) the arithmetic and its order are the form above's — q.k: the lane's 4-term fmaf chain, then row16_sum;
+// softmax: lane c <-> key c inside the row; P.V: four partial sums over the keys j = g (mod 4) in ascending order combined as
+// (a0 + a1) + (a2 + a3), which is what the other form's two xor-shuffles compute — so the output is bit-identical
+// (tools/exp_ab_bits.py, tests/test_gpu_decode.py).
+template <int MAXK>
+__global__ __launch_bounds__(256) void attention_decode_heads4_kernel(const AttnArgs a) {
+  __shared__ float strip[4][4][16];  // [wave][head row][key]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  unsigned bid = blockIdx.x;
+  {
+    const unsigned nblk = gridDim.x, q_ = nblk >> 3, r_ = nblk & 7u, xcd_ = bid & 7u, j_ = bid >> 3;
+    bid = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + j_;
+  }
+  const int HG = a.H >> 2;  // head quads per row
+  const int item = (int)bid * 4 + wave;
+  if (item >= a.B * HG) return;
+  if (a.live && *a.live == 0) return;  // every query of the generate call is done
+  const int b = item / HG, h0 = item % HG;
+  if (a.b_count_dev && b >= (int)*a.b_count_dev) return;
+  const int Lk = a.Lk, kb = b / a.kv_group;
+  const int hg = lane >> 4, c = lane & 15, h = h0 * 4 + hg;
+  const int colw = h0 * 256 + lane * 4;  // this lane's first column: the wave covers 256 consecutive floats of a row
+  float* S = strip[wave][hg];
+  int myrow = 0;
+  if (lane < Lk) myrow = a.kv_rows ? a.kv_rows[(int64_t)b * Lk + lane] : kb * (int)a.k_bstride + lane;
+  float4 q = *reinterpret_cast<const float4*>(a.q + (int64_t)b * a.q_bstride * a.ldq + colw);
+  // bias + mask of key c of this lane's head (lane c <-> key c inside every DPP row)
+  float add = 0.f;
+  if (c < Lk) {
+    const int j = c, i_abs = a.q_pos0;
+    if (a.rel_bias) {
+      int n = i_abs - j, bucket = 0;
+      if (a.bidirectional) {
+        if (n < 0) {
+          bucket = a.num_buckets >> 1;
+          n = -n;
+        }
+      } else if (n < 0) {
+        n = 0;
+      }
+      bucket += a.lut.v[n < 127 ? n : 127];
+      add = a.rel_bias[bucket * a.H + h];
+    }
+    bool allowed = true;
+    if (a.causal) allowed = j <= i_abs;
+    if (a.key_mask) allowed = allowed && (a.key_mask[(int64_t)kb * a.mask_bstride + j] != 0);
+    if (!allowed) add += a.causal_neg_inf ? -INFINITY : -1e9f;
+  }
+  float4 kreg[MAXK], vreg[MAXK];
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    if (j < Lk) {  // uniform
+      const int64_t rj = __builtin_amdgcn_readlane(myrow, j);
+      kreg[j] = *reinterpret_cast<const float4*>(a.k + (rj * a.ldk + colw));
+      vreg[j] = *reinterpret_cast<const float4*>(a.v + (rj * a.ldv + colw));
+    }
+  }
+  q.x *= a.scale, q.y *= a.scale, q.z *= a.scale, q.w *= a.scale;
+  float sj = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    if (j < Lk) {
+      const float4 kk = kreg[j];
+      float part = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
+      part = row16_sum(part);  // every lane of the head's row holds the score of key j
+      if (c == j) sj = part + add;
+    }
+  }
+  const float mx = row16_max(sj);
+  const float p0 = c < Lk ? expf(sj - mx) : 0.f;
+  const float inv = 1.0f / row16_sum(p0);
+  if (c < Lk) S[c] = p0 * inv;
+  __builtin_amdgcn_wave_barrier();  // the strip is private to this wave: LDS operations of one wave complete in order
+  float4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    if (j < Lk) {
+      const float4 vv = vreg[j];
+      const float pj = S[j];
+      float4& o = acc[j & 3];
+      o.x = fmaf(pj, vv.x, o.x), o.y = fmaf(pj, vv.y, o.y), o.z = fmaf(pj, vv.z, o.z), o.w = fmaf(pj, vv.w, o.w);
+    }
+  }
+  float4 o;
+  o.x = (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x), o.y = (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y);
+  o.z = (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z), o.w = (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w);
+  const int64_t off = (int64_t)b * a.o_bstride * a.ldo + colw;
+  if (a.out_bf16)
+    *reinterpret_cast<uint2*>(static_cast<__bf16*>(a.out_bf16) + off) = pack_bf16x4(o.x, o.y, o.z, o.w);
+  else
+    *reinterpret_cast<float4*>(a.out + off) = o;
+}
+
 // Measured and dropped (r05): a workgroup per (query, head) that numbers the DISTINCT (position, row) pairs of the query's R beam rows,
 // stages each of them once in LDS and serves all R rows from there (97 distinct of 270 gathered rows per query at 30 beams,
 // tools/exp_prefix_sharing.py) — bit-identical, but generate() at 512 x 30 beams took 47.9 ms (50.3 with the queries prefetched and a
@@ -1455,6 +1557,22 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   if (a.Lq == 1 && a.dk <= 128 && a.ldo % 4 == 0) {
     if (a.Lk <= (a.dk <= 64 ? 16 : 12)) {  // a decode step's key list
       // the beam rows of a query share their ancestors: one workgroup per (query, head) stages the distinct K / V rows once
+#ifndef GDR_LAB_ATTN_NO_HEADS4
+      // from a few thousand (row, head) items on the per-(row, head) form is bound by its instruction count: four heads per wave
+      if (a.dk == 64 && a.H % 4 == 0 && !a.q_part && (int64_t)a.B * a.H >= 4096) {
+        const dim3 g4((unsigned)((a.B * (a.H / 4) + 3) / 4));
+        if (a.Lk <= 4)
+          hipLaunchKernelGGL(attention_decode_heads4_kernel<4>, g4, dim3(256), 0, stream, a);
+        else if (a.Lk <= 8)
+          hipLaunchKernelGGL(attention_decode_heads4_kernel<8>, g4, dim3(256), 0, stream, a);
+        else if (a.Lk <= 12)
+          hipLaunchKernelGGL(attention_decode_heads4_kernel<12>, g4, dim3(256), 0, stream, a);
+        else
+          hipLaunchKernelGGL(attention_decode_heads4_kernel<16>, g4, dim3(256), 0, stream, a);
+        GDR_CHECK_LAUNCH("attention_decode_heads4_kernel");
+        return GDR_OK;
+      }
+#endif
       const dim3 grids((unsigned)((a.B * a.H + 3) / 4));
       if (a.dk <= 64)
         hipLaunchKernelGGL(attention_decode_short_kernel<16>, grids, dim3(256), 0, stream, a);
