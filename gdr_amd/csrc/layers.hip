@@ -1558,8 +1558,8 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     if (a.Lk <= (a.dk <= 64 ? 16 : 12)) {  // a decode step's key list
       // the beam rows of a query share their ancestors: one workgroup per (query, head) stages the distinct K / V rows once
 #ifndef GDR_LAB_ATTN_NO_HEADS4
-      // from a few thousand (row, head) items on the per-(row, head) form is bound by its instruction count: four heads per wave
-      if (a.dk == 64 && a.H % 4 == 0 && !a.q_part && (int64_t)a.B * a.H >= 4096) {
+      // from ~1 400 beam rows on: four heads per wave (at 640 rows x 12 heads the two forms tie: 12.07 against 12.02 ms per generate())
+      if (a.dk == 64 && a.H % 4 == 0 && !a.q_part && (int64_t)a.B * a.H >= 16384) {
         const dim3 g4((unsigned)((a.B * (a.H / 4) + 3) / 4));
         if (a.Lk <= 4)
           hipLaunchKernelGGL(attention_decode_heads4_kernel<4>, g4, dim3(256), 0, stream, a);
