@@ -232,11 +232,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void sim_stream_bf16_kernel(const S
   __syncthreads();
   const char* qrow = qsb + l31 * QSB + 64 * h;
   const int G = d >> 6;  // 64-k groups, multiple of 4
-#ifdef GDR_LAB_STREAM_NOSURV
-  const float thr = INFINITY;  // lab ablation: nothing survives the filter
-#else
   const float thr = (MODE == 2 && l31 < g.B) ? g.sim.thr[l31] : 0.f;
-#endif
   float* cv = g.sim.cand_val + (int64_t)l31 * g.sim.cap;
   int32_t* ci = g.sim.cand_idx + (int64_t)l31 * g.sim.cap;
   const int capl = MODE == 2 ? g.capl : 0;
@@ -333,11 +329,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void sim_stream_bf16_kernel(const S
         }
         const int mine = __popc(keep);
         const int other = __shfl_xor(mine, 32);
-#ifdef GDR_LAB_STREAM_EPI
-        const int total = (mine + other) == 12345 ? 1 : 0;  // lab ablation: the flags are computed, nothing is ever appended
-#else
         const int total = mine + other;
-#endif
         int base = 0;
         bool local = false;
         if (capl) {

@@ -148,6 +148,8 @@ def test_bench_gpus_2_on_one_gpu_through_gloo():
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 128 and j["config"]["workload"].startswith("C4-layout")
     assert j["config"]["dist_backend"] == "gloo" and j["value"] > 0 and j["cpu_baseline"] is None
     assert abs(j["value"] - 128 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
+    p = _run("--gpus", "2", "--backend", "gloo", "--no-stages", "--sim-prefilter", "bf16")     # every shard behind its bf16 pre-filter
+    assert p["n_gpus"] == 2 and p["config"]["workload"].startswith("C4-layout/ragged/prefilter") and p["value"] > 0
     k = _run("--gpus", "2", "--backend", "gloo", "--workload", "c3", "--batch", "8")
     assert k["n_gpus"] == 2 and k["config"]["workload"].startswith("C3/sharded") and k["config"]["global_batch"] == 16
     assert k["value"] > 0 and k["config"]["candidates_per_query"] == 120
