@@ -701,7 +701,8 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamBufs bb, BeamDims 
             *bb.live = 0;  // the steps already enqueued skip their linears (StreamK::live) and their miss-row chain
             if (bb.all_done_host) {
               __hip_atomic_store(bb.all_done_host + 64, cur_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the step it happened at
-              __hip_atomic_store(bb.all_done_host, bb.done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              // release: a host that sees the epoch also sees the step word stored just above
+              __hip_atomic_store(bb.all_done_host, bb.done_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
           }
         }
@@ -1568,7 +1569,7 @@ extern "C" int gdr_t5_generate_last_done_step(void) {
   int32_t* words = gdr::done_words();
   const int32_t e = gdr::g_done_epoch.load();
   if (!words || e == 0) return 0;
-  return __atomic_load_n(words + (e & 63), __ATOMIC_RELAXED) == e ? __atomic_load_n(words + 64 + (e & 63), __ATOMIC_RELAXED) : 0;
+  return __atomic_load_n(words + (e & 63), __ATOMIC_ACQUIRE) == e ? __atomic_load_n(words + 64 + (e & 63), __ATOMIC_RELAXED) : 0;
 }
 
 extern "C" int gdr_t5_generate(const GdrT5DecoderWeights* w, const float* enc_hidden, const int64_t* enc_mask, int B,

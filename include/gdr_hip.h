@@ -489,7 +489,10 @@ int64_t gdr_t5_generate_early_exits(void);
 /* The device half of the same exit, observable: the decode step (cur_len, 1-based) at which the LAST query of the most recent
  * gdr_t5_generate call of this process became done, written by the beam bookkeeping kernel into host-mapped memory; 0 when
  * that call ran to max_length without every query finishing (or ran with the per-step trace).  Read it after the call's
- * stream has been synchronised.  Deterministic (unlike the host-side counter above, which races with the GPU by design). */
+ * stream has been synchronised.  Deterministic (unlike the host-side counter above, which races with the GPU by design) —
+ * for STRICTLY SERIAL calls only: "the most recent call" is the most recently STARTED one of the process, so with several calls
+ * in flight (GDRRetriever.validation_steps at depth >= 2, several host threads) or after a call that took no epoch (per-step trace
+ * requested) it reports another call's step, or 0.  A monitoring / test hook, not part of the result. */
 int gdr_t5_generate_last_done_step(void);
 int gdr_t5_prefix_table_build_bf16(const GdrT5DecoderWeights* w, int n_levels, const int32_t* level_off,
                                    const int64_t* node_tok, const int32_t* node_anc, float* kv, float* W, void* workspace,
