@@ -81,8 +81,22 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
   int64_t m0, slot_base = 0;
   int64_t n0;
   if (LIN) {
-    m0 = (int64_t)(bid / (unsigned)g.tiles_n) * BM;
-    n0 = (int64_t)(bid % (unsigned)g.tiles_n) * 128;
+    if (g.tiles_n >= 32) {
+      // wide outputs (the decode head: N = 23 808 = 186 column tiles, 36.6 MB of W): in row-panel-major order every row panel streams
+      // ALL of W past an XCD's 4 MiB L2 — 120 panels x 36.6 MB = 4.4 GB per launch at 15 360 rows, the launch ran at 7 TB/s of
+      // HBM-side fetches (profiles/r05_generate_bf16_512x30_pmc_by_kernel.txt).  Supertiles of 8 row panels x all column tiles,
+      // row-panel-fastest inside: a W tile is fetched once per 8 panels, the 8 A panels (1.5 MB) stay resident.
+      constexpr unsigned GM = 8;
+      const unsigned tiles_m = (unsigned)((Mv + BM - 1) / BM);
+      const unsigned per = GM * (unsigned)g.tiles_n, grp = bid / per, loc = bid - grp * per;
+      const unsigned gm = min(GM, tiles_m - grp * GM);
+      const unsigned nt = loc / gm;
+      m0 = (int64_t)(grp * GM + (loc - nt * gm)) * BM;
+      n0 = (int64_t)nt * 128;
+    } else {
+      m0 = (int64_t)(bid / (unsigned)g.tiles_n) * BM;
+      n0 = (int64_t)(bid % (unsigned)g.tiles_n) * 128;
+    }
   } else {
     int64_t dt = bid / (unsigned)g.tiles_n;  // doc tile of this pass
     m0 = (int64_t)(bid % (unsigned)g.tiles_n) * 128;  // query tile
