@@ -335,6 +335,8 @@ def stages(dev, cfg, D, D_dev, a):
                                  kary=30, position=1, score_rate=[0, 0.5, 1, 1.5, 2, 2.5, 3], loss_func="tanh")
     gen, cpu_two = {}, {}
     ids_np, mask_np = {}, {}
+    from gdr_amd import _ffi as _ffi_s
+    lib_count = _ffi_s.lib().gdr_launch_count
     # C3 at infer.sh's eval batch, one query x 100 beams, C2's batch; --sweep: the batch sizes that show where the decode chain
     # stops being launch-bound
     sweep = ((64, 10), (1, 100), (512, 10)) + (((128, 10), (256, 10), (1024, 10), (2048, 10)) if a.sweep else ())
@@ -346,6 +348,10 @@ def stages(dev, cfg, D, D_dev, a):
         g = lambda: model.generate(ids, attention_mask=mask, max_length=10, num_beams=R, length_penalty=0.8,   # noqa: E731
                                    num_return_sequences=R, output_scores=True, output_encoder_embedding=True)
         t = timed(g, reps=5, warm=2)
+        n0_l = lib_count()
+        g()
+        torch.cuda.synchronize()
+        launches = lib_count() - n0_l                                     # library kernel launches of one generate() call (encoder + decode)
         t_enc = timed(lambda: model.enc.forward(ids, mask, want_pooled=False, ragged=True), reps=5, warm=1)
         rows = B * R
         flops = rows * steps * (mf_dec + mf_adp + mf_head) * 1e6          # the reference-equivalent work (no table)
@@ -359,6 +365,7 @@ def stages(dev, cfg, D, D_dev, a):
         floor_exec = max(flops_exec / (F32_MFMA_PEAK_TFLOPS * 1e12), wbytes / (HBM_PEAK_GBS * 1e9))
         gen[f"B{B}_beam{R}"] = {
             "generate_ms": t * 1e3, "encoder_ms": t_enc * 1e3, "decode_ms": (t - t_enc) * 1e3, "queries_per_s": B / t,
+            "kernel_launches_per_call": int(launches),
             "decode_gflop_without_table": flops / 1e9, "decode_weight_gb_streamed": wbytes / 1e9,
             "decode_floor_ms": floor * 1e3, "floor_bound": "mfma" if flops / (F32_MFMA_PEAK_TFLOPS * 1e12) >= wbytes / (HBM_PEAK_GBS * 1e9) else "hbm",
             "frac_of_floor": floor / (t - t_enc), "decode_tflops": flops / (t - t_enc) / 1e12,
@@ -599,6 +606,7 @@ def stages_summary(st):
             "B64_beam10_decode_ms": g["B64_beam10"]["decode_ms"],
             "B64_beam10_frac_of_floor_executed": g["B64_beam10"]["frac_of_floor_executed"],
             "B1_beam100_decode_ms": g["B1_beam100"]["decode_ms"],
+            "B64_beam10_launches": g["B64_beam10"]["kernel_launches_per_call"],
             "bf16_c2_qps": st["bf16_mode_c2_step"]["queries_per_s"],
             "bf16_B64_beam30_generate_ms": st["bf16_mode_generate_B64_beam30"]["generate_ms"],
             "sim_B1_ms": sim["B1"]["ms"], "sim_B32_ms": sim["B32"]["ms"],

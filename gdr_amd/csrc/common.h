@@ -19,8 +19,11 @@ void set_error(const char* fmt, ...);
     }                                           \
   } while (0)
 
+void count_launch();
+// every kernel launch of the library passes here: a relaxed process-wide count (gdr_launch_count: the bench reports launches per call)
 #define GDR_CHECK_LAUNCH(what)                                                   \
   do {                                                                           \
+    gdr::count_launch();                                                         \
     hipError_t e__ = hipGetLastError();                                          \
     if (e__ != hipSuccess) {                                                     \
       gdr::set_error("%s: %s", what, hipGetErrorString(e__));                    \

@@ -1,3 +1,5 @@
+#include <atomic>
+
 #include "common.h"
 
 #include <mutex>
@@ -115,6 +117,11 @@ extern "C" int gdr_prof_collect(int64_t* launches, double* total_ms, double* tot
   return rc;
 }
 
+namespace gdr {
+static std::atomic<int64_t> g_launches{0};
+void count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+}  // namespace gdr
+extern "C" int64_t gdr_launch_count(void) { return gdr::g_launches.load(std::memory_order_relaxed); }
 extern "C" const char* gdr_last_error(void) { return gdr::g_err; }
 // 2: gdr_t5_generate takes a GdrPrefixTable; GdrTrie carries V
 // 3: gdr_rerank_topk takes a shard range, flags and a workspace; gdr_rerank_topk_bf16, gdr_cluster_candidates added

@@ -38,6 +38,9 @@ extern "C" {
 
 const char* gdr_last_error(void);
 int gdr_abi_version(void);
+/* Kernel launches this library has enqueued in this process so far (every entry point, every stream): a monitoring counter —
+ * bench.py reports launches per generate() call from it. */
+int64_t gdr_launch_count(void);
 
 /* Opt-in launch profiler used by bench.py for the roofline line: while enabled, every launch of the dense
  * kernels is bracketed by a hipEvent pair recorded on the stream it is launched on.  Process-global, not

@@ -58,7 +58,7 @@ def test_bench_line_contract_fp32():
     assert len(ss) <= 16 and all(isinstance(v, (int, float)) and v > 0 for v in ss.values()), ss
     for key in ("c3_B64_beam10_qps", "B64_beam10_decode_ms", "B64_beam10_frac_of_floor_executed", "B1_beam100_decode_ms",
                 "c3_best_sustained_qps", "bf16_c2_qps", "bf16_B64_beam30_generate_ms", "sim_B32_ms", "sim_B32_frac_of_hbm_peak",
-                "doc_tower_frac_of_f32_mfma_peak", "c2_prefilter_qps", "sim_B32_prefilter_ms", "sim_B1_prefilter_ms"):
+                "doc_tower_frac_of_f32_mfma_peak", "c2_prefilter_qps", "sim_B32_prefilter_ms", "sim_B1_prefilter_ms", "B64_beam10_launches"):
         assert key in ss, key
     pre = det["stages"]["c2_step_bf16_prefilter"]      # the same step through the bf16 pre-filter: same fp32 top-k, held to the oracle
     assert pre["rows_violating_tie_rule"] == 0 and pre["flagged_rows"] == 0 and pre["recall"] == rec["gpu"] and pre["queries_per_s"] > 0
