@@ -48,6 +48,20 @@ assert E(l.gdr_linear_bf16(FAKE, 4, FAKE, 8, FAKE, 8, 4, 8, 8, 0, None, None, 0,
 assert E(l.gdr_sim_topk(None, 4, None, 100, 768, 10, 0, None, None, None, 0, None, 0, None))
 assert E(l.gdr_sim_topk(FAKE, 4, FAKE, 100, 768, 200, 0, FAKE, FAKE, None, 0, FAKE, 1 << 20, None))  # k > N
 assert E(l.gdr_sim_topk_bf16(FAKE, 4, FAKE, 100, 770, 10, 0, FAKE, FAKE, None, 0, FAKE, 1 << 20, None))
+# the bf16 pre-filter (r05): sizes, and every refusal before a launch
+assert l.gdr_sim_topk_prefilter_workspace_bytes(512, 320000, 768, 100) > l.gdr_sim_topk_workspace_bytes(512, 320000, 768, 100, 0)
+assert l.gdr_sim_topk_prefilter_workspace_bytes(0, 10, 768, 1) == 0
+pw = l.gdr_sim_topk_prefilter_workspace_bytes(4, 1000, 768, 10)
+assert E(l.gdr_sim_topk_prefilter(None, 4, None, None, 1.0, 1000, 768, 10, 0, None, None, None, None, 0, None))
+assert E(l.gdr_sim_topk_prefilter(FAKE, 4, FAKE, FAKE, 1.0, 1000, 770, 10, 0, FAKE, FAKE, None, FAKE, pw, None))       # d % 8
+assert E(l.gdr_sim_topk_prefilter(FAKE, 4, FAKE, FAKE, 1.0, 1000, 768, 2000, 0, FAKE, FAKE, None, FAKE, pw, None))     # k > N
+assert E(l.gdr_sim_topk_prefilter(FAKE, 4, FAKE, FAKE, 0.0, 1000, 768, 10, 0, FAKE, FAKE, None, FAKE, pw, None))       # dnorm_max
+assert E(l.gdr_sim_topk_prefilter(FAKE, 4, FAKE, FAKE, float("inf"), 1000, 768, 10, 0, FAKE, FAKE, None, FAKE, pw, None))
+assert E(l.gdr_sim_topk_prefilter(FAKE, 4, FAKE, FAKE, 1.0, 1000, 768, 10, 0, FAKE, FAKE, None, FAKE, 64, None))        # ENOSPC
+assert E(l.gdr_sim_topk_prefilter(FAKE, 4, FAKE, FAKE, 1.0, 1000, 768, 10, 0, FAKE, FAKE, None, FAKE, pw, None))        # no GPU: EHIP
+assert E(l.gdr_row_norm2_max(None, 10, 768, None, None))
+assert E(l.gdr_row_norm2_max(FAKE, 10, 770, FAKE, None))
+assert l.gdr_launch_count() >= 0
 assert E(l.gdr_cast_f32_bf16(None, None, 8, None))
 assert E(l.gdr_topk_merge(None, None, 2, 2, 2, None, None, None))
 assert E(l.gdr_topk_pack(None, None, None, 2, 2, None, None))
