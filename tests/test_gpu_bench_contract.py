@@ -60,6 +60,8 @@ def test_bench_line_contract_fp32():
                 "c3_best_sustained_qps", "bf16_c2_qps", "bf16_B64_beam30_generate_ms", "sim_B32_ms", "sim_B32_frac_of_hbm_peak",
                 "doc_tower_frac_of_f32_mfma_peak", "c2_prefilter_qps", "sim_B32_prefilter_ms", "sim_B1_prefilter_ms", "B64_beam10_launches"):
         assert key in ss, key
+    wp = j["with_bf16_prefilter"]                     # reported beside the headline, never as `value`
+    assert wp["value"] > 0 and wp["rows_violating_tie_rule"] == 0 and wp["recall"] == rec["gpu"]
     pre = det["stages"]["c2_step_bf16_prefilter"]      # the same step through the bf16 pre-filter: same fp32 top-k, held to the oracle
     assert pre["rows_violating_tie_rule"] == 0 and pre["flagged_rows"] == 0 and pre["recall"] == rec["gpu"] and pre["queries_per_s"] > 0
     assert os.path.exists(os.path.join(ROOT, "bench_stages.json"))
