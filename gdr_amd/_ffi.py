@@ -106,6 +106,7 @@ SIGNATURES = {
     "gdr_sim_topk": (_i, [_vp, _i, _vp, _i64, _i, _i, C.c_int32, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "gdr_sim_topk_bf16": (_i, [_vp, _i, _vp, _i64, _i, _i, C.c_int32, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "gdr_launch_count": (C.c_int64, []),
+    "gdr_prof_gate": (None, [_i]),
     "gdr_sim_topk_prefilter_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
     "gdr_sim_topk_prefilter": (_i, [_vp, _i, _vp, _vp, C.c_float, _i64, _i, _i, C.c_int32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gdr_row_norm2_max": (_i, [_vp, _i64, _i, _vp, _vp]),

@@ -46,6 +46,7 @@ int ensure_dyn_lds(const void* kernel, int bytes, const char* what) {
 // ---------------------------------------------------------------------------------------- profiler
 struct ProfState {
   bool on = false;
+  bool gate = true;  // gdr_prof_gate: while false the enabled profiler records nothing (sampling by step)
   int cap = 0, used = 0;
   hipEvent_t* start = nullptr;
   hipEvent_t* stop = nullptr;
@@ -55,7 +56,7 @@ struct ProfState {
 static ProfState g_prof;
 
 ProfScope::ProfScope(int c, double w, hipStream_t s) : slot(-1), stream(s) {
-  if (!g_prof.on || g_prof.used >= g_prof.cap) return;
+  if (!g_prof.on || !g_prof.gate || g_prof.used >= g_prof.cap) return;
   slot = g_prof.used++;
   g_prof.cls[slot] = c;
   g_prof.work[slot] = w;
@@ -65,6 +66,8 @@ ProfScope::~ProfScope() {
   if (slot >= 0) (void)hipEventRecord(g_prof.stop[slot], stream);
 }
 }  // namespace gdr
+
+extern "C" void gdr_prof_gate(int on) { gdr::g_prof.gate = on != 0; }
 
 extern "C" int gdr_prof_enable(int max_events) {
   using namespace gdr;

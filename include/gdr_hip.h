@@ -49,6 +49,10 @@ int64_t gdr_launch_count(void);
  * 2 sim filter GEMM} with {launch count, total ms, total flops}, and disables the profiler again. */
 int gdr_prof_enable(int max_events);
 int gdr_prof_collect(int64_t* launches, double* total_ms, double* total_work);
+/* Sampling: while the gate is 0 an enabled profiler records nothing (and costs nothing).  Two hipEventRecord packets per launch are
+ * not free — around every dense launch of the C2 step they took 2.4 % of its throughput (28.69 k against 28.02 k q/s, r05) —, so
+ * bench.py opens the gate for every 4th step of its timed region only.  The gate is open after gdr_prof_enable. */
+void gdr_prof_gate(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense linear:  C[M,N] = epilogue(A[M,K] · W[N,K]^T)      (nn.Linear layout, both K-contiguous)
