@@ -257,7 +257,9 @@ class DenseModel:
     forward = __call__
 
     def search(self, q_reps, p_reps, k):
-        """compute_similarity + topk(k) fused (never writes the score matrix). Returns (values, int64 indices)."""
+        """compute_similarity + topk(k) fused (never writes the score matrix). Returns (values, int64 indices).
+        p_reps: the passage embeddings [N,d] (fp32, or bf16 = the C5 precision mode), or an ops.PrefilteredCorpus built from them once
+        (the same fp32 top-k through the bf16 pre-filter, gdr_sim_topk_prefilter)."""
         if self._ws is None:
             self._ws = ops.Workspace(q_reps.device)
         v, i = ops.sim_topk(q_reps.contiguous(), p_reps, k, workspace=self._ws, exact_on_overflow=True)
