@@ -44,6 +44,8 @@ def test_bench_line_contract_fp32():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1 and len(r["kernel"]) <= 120
     for key in ("traffic", "traffic_source", "launches", "avg_launch_ms", "algorithmic_gflop_per_launch", "share_of_step"):
         assert key in r, key
+    # the event pairs are recorded around every dense launch of every 4th timed step (here: step 0 of 2): 48 linears of one ragged pass
+    assert r["timed_steps"] == 1 and r["launches"] == 48 and 0 < r["share_of_step"] < 1
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and 0 < len(c["sample"]) <= 160
     assert j["value"] > 0 and abs(j["value"] - 64 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
@@ -93,7 +95,8 @@ def test_bench_line_contract_fp32():
 
 
 def test_bench_padded_encoder_form_gives_the_same_recall():
-    a, b = _run("--encoder", "padded", "--no-stages"), _run("--no-stages")
+    a, b = _run("--encoder", "padded", "--no-stages", "--prof-every", "1"), _run("--no-stages")
+    assert a["roofline"]["timed_steps"] == 2 and a["roofline"]["launches"] == 96          # --prof-every 1: every step carries the events
     assert a["config"]["encoder_rows"] == "padded" and b["config"]["encoder_rows"] == "ragged"
     assert a["recall"] == b["recall"] and a["stages_summary"] is None
 
