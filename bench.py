@@ -62,20 +62,42 @@ def sig(x, n=5):
     return x
 
 
+TAIL_BUDGET = 7600               # both lines together must fit the driver's 8 KB stdout tail: then the tail starts at the '#'
+
+
+def compact(x, drop=("note", "sample", "cpu_model", "recall_rule", "config_note", "roofline_note", "roofline_sampling")):
+    """The stdout form of the detail object: prose keys dropped (they stay in bench_stages.json), floats to 4 digits."""
+    if isinstance(x, dict):
+        return {k: compact(v, drop) for k, v in x.items() if not (k in drop or k.endswith("_note"))}
+    if isinstance(x, (list, tuple)):
+        return [compact(v, drop) for v in x]
+    return sig(x, 4) if isinstance(x, float) else x
+
+
 def emit(result, detail=None):
-    """Rank 0's output: the full detail object on a `#stages` line (and in bench_stages.json next to this script), then THE one
-    JSON line — headline, roofline, cpu_baseline, recall / parity and a dozen stage scalars — which must stay under LINE_LIMIT."""
-    if detail:
-        text = json.dumps(sig(detail))
-        try:
-            with open(os.path.join(REPO, "bench_stages.json"), "w") as f:
-                f.write(text + "\n")
-        except OSError:
-            pass
-        print("#stages " + text)
+    """Rank 0's output: the detail object on a `#stages` line (in full, with its prose, in bench_stages.json next to this script), then
+    THE one JSON line — headline, roofline, cpu_baseline, recall / parity and a dozen-odd stage scalars — which must stay under
+    LINE_LIMIT.  The two lines together stay under TAIL_BUDGET: the driver keeps the last 8 KB of stdout, and a tail that starts inside
+    the `#stages` line could begin with a `{` of its own."""
     line = json.dumps(sig(result))
     if len(line) > LINE_LIMIT:
         raise SystemExit(f"bench: the JSON line is {len(line)} bytes (> {LINE_LIMIT}): move detail to the #stages line")
+    if detail:
+        try:
+            with open(os.path.join(REPO, "bench_stages.json"), "w") as f:
+                f.write(json.dumps(sig(detail)) + "\n")
+        except OSError:
+            pass
+        small = compact(detail)
+        text = json.dumps(small)
+        # still too long: drop the least consulted stage objects one by one (they remain in the file)
+        for key in ("rerank", "prefix_table", "generate_trie_constrained", "c3_two_stage_B512", "kernels", "doc_tower_bert_base_L128"):
+            if len(text) + len(line) + 10 <= TAIL_BUDGET:
+                break
+            (small.get("stages") or {}).pop(key, None)
+            small.pop(key, None)
+            text = json.dumps(small)
+        print("#stages " + text)
     print(line)
     sys.stdout.flush()
 
