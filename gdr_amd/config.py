@@ -54,7 +54,11 @@ class GDRConfig:
 
     @staticmethod
     def from_args(args):
-        """From a reference-style argparse namespace (main.py:422-442 sizes by --model_info)."""
+        """From a reference-style argparse namespace (main.py:422-442 sizes by --model_info).  Raises SystemExit on a
+        model variant the kernels do not implement (`unsupported_variant`) — never a silently different model."""
+        why = unsupported_variant(args)
+        if why:
+            raise SystemExit("gdr_amd: " + why)
         V = args.output_vocab_size
         L = args.max_output_length
         return GDRConfig(d_model=args.d_model, d_kv=getattr(args, "d_kv", 64), d_ff=args.d_ff,
@@ -63,3 +67,36 @@ class GDRConfig:
                          output_vocab_size=V, max_output_length=L,
                          decode_vocab_size=V * L + 2,
                          adaptor_layer_num=args.adaptor_layer_num)
+
+
+# Reference model variants selected by flags that main.py forwards into T5Config (main_models.py:748-780) and that change
+# the arithmetic of the decode branch (modeling_t5.py:1578-1640) or of the validation step (main_models.py:1350-1397).
+# The kernels implement exactly ONE of them — the shipped infer.sh / train.sh setting.  Anything else must fail loudly:
+# (flag, the value the kernels implement, what the reference would compute instead)
+_ONLY = [
+    ("adaptor_decode", 1, "without the adaptor the head is the plain lm_head (modeling_t5.py:1640-1644)"),
+    ("adaptor_efficient", 1, "adaptor_efficient=0 runs the per-position adaptor of modeling_t5.py:1578-1600"),
+    ("decode_embedding", 2, "decode_embedding 0/1 decodes over the T5 vocabulary / a shared docid table "
+                            "(main_models.py:1357-1374, modeling_t5.py:1266-1272)"),
+    ("hierarchic_decode", 0, "hierarchic_decode=1 shares one V-column head over all positions (main_models.py:741,554)"),
+    ("multiple_decoder", 0, "multiple_decoder=1 decodes with decoder_num separate decoders (main_models.py:1376-1379)"),
+    ("denoising", 0, "denoising=1 changes the decoder inputs (main_models.py:932, modeling_t5.py)"),
+    ("tie_decode_embedding", 1, "tie_decode_embedding=0 unties lm_head from decode_embeddings (modeling_t5.py:1266-1272)"),
+    ("softmax", 0, "softmax=1 builds a decoder-less classifier (main_models.py:750,822; validation asserts it off, :1350)"),
+    ("gen_method", "greedy", "only gen_method='greedy' (= the beam search of main.py:169-187) is implemented; the "
+                             "validation step asserts it (main_models.py:1350)"),
+    ("position", 1, "position=0 uses a 12-column position-free docid head (main_models.py:740-745)"),
+]
+
+
+def unsupported_variant(args):
+    """None when `args` selects the model variant the HIP path implements, else one sentence naming the first flag that
+    does not (reference: main_models.py:748-780 forwards these into T5Config; modeling_t5.py:1578-1640 branches on them)."""
+    for name, only, what in _ONLY:
+        if hasattr(args, name) and getattr(args, name) != only:
+            return (f"--{name} {getattr(args, name)!r} selects a reference model variant this build does not implement "
+                    f"(implemented: {only!r}; {what})")
+    if getattr(args, "model_info", "base") in ("3b", "11b"):
+        return (f"--model_info {args.model_info}: the reference sets no sizes for 3b / 11b (main.py:422-442 covers small / base / "
+                "large only, so args.d_kv is undefined at main_models.py:757); refusing to run a base-sized model under that name")
+    return None

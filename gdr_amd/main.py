@@ -33,7 +33,7 @@ if __package__ in (None, ""):
     __package__ = "gdr_amd"
 
 from . import _ffi, codec, launch, synth        # noqa: E402
-from .config import GDRConfig                   # noqa: E402
+from .config import GDRConfig, unsupported_variant   # noqa: E402
 
 # (flag, type, default[, choices]) — names, types and defaults of main.py:262-396
 _FLAGS = [
@@ -336,6 +336,9 @@ def main(argv=None):
         raise SystemExit("gdr_amd implements GDR's inference hot path only; --mode train is out of scope (SURVEY §2.2)")
     if args.mode == "eval":
         args.recall_num = [1, 5, 10, 20, 50, 100]
+        why = unsupported_variant(args)                      # before any rank is started: a variant the kernels lack
+        if why:
+            raise SystemExit("gdr_amd: " + why)
         if args.n_gpu > 1 and not launch.under_launcher():
             # one command, N GPUs: this process (which has not touched a GPU) starts the N ranks as children and relays
             # their output; rank 0 writes the TSVs and prints the metrics

@@ -162,6 +162,28 @@ def test_cli_namespace_matches_reference_parser():
     assert a.trivia == 0 and a.num_return_sequences == 100 and a.d_model == 768
 
 
+@pytest.mark.parametrize("flag,value", [
+    ("adaptor_decode", "0"), ("adaptor_efficient", "0"), ("decode_embedding", "1"), ("decode_embedding", "0"),
+    ("hierarchic_decode", "1"), ("multiple_decoder", "1"), ("denoising", "1"), ("tie_decode_embedding", "0"),
+    ("softmax", "1"), ("gen_method", "top_k"), ("position", "0"), ("model_info", "3b"), ("model_info", "11b")])
+def test_reference_model_variants_the_kernels_do_not_implement_fail_loudly(flag, value):
+    """main.py forwards these flags into T5Config (main_models.py:748-780) and modeling_t5.py:1578-1640 /
+    main_models.py:1350-1397 branch on them; the HIP path implements the shipped setting only, so any other value must stop
+    the run before a model is built — through GDRConfig.from_args AND through the `--mode eval` entry point."""
+    from gdr_amd import main as gmain
+    from gdr_amd.config import GDRConfig, unsupported_variant
+    a = gmain.parsers_parser(["--mode", "eval", "--" + flag, value])
+    assert flag in unsupported_variant(a)
+    with pytest.raises(SystemExit) as e:
+        GDRConfig.from_args(a)
+    assert "--" + flag in str(e.value)
+    with pytest.raises(SystemExit) as e:                     # the entry point stops before touching a GPU or a file
+        gmain.main(["--mode", "eval", "--" + flag, value])
+    assert "--" + flag in str(e.value)
+    # the shipped settings pass
+    assert unsupported_variant(gmain.parsers_parser(["--mode", "eval"])) is None
+
+
 def _gloo_worker(rank, world, port, tmp):
     import os
     import numpy as np
