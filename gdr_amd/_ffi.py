@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDR_HIP_LIB") or os.path.join(_HERE, "libgdr_hip.so")   # override: A/B builds in the lab
 
 GDR_OK, GDR_EINVAL, GDR_ENOSPC, GDR_EHIP = 0, -1, -2, -3
-ABI_VERSION = 7                  # what this binding was written against (gdr_abi_version(), csrc/common.hip)
+ABI_VERSION = 8                  # what this binding was written against (gdr_abi_version(), csrc/common.hip)
 RERANK_POSITIONS = 1
 SIM_EXHAUSTIVE = 1
 SIM_NO_STREAM = 2
@@ -92,6 +92,7 @@ SIGNATURES = {
     "gdr_prof_collect": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gdr_linear_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "gdr_linear_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    "gdr_linear_bf16_tile_form": (_i, [_i64, _i, _i, _i]),
     "gdr_linear_f32_splitk": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "gdr_l2_normalize": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
     "gdr_t5_layer_norm": (_i, [_vp, _vp, _vp, _i64, _i, _f, _vp]),

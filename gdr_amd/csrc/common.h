@@ -129,6 +129,7 @@ int launch_linear_f32_small(const float* A, int64_t lda, const float* W, int64_t
 int launch_linear_bf16_headdot(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, const int64_t* m_dev, int N, int K,
                                const float* h, int64_t ldh, const int32_t* rows_map, const float* E, int dot_d, float scale,
                                float* partial, hipStream_t stream);
+int linear_bf16_tile_form(int64_t M, int N, int K, int has_residual, int out_bf16);
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, int out_bf16, hipStream_t stream, const int64_t* m_dev = nullptr);

@@ -135,4 +135,4 @@ extern "C" const char* gdr_last_error(void) { return gdr::g_err; }
 //    process-wide word and every stream-K launch enqueued while it is raised fails with GDR_EHIP); gdr_t5_layer_norm (a2 as an
 //    operator of its own); gdr_t5_generate_last_done_step
 // 7: gdr_sim_topk_prefilter (+ _workspace_bytes), gdr_row_norm2_max: the fp32 top-k through a bf16 pre-filter
-extern "C" int gdr_abi_version(void) { return 7; }
+extern "C" int gdr_abi_version(void) { return 8; }

@@ -599,42 +599,42 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
 #undef WAIT_3HALVES
 #undef BAR
 
-// 0: the 128-row forms; 1: 256 x 256 tiles; 2: 256 x 192 tiles.  A cost model in microseconds, fitted to one sweep of the three
-// forms forced over M = 4 096 .. 20 480 x the six call shapes (tools/exp_bf16_linear.py on builds with -DGDR_LAB_BF16_FORCE=0/1/2,
-// profiles/r05_bf16_tile_forms.txt); nk = K / 64:
-//   128 x 128 form (up to 4 workgroups per CU = 1 024 slots):  occ(T) x (17 + 1.6 nk),  occ = T / 1024 from one round on, else
-//                                                              0.35 + 0.65 T / 1024 (a sparse round's tiles run faster)
-//   256-row tiles of width w (one per CU):                     ceil(T / 256) x (fix_w + 1.49 nk w / 256),  fix = 12.1 / 11.5
-//   every form:                                                at least bytes / 3.5 TB/s (operands + output + residual)
-// It picks the measured-fastest form in 26 of the sweep's 30 cases and is within 5 % of it in the rest.
-// (lab forcing: -DGDR_LAB_BF16_FORCE=0/1/2 builds a library that always answers 0 / 1 / 2 where the shape allows)
+// 0: the 128-row forms; 1: 256 x 256 tiles; 2: 256 x 192 tiles.
+// WHETHER a 256-row tile runs is a hard gate measured IN SITU: only the deep contractions (K >= 2048) at >= 8 192 rows keep it.  Alone and
+// replayed back to back the wide K = 768 linears gain 5-15 % on it, inside the encoder / decode chains they LOSE (bf16 C2 step 117.6 k ->
+// 112.3 k q/s, C5 10 410 -> 10 328 with every shape routed by a cost model against the 128-row form): a 512-thread workgroup that owns a
+// CU's whole LDS shuts out the other chain's kernels, and between other launches its operands are no longer L2 / MALL-hot as in a replay.
+// WHICH width is a cost model in microseconds fitted to one sweep of the forms forced over M = 4 096 .. 20 480 x the six call shapes
+// (tools/exp_bf16_linear.py on builds with -DGDR_LAB_BF16_FORCE=1/2, profiles/r05_bf16_tile_forms.txt); nk = K / 64:
+//   256-row tiles of width w (one per CU):   ceil(T / 256) x (fix_w + 1.49 nk w / 256),  fix = 12.1 (w = 256) / 11.5 (w = 192)
+//   either width:                            at least bytes / 3.5 TB/s (operands + output + residual)
+// (lab forcing: -DGDR_LAB_BF16_FORCE=0/1/2 builds a library that always answers 0 / 1 / 2 where the launcher's preconditions allow)
 static int pick_tile256(int64_t M, int N, int K, int has_residual, int out_bf16) {
 #ifdef GDR_LAB_BF16_FORCE
   return GDR_LAB_BF16_FORCE;
 #else
+  if (K < 2048 || M < 8192) return 0;
   const double nk = K / 64.0;
   const double bytes = 2.0 * M * K + 2.0 * N * K + (out_bf16 ? 2.0 : 4.0) * M * N + (has_residual ? 4.0 * M * N : 0.0);
   const double floor_us = bytes / 3.5e6;
-  const double t128n = (double)((M + 127) / 128) * ((N + 127) / 128);
-  const double occ = t128n >= 1024.0 ? t128n / 1024.0 : 0.35 + 0.65 * t128n / 1024.0;
-  double t128 = occ * (17.0 + 1.6 * nk);
-  t128 = t128 > floor_us ? t128 : floor_us;
   const int64_t pm = (M + 255) / 256;
   auto est = [&](int bn, double fix) {
     const int64_t tiles = pm * ((N + bn - 1) / bn);
     const double t = (double)((tiles + 255) / 256) * (fix + 1.49 * nk * bn / 256.0);
     return t > floor_us ? t : floor_us;
   };
-  const double t256 = est(256, 12.1), t192 = est(192, 11.5);
-  // IN SITU only the deep contractions keep the 256-row tile: alone and replayed back to back (the sweep) the wide K = 768 linears
-  // gain 5-15 % on it, inside the encoder / decode chains they LOSE (bf16 C2 step 117.6 k -> 112.3 k q/s, C5 10 410 -> 10 328 with
-  // every shape routed by the model): a 512-thread workgroup that owns a CU's whole LDS shuts out the other chain's kernels, and
-  // between other launches its operands are no longer L2 / MALL-hot as they are in a replay.  So: K >= 2048 at >= 8 192 rows, the
-  // width by the model.
-  (void)t128;
-  if (K < 2048 || M < 8192) return 0;
-  return t256 < t192 ? 1 : 2;
+  return est(256, 12.1) < est(192, 11.5) ? 1 : 2;
 #endif
+}
+
+// The form launch_linear_bf16_glds gives an aligned launch (gdr_linear_bf16_tile_form): must mirror the branches below.
+int linear_bf16_tile_form(int64_t M, int N, int K, int has_residual, int out_bf16) {
+  if (K % 64 != 0) return 0;
+  if (K % 128 == 0 && N % 4 == 0) {
+    const int sel = pick_tile256(M, N, K, has_residual, out_bf16);
+    if (sel) return sel == 1 ? 256 : 192;
+  }
+  return ((M + 127) / 128) * (int64_t)((N + 127) / 128) < 512 ? 64 : 128;
 }
 
 // Returns 1 if the shape is not served here (caller falls back to the generic core), 0 on launch, < 0 on error.
@@ -657,9 +657,9 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
   }
   // The 256-row tile (gemm_nt_bf16_tile256_kernel, 8-phase schedule, one workgroup per CU), 256 or 192 columns wide: twice the flops
   // per operand byte of the 128^2 kernel, but every CU reaches its prologue / epilogue alone, so it pays where the K loop is long or
-  // where its tile count fills whole rounds of 256 CUs.  The choice is a cost estimate in K-tile units per CU:
-  //   rounds x (K-tiles x width factor + fixed prologue / epilogue cost)      against the 128^2 form's measured ~0.33 of peak.
-  if (M >= 4096 && K % 128 == 0 && N % 4 == 0 && (ldc & 3) == 0 && (!has_residual || (ldr & 3) == 0)) {
+  // where its tile count fills whole rounds of 256 CUs.  pick_tile256: a hard in-situ gate (K >= 2048, M >= 8 192), then the width by
+  // a fitted cost model.
+  if (K % 128 == 0 && N % 4 == 0 && (ldc & 3) == 0 && (!has_residual || (ldr & 3) == 0)) {
     const int sel = pick_tile256(M, N, K, has_residual, out_bf16);
     if (sel) {
       const int bn = sel == 1 ? 256 : 192;

@@ -503,8 +503,10 @@ namespace gdr {
 // the C2 step — runs on the bf16 MFMA path over a bf16 image of the corpus, and only a few hundred docs per query are scored in
 // fp32.  The result is the top-k of the FP32 scores, exactly, for every input; the bf16 pass only decides which docs get an fp32 score:
 //   * s(doc) = the fp32 score the rescoring computes, s~(doc) = the bf16-operand score (products of bf16 values are exact in fp32,
-//     fp32 accumulate).  With u = 2^-9 (bf16 RNE) and any summation orders:
-//         |s~ - s| <= ||q||·||d||·(2u + u^2 + 2·d·2^-24·1.01) =: eps(q, d) <= eps_q := ||q||·max_doc||d||·(2^-8 + 2^-17 + d·2^-22)
+//     fp32 accumulate).  bf16 keeps 8 significand bits (1 implicit + 7 stored), so round-to-nearest-even has unit roundoff u = 2^-8
+//     (r05 coded 2^-9 — half the true bound; r06 fix, tests/test_gpu_prefilter.py holds a coherent-rounding input that needs it).
+//     For any summation orders:
+//         |s~ - s| <= ||q||·||d||·(2u + u^2 + 2·d·2^-24·1.01) =: eps(q, d) <= eps_q := ||q||·max_doc||d||·(2^-7 + 2^-16 + d·2^-22)
 //   * t~_k = k-th largest s~ over all docs.  The k docs with the largest s~ have s >= t~_k - eps, so T_k (k-th largest s) >= t~_k - eps;
 //     a doc of the true top-k has s >= T_k, hence s~ >= t~_k - 2·eps.  So {s~ >= t~_k - 2 eps_q} contains the true top-k (with every doc
 //     tied at T_k), and the exact select over their fp32 scores (higher score, then lower id — as the fp32 path) is the brute-force result.
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void sim_qprep_kernel(const float* __restrict_
   __syncthreads();
   if (threadIdx.x == 0) {
     const float nq = sqrtf(red[0] + red[1] + red[2] + red[3]) * 1.0001f;  // the norm itself is rounded: a hair of slack
-    const float c = 0.00390625f + 7.62939453125e-6f + (float)d * 2.384185791015625e-7f;  // 2^-8 + 2^-17 + d * 2^-22
+    const float c = 0.0078125f + 1.52587890625e-5f + (float)d * 2.384185791015625e-7f;  // 2^-7 + 2^-16 + d * 2^-22  (u_bf16 = 2^-8)
     eps2[q] = 2.0f * nq * dnorm_max * c * 1.01f;
   }
 }

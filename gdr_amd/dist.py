@@ -66,7 +66,10 @@ class ShardedIndex:
         -> (values [B,A,k], int32 [B,A,k]) — ops.rerank_topk in the per-query block layout;
         wire = (wire_pack(q, beam, offs, ids) -> int32 [B,W], wire_unpack(rows, d, R, stride) -> (q, beam, offs, ids),
         positions_to_ids(pos [B,...], ids [B,stride]) -> int32 ids) — ops.rerank_wire_pack / _unpack / rerank_positions_to_ids."""
+        # D: what local_topk searches (a tensor, or an ops.PrefilteredCorpus around it); rows: the raw tensor for everything
+        # that is not a search (the rerank gathers, shapes)
         self.D, self.lo, self.group = D_shard, int(lo), group
+        self.rows = getattr(D_shard, "D", D_shard) if not isinstance(D_shard, torch.Tensor) else D_shard
         if wire is None:
             from . import ops as _wops
             wire = (_wops.rerank_wire_pack, _wops.rerank_wire_unpack, _wops.rerank_positions_to_ids)
@@ -164,16 +167,16 @@ class ShardedIndex:
         ops.rerank_topk over the whole corpus.  Collectives: ONE all-gather (queries + candidate lists, fixed size), ONE
         all-to-all (per-shard {score, position} lists of B*A rows in the wire form of the brute-force search)."""
         Bl, d = q_local.shape
-        R, stride, hi = beam_scores.shape[1], cand_ids.shape[1], self.lo + self.D.shape[0]
+        R, stride, hi = beam_scores.shape[1], cand_ids.shape[1], self.lo + self.rows.shape[0]
         A = len(alphas)
         if not self.distributed:
-            return self.local_rerank(q_local, self.D, cand_offsets, cand_ids, beam_scores, alphas, k, self.lo, hi, func, False)
+            return self.local_rerank(q_local, self.rows, cand_offsets, cand_ids, beam_scores, alphas, k, self.lo, hi, func, False)
         mine = self.wire_pack(q_local, beam_scores, cand_offsets.view(Bl, R + 1), cand_ids.view(Bl, stride))   # [Bl, W] int32
         allb = torch.empty((self.world * Bl, mine.shape[1]), dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(allb, mine, group=self.group)
         B = self.world * Bl
         q_all, beam_all, offs_all, ids_all = self.wire_unpack(allb, d, R, stride)
-        v, pos = self.local_rerank(q_all, self.D, offs_all, ids_all, beam_all, alphas, k, self.lo, hi, func, True)
+        v, pos = self.local_rerank(q_all, self.rows, offs_all, ids_all, beam_all, alphas, k, self.lo, hi, func, True)
         send = self.pack(v.reshape(B * A, k), pos.reshape(B * A, k), None)          # [B*A, k+1]; block g = rank g's queries
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)

@@ -28,24 +28,47 @@ def free_port():
     return port
 
 
-def descendants(pid):
-    """PIDs of every live descendant of `pid` (children, grandchildren, ...) from /proc/<pid>/stat's parent field."""
-    kids = {}
+def _stat(pid):
+    """(parent pid, start time in clock ticks) of a live process from /proc/<pid>/stat (fields 4 and 22), else None."""
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            rest = f.read().rsplit(")", 1)[1].split()
+        return int(rest[1]), int(rest[19])
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def descendants(pid, with_start=False):
+    """PIDs of every live descendant of `pid` (children, grandchildren, ...) from /proc/<pid>/stat's parent field; with_start:
+    {pid: start time} — a PID alone does not name a process (it is recycled), (pid, start time) does."""
+    kids, started = {}, {}
     for name in os.listdir("/proc"):
         if not name.isdigit():
             continue
-        try:
-            with open(f"/proc/{name}/stat") as f:
-                ppid = int(f.read().rsplit(")", 1)[1].split()[1])
-        except (OSError, ValueError, IndexError):
+        st = _stat(name)
+        if st is None:
             continue
-        kids.setdefault(ppid, []).append(int(name))
+        kids.setdefault(st[0], []).append(int(name))
+        started[int(name)] = st[1]
     out, todo = [], [pid]
     while todo:
         for c in kids.get(todo.pop(), []):
             out.append(c)
             todo.append(c)
-    return out
+    return {c: started[c] for c in out} if with_start else out
+
+
+def kill_if_same(pid, start, sig=signal.SIGKILL):
+    """Signals `pid` only if it is still the process that was collected (same start time): a PID that exited and was handed to an
+    unrelated process during the grace period is left alone.  Returns True if a signal was sent."""
+    st = _stat(pid)
+    if st is None or st[1] != start:
+        return False
+    try:
+        os.kill(pid, sig)
+        return True
+    except (ProcessLookupError, PermissionError):
+        return False
 
 
 def spawn_ranks(n, argv, script=None, module=None, env=None, relay=True, timeout=None):
@@ -73,21 +96,26 @@ def spawn_ranks(n, argv, script=None, module=None, env=None, relay=True, timeout
     lines = []
 
     def stop(grace=5.0):
-        """SIGTERM to the launcher (torch.distributed.run forwards it to its workers), then SIGKILL to every process of its tree
-        (collected before and after the grace period: a rank re-parented to init is no longer findable through its parent)."""
-        tree = set(descendants(proc.pid))
+        """SIGTERM to the launcher (torch.distributed.run forwards it to its workers), then SIGKILL to (1) the launcher's own process
+        group — it leads a session of its own (start_new_session), so the group holds the launcher and whatever it started without
+        a new session — and (2) every process of its tree, each identified by (pid, start time) and collected before and during the
+        grace period (a rank re-parented to init is no longer findable through its parent; a PID recycled meanwhile is not touched)."""
+        tree = descendants(proc.pid, with_start=True)
         try:
             proc.terminate()
             t_end = time.monotonic() + grace
             while proc.poll() is None and time.monotonic() < t_end:
                 time.sleep(0.05)
-                tree.update(descendants(proc.pid))
+                for pid, st in descendants(proc.pid, with_start=True).items():
+                    tree.setdefault(pid, st)
         finally:
-            for pid in sorted(tree | {proc.pid}):
+            if proc.poll() is None:                      # still ours: its pgid == its pid (session leader), not a recycled one
                 try:
-                    os.kill(pid, signal.SIGKILL)
+                    os.killpg(proc.pid, signal.SIGKILL)
                 except (ProcessLookupError, PermissionError):
                     pass
+            for pid, st in sorted(tree.items()):
+                kill_if_same(pid, st)
 
     # the read loop below only ends when the ranks close their stdout: a watchdog enforces `timeout` on a hung launch
     watchdog = threading.Timer(timeout, stop) if timeout else None

@@ -132,7 +132,8 @@ def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_o
     prefilter = isinstance(D, PrefilteredCorpus)
     if prefilter:
         P, D = D, D.D
-        if Q.shape[0] < PREFILTER_MIN_BATCH or D.shape[1] % 8 or D.shape[1] > 1024 or (flags & _ffi.SIM_EXHAUSTIVE):
+        if (Q.shape[0] < PREFILTER_MIN_BATCH or D.shape[1] % 8 or D.shape[1] > 1024 or (flags & _ffi.SIM_EXHAUSTIVE)
+                or not P.dnorm_max > 0.0):                               # an all-zero corpus has no band: the fp32 path serves it
             prefilter = False
     _need_cuda(Q, D)
     if D.dtype == torch.bfloat16:                                    # bf16 corpus: queries are cast on the device
@@ -163,16 +164,26 @@ def sim_topk(Q, D, k, idx_offset=0, workspace=None, return_status=False, exact_o
 class PrefilteredCorpus:
     """An fp32 corpus [N,d] with what gdr_sim_topk_prefilter needs beside it: its bf16 image (RNE, +50 % memory) and the largest
     row norm, both made once on the device.  ops.sim_topk(Q, PrefilteredCorpus(D), k) returns the top-k of the FP32 scores (the
-    bf16 pass only decides which few hundred docs per query get one: include/gdr_hip.h)."""
+    bf16 pass only decides which few hundred docs per query get one: include/gdr_hip.h).
+    The image and the norm bound are SNAPSHOTS of D: after any in-place update of D (an index refresh) call refresh() before the
+    next search — a stale image can drop docs from the band, a stale norm bound can make the band too narrow.  `.D` is the raw
+    fp32 tensor for everything that is not a search (rerank, gathers).  An all-zero corpus (dnorm_max = 0) is served by the
+    fp32 path."""
 
     def __init__(self, D):
         _need_cuda(D)
         self.D = _f32c(D)
-        self.D16 = to_bf16(self.D)
-        m = torch.empty(1, dtype=torch.float32, device=D.device)
+        self.shape, self.dtype, self.device = self.D.shape, self.D.dtype, self.D.device
+        self.D16 = torch.empty(self.D.shape, dtype=torch.bfloat16, device=self.D.device)
+        self.refresh()
+
+    def refresh(self):
+        """Re-derive the bf16 image and the largest row norm from the current contents of D (one sync)."""
+        check(lib().gdr_cast_f32_bf16(ptr(self.D), ptr(self.D16), self.D.numel(), stream_ptr()), "gdr_cast_f32_bf16")
+        m = torch.empty(1, dtype=torch.float32, device=self.D.device)
         check(lib().gdr_row_norm2_max(ptr(self.D), self.D.shape[0], self.D.shape[1], ptr(m), stream_ptr()), "gdr_row_norm2_max")
         self.dnorm_max = float(m.item()) ** 0.5 * (1.0 + 1e-6)       # the squared norm is itself rounded
-        self.shape, self.dtype, self.device = self.D.shape, self.D.dtype, self.D.device
+        return self
 
 
 PREFILTER_MIN_BATCH = 1           # the pre-filter serves every batch size: at B <= 32 its corpus-wide pass is the HBM stream over

@@ -94,6 +94,9 @@ int gdr_linear_f32_splitk(const float* A, int64_t lda, const float* W, int64_t l
  * ldw multiples of 8.  K % 64 == 0 takes the LDS-DMA kernel (gemm_bf16.hip), other K the generic core. */
 int gdr_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                     int K, int epilogue, const float* bias, const float* residual, int64_t ldr, void* stream);
+/* Which tile form gdr_linear_bf16 gives a well-aligned [M,K] x [N,K] launch (host-only, no GPU work; for tests and profiles):
+ * 64 / 128 = the 128-column kernel with 64- / 128-row tiles, 192 / 256 = the 256-row tile of that width, 0 = generic core. */
+int gdr_linear_bf16_tile_form(int64_t M, int N, int K, int epilogue);
 
 /* T5LayerNorm (modeling_t5.py:164-171): y = w * (x / sqrt(mean(x^2) + eps)) per row, fp32 — the norm every T5 block of the
  * path applies, as an operator of its own.  The quotient is the IEEE division's, bit for bit (the kernels divide a row by its
@@ -214,7 +217,7 @@ int gdr_sim_topk_bf16(const void* Q, int B, const void* D, int64_t N, int d, int
 /* The same fp32 result through a bf16 PRE-FILTER (r05; replaces the same call site, dense.py:53-54 + topk as at main_models.py:1625):
  * the corpus-wide pass runs on the bf16 MFMA path over D_bf16 (= gdr_cast_f32_bf16(D), resident beside D), and only the docs whose
  * bf16-operand score lies within 2*eps_q of the k-th largest one are scored in fp32 (from D) and ranked exactly — with
- *     eps_q = ||q|| * dnorm_max * (2^-8 + 2^-17 + d * 2^-22)   >=   |bf16-operand score - fp32 score|   for every doc,
+ *     eps_q = ||q|| * dnorm_max * (2^-7 + 2^-16 + d * 2^-22)   >=   |bf16-operand score - fp32 score|   for every doc,
  * that band provably contains the fp32 top-k including every doc tied at the cut (derivation: csrc/sim_topk.hip), so out_val / out_idx
  * are the top-k of the fp32 scores for every input, ties as in gdr_sim_topk (higher score, then lower id); the values are fp32 dot
  * products of the same operands in another summation order.  dnorm_max: the largest ||D[r]||_2 (sqrt of gdr_row_norm2_max's result).

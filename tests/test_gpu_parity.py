@@ -159,18 +159,27 @@ def test_linear_bf16_tile_heights_give_the_same_bits(dev):
         part = ops.linear_bf16(A2[:small].contiguous(), W2, epilogue=epi, **kw_small)
         assert torch.equal(full[:small], part), f"256-row tiles, epilogue {epi}"
     torch.testing.assert_close(ops.linear_bf16(A2, W2)[-200:].cpu(), a2[-200:].bfloat16().float() @ w2.bfloat16().float().T, rtol=TOL, atol=TOL)
-    # r05: the 256-row tile comes 256 or 192 columns wide and is routed by a cost model (gemm_bf16.hip pick_tile256): every shape of
-    # the C5 / C2 call sites that it sends to either width — incl. N = 2048, whose last 192-column tile is partial, and a row count
-    # with a partial last row panel — must give the bits of the 64-row form, and the last rows must equal the fp32 product
-    for big3, N3 in ((15360, 2304), (15360, 3072), (15360, 2048), (20480, 2304), (12308, 2304), (4100, 3072)):
-        w3 = torch.randn(N3, K, generator=g) * K ** -0.5
-        W3, A3 = w3.to(dev), A[:big3].contiguous() if big3 <= big else torch.cat([A, A[:big3 - big]]).contiguous()
+    # r05/r06: the 256-row tile comes 256 or 192 columns wide; a hard gate (K >= 2048, M >= 8192) decides whether it runs, a cost
+    # model which width (gemm_bf16.hip pick_tile256).  gdr_linear_bf16_tile_form says which form a shape gets, so the test ASSERTS
+    # that each width — incl. N = 2048, whose last 192-column tile is partial, a partial last row panel, and the 128-row form at
+    # K = 768 — is reached, and each must give the bits of the 64-row form; the last rows must equal the fp32 product
+    from gdr_amd._ffi import lib
+    reached = set()
+    for big3, N3, K3, want in ((20480, 768, 3072, 256), (10240, 2048, 2048, 192), (12308, 768, 3072, 192), (9100, 3072, 2048, 256),
+                               (15360, 2304, 768, 128), (4100, 3072, 768, 128)):
+        form = lib().gdr_linear_bf16_tile_form(big3, N3, K3, _ffi.EPI_RELU)
+        assert form == want, (big3, N3, K3, form)
+        reached.add(form)
+        a3, w3 = torch.randn(big3, K3, generator=g), torch.randn(N3, K3, generator=g) * K3 ** -0.5
+        W3, A3 = w3.to(dev), a3.to(dev)
+        assert lib().gdr_linear_bf16_tile_form(small, N3, K3, _ffi.EPI_RELU) in (64, 128)
         full = ops.linear_bf16(A3, W3, epilogue=_ffi.EPI_RELU)
         part = ops.linear_bf16(A3[:small].contiguous(), W3, epilogue=_ffi.EPI_RELU)
-        assert torch.equal(full[:small], part), f"routed tile form at {big3} x {N3}"
-        ref = torch.relu(A3[-130:].cpu().bfloat16().float() @ w3.bfloat16().float().T)
+        assert torch.equal(full[:small], part), f"routed tile form {form} at {big3} x {N3} x {K3}"
+        ref = torch.relu(a3[-130:].bfloat16().float() @ w3.bfloat16().float().T)
         torch.testing.assert_close(full[-130:].cpu(), ref, rtol=TOL, atol=TOL)
         del full, part, W3, A3
+    assert reached == {128, 192, 256}
     base = a[:small].bfloat16().float() @ w.bfloat16().float().T
     torch.testing.assert_close(ops.linear_bf16(A[:small].contiguous(), W).cpu(), base, rtol=TOL, atol=TOL)
     torch.testing.assert_close(ops.linear_bf16(A, W)[-300:].cpu(), a[-300:].bfloat16().float() @ w.bfloat16().float().T, rtol=TOL, atol=TOL)

@@ -137,3 +137,38 @@ def test_latency_mode_bf16_stream_and_prefilter(dev, B):
     order_insensitive_topk_match(fv.cpu().numpy(), fi.cpu().numpy().astype(np.int64), pv.cpu().numpy(), pi.cpu().numpy().astype(np.int64), TOL32)
     ov, oi = retrieval_ref.sim_topk(torch.from_numpy(Q), torch.from_numpy(D), k)
     order_insensitive_topk_match(ov.numpy(), oi.numpy(), pv.cpu().numpy(), pi.cpu().numpy().astype(np.int64), 1e-4)
+
+
+@pytest.mark.parametrize("B", [4, 40])
+def test_prefilter_band_holds_under_coherent_bf16_rounding(dev, B):
+    """r06 (advisor finding on r05): bf16 has an 8-bit significand, so RNE's unit roundoff is 2^-8 and the per-doc bound is
+    ||q||·||d||·(2^-7 + 2^-16 + ...) — r05 coded half of that.  An input whose coordinates all round the SAME way reaches 2/3 of the
+    true bound: q and doc A hold 1 + 2^-8 - 2^-14 on 384 coordinates (bf16 rounds them DOWN to 1), q and doc B hold 1 + 2^-8 + 2^-14
+    on the next 383 (rounded UP to 1 + 2^-7).  fp32: A = 386.96 > B = 386.04; bf16 operands: A = 384.0 < B = 389.0.  With the r05
+    band (2 eps = 4.5) A — the true top-1 — fell outside [389.0 - 4.5, ...] and was dropped with status 0; the band must keep it."""
+    from gdr_amd import ops
+    d, N = 768, 20000
+    lo, hi = np.float32(1 + 2.0 ** -8 - 2.0 ** -14), np.float32(1 + 2.0 ** -8 + 2.0 ** -14)
+    D = (synth.make_corpus(N, d, seed=21) * 0.1).astype(np.float32)
+    ia, ib = 777, 12345
+    D[ia] = 0
+    D[ia, :384] = lo
+    D[ib] = 0
+    D[ib, 384:767] = hi
+    q = np.zeros(d, np.float32)
+    q[:384], q[384:767] = lo, hi
+    Q = np.repeat(q[None], B, 0)
+    Q[1::2] *= np.float32(0.5)                                            # the band scales with ||q||
+    Qd, Dd = torch.from_numpy(Q).to(dev), torch.from_numpy(D).to(dev)
+    s16 = (torch.from_numpy(D[[ia, ib]]).bfloat16().float() @ torch.from_numpy(q).bfloat16().float()).numpy()
+    s32 = D[[ia, ib]].astype(np.float64) @ q.astype(np.float64)
+    assert s32[0] > s32[1] + 0.9 and s16[1] > s16[0] + 4.9, "the construction: fp32 ranks A first, bf16 operands rank B first by 5.0"
+    for k in (1, 2, 10):
+        fv, fi, fs = ops.sim_topk(Qd, Dd, k, return_status=True)
+        pv, pi, ps = ops.sim_topk(Qd, ops.PrefilteredCorpus(Dd), k, return_status=True, exact_on_overflow=False)
+        assert int(fs.sum()) == 0 and int(ps.sum()) == 0
+        assert (fi[:, 0].cpu().numpy() == ia).all() and (pi[:, 0].cpu().numpy() == ia).all(), "the true top-1 (doc A) was filtered out"
+        if k > 1:
+            assert (pi[:, 1].cpu().numpy() == ib).all()
+        order_insensitive_topk_match(fv.cpu().numpy(), fi.cpu().numpy().astype(np.int64), pv.cpu().numpy(),
+                                     pi.cpu().numpy().astype(np.int64), 1e-4)

@@ -24,7 +24,7 @@ def test_header_symbols_all_bound_and_exported():
     l = _ffi.lib()                      # raises if the .so is missing or lacks a symbol
     for name in declared:
         assert hasattr(l, name)
-    assert l.gdr_abi_version() == _ffi.ABI_VERSION == 7
+    assert l.gdr_abi_version() == _ffi.ABI_VERSION == 8
 
 
 def test_missing_library_fails_loudly(monkeypatch):
