@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "layers.h"
+#include "decode_fused.h"
 
 namespace gdr {
 
@@ -1096,7 +1097,7 @@ static const float* w_at(const float* W, size_t elems, bool bf16) {
 
 // ------------------------------------------------------------------------------------------ model workspace
 struct GenWs {
-  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, abf, abf2, img1, img2, c16a, c16b, f16a, f16b, total;
+  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, abf, abf2, img1, img2, c16a, c16b, f16a, f16b, fslab, fslab2, total;
 };
 
 static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
@@ -1133,6 +1134,10 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
   g.c16b = carve(o, 2 * rows * d);                         // producers (a: decoder chain, b: adaptor chain) — the operand of
   g.f16a = carve(o, 2 * rows * ffw);                       // the linear behind them, which then needs no cast launch
   g.f16b = carve(o, 2 * rows * (size_t)w.adaptor_ff);
+  // fused sub-blocks (decode_fused.hip, <= 1 024 rows): the partial slabs of one sub-block, per chain
+  const bool fused = decode_fused_rt((int64_t)rows, (int)d, (int)inner, dm.d_kv) != 0;
+  g.fslab = carve(o, fused ? decode_fused_slab_bytes((int64_t)rows, (int)d, dm.d_ff, dm.num_heads) : 0);
+  g.fslab2 = carve(o, fused ? decode_fused_slab_bytes((int64_t)rows, (int)d, w.adaptor_ff, w.adaptor_nhead) : 0);
   g.total = o;
   return g;
 }
@@ -1205,7 +1210,8 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
   float *dcache = F(g.dcache), *acache = F(g.acache), *crosskv = F(g.crosskv), *xd = F(g.xd), *xa = F(g.xa),
         *nx = F(g.nx), *ctx = F(g.ctx), *qc = F(g.qc), *ff = F(g.ff), *tmp = F(g.tmp), *A = F(g.A), *hl = F(g.hl),
-        *skw = F(g.splitk), *ctx2 = F(g.ctx2), *ff2 = F(g.ff2), *skw2 = F(g.splitk2), *qkv_c = F(g.qkv_c);
+        *skw = F(g.splitk), *ctx2 = F(g.ctx2), *ff2 = F(g.ff2), *skw2 = F(g.splitk2), *qkv_c = F(g.qkv_c), *fslab = F(g.fslab),
+        *fslab2 = F(g.fslab2);
   void *abf = base + g.abf, *abf2 = base + g.abf2;
   Bf16Image img1{nullptr, bf16 ? base + g.img1 : nullptr}, img2{nullptr, bf16 ? base + g.img2 : nullptr};
   Bf16Image c16a{nullptr, bf16 ? base + g.c16a : nullptr}, c16b{nullptr, bf16 ? base + g.c16b : nullptr};
@@ -1307,6 +1313,10 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
                                 2 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
   }
 
+  static const int fused_mask = [] {
+    const char* e = getenv("GDR_DECODE_FUSED");  // A/B knob, bit mask: 1 self-attention, 2 cross-attention, 4 feed-forward sub-block fused
+    return e ? atoi(e) : 7;                      // (decode_fused.hip); 0 = every phase its own launch (the round-5 chain)
+  }();
   static const bool slab_q_on = [] {
     const char* e = getenv("GDR_DECODE_SLAB_Q");  // A/B knob: 0 = reduce the cross-attention q projection in its own launch
     return e ? atoi(e) != 0 : true;
@@ -1428,6 +1438,21 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       const GdrT5DecLayer& ly = w->layers[l];
       float* cache = dcache + l * dlayer;
       float* slot = cache + s * dslab;
+      // fused sub-blocks (decode_fused.hip): <= 1 024 rows, fp32, d_kv = 64 — (row panel, head / d_ff chunk) workgroups write
+      // partial slabs, one reduction launch folds them with the residual and the next norm
+      const int frt = (!bf16 && s + 1 <= 16 && dm.d_ff % 256 == 0) ? decode_fused_rt(rows_s, d, inner, dk) : 0;
+      const bool f_sa = frt && (fused_mask & 1), f_ca = frt && (fused_mask & 2) && R_s > 1, f_ff = frt && (fused_mask & 4);
+      FusedArgs fa{};
+      fa.X = nx, fa.slabs = fslab, fa.M = rows_s, fa.d = d, fa.live = sk1.live, fa.H = H, fa.q_pos0 = s, fa.scale = 1.0f;
+      fa.num_buckets = dm.rel_buckets;
+      if (f_sa) {
+        FusedArgs g1 = fa;
+        g1.W1 = ly.wqkv, g1.w1_seg_stride = inner, g1.w1_slice_rows = 64, g1.W3 = ly.wo, g1.ld3 = inner, g1.n_slices = H;
+        g1.slot = slot, g1.kbase = cache + inner, g1.vbase = cache + 2 * inner, g1.ld_kv = 3 * inner, g1.k_off = inner, g1.v_off = 2 * inner;
+        g1.kv_rows = bb.kv_rows, g1.Lk = s + 1, g1.rel_bias = w->self_rel_bias, g1.lut = lut_uni;
+        GDR_TRY(launch_decode_fused(FUSED_SA, g1, frt, 192, stream));
+        GDR_TRY(launch_slab_reduce_norm(fslab, H, rows_s, d, xd, d, nullptr, xd, d, rms(ly.ln_cross, nx), sk1.live, stream));
+      } else {
       // every later RMS norm rides on the reduction of the residual linear in front of it (dec_linear_norm)
       // (the first block's norm rides on the embedding launch: embed_rmsnorm_kernel)
       GDR_TRY(LIN(nx, d, ly.wqkv, d, slot, 3 * inner, rows_s, 3 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
@@ -1443,7 +1468,20 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       GDR_TRY(launch_attention(at, stream));
       GDR_TRY(dec_linear_norm(bf16, abf, ctx, inner, ly.wo, inner, xd, d, rows_s, nullptr, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, skw,
                               stream, rms(ly.ln_cross, nx), &sk1, &img1, &c16a));
+      }
       // cross attention over the encoder states of the row's query
+      if (f_ca) {
+        FusedArgs g2 = fa;
+        g2.W1 = ly.wq_c, g2.w1_seg_stride = 0, g2.w1_slice_rows = 64, g2.W3 = ly.wo_c, g2.ld3 = inner, g2.n_slices = H;
+        g2.ck = crosskv + l * ckv_layer, g2.cv = crosskv + l * ckv_layer + inner, g2.ld_c = 2 * inner, g2.L = L, g2.R = R_s;
+        g2.key_mask = enc_mask, g2.rel_bias = w->cross_rel_bias, g2.lut = lut_bi;
+        if (s == 0 && ckv_side && hipStreamWaitEvent(stream, lease.ss->ckv[l], 0) != hipSuccess) {
+          set_error("generate: wait for the cross K/V of layer %d failed", l);
+          return GDR_EHIP;
+        }
+        GDR_TRY(launch_decode_fused(FUSED_CA, g2, frt, 64, stream));
+        GDR_TRY(launch_slab_reduce_norm(fslab, H, rows_s, d, xd, d, nullptr, xd, d, rms(ly.ln_ff, nx), sk1.live, stream));
+      } else {
       // the q projection's split-K slabs go to the attention kernel un-reduced (it sums them while it stages the beam rows_s'
       // queries): one dependent launch less per layer and step
       SlabRef qsl{nullptr, 1, 0};
@@ -1476,6 +1514,17 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
       GDR_TRY(launch_attention(ca, stream));
       GDR_TRY(dec_linear_norm(bf16, abf, ctx, inner, ly.wo_c, inner, xd, d, rows_s, nullptr, d, inner, GDR_EPI_RESIDUAL, nullptr, xd, d, skw,
                               stream, rms(ly.ln_ff, nx), &sk1, &img1, &c16a));
+      }
+      const bool last = l + 1 == dm.num_layers;  // the norm behind the block: the next block's first, or final_layer_norm
+      if (f_ff) {
+        FusedArgs g3 = fa;
+        const int n1 = frt == 1 ? 128 : 256;
+        g3.W1 = ly.wi, g3.w1_seg_stride = 0, g3.w1_slice_rows = n1, g3.W3 = ly.wo_ff, g3.ld3 = dm.d_ff, g3.n_slices = dm.d_ff / n1;
+        GDR_TRY(launch_decode_fused(FUSED_FFN, g3, frt, n1, stream));
+        GDR_TRY(launch_slab_reduce_norm(fslab, dm.d_ff / n1, rows_s, d, xd, d, nullptr, xd, d,
+                                        rms(last ? w->final_ln : w->layers[l + 1].ln_self, last ? hl : nx), sk1.live, stream));
+        return GDR_OK;
+      }
       int r16 = bf16 ? dec_linear_out16(abf, nx, d, ly.wi, d, ff, dm.d_ff, rows_s, nullptr, dm.d_ff, d, GDR_EPI_RELU, nullptr, stream, &img1,
                                         &f16a) : 1;
       if (r16 < 0) return r16;
@@ -1483,7 +1532,6 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
           f16a.src = nullptr;
           GDR_TRY(LIN(nx, d, ly.wi, d, ff, dm.d_ff, rows_s, dm.d_ff, d, GDR_EPI_RELU, nullptr, nullptr, 0));
         }
-      const bool last = l + 1 == dm.num_layers;  // the norm behind the block: the next block's first, or final_layer_norm
       GDR_TRY(dec_linear_norm(bf16, abf, ff, dm.d_ff, ly.wo_ff, dm.d_ff, xd, d, rows_s, nullptr, d, dm.d_ff, GDR_EPI_RESIDUAL, nullptr, xd, d,
                               skw, stream, rms(last ? w->final_ln : w->layers[l + 1].ln_self, last ? hl : nx), &sk1, &img1, &f16a));
       return GDR_OK;

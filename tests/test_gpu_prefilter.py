@@ -149,7 +149,9 @@ def test_prefilter_band_holds_under_coherent_bf16_rounding(dev, B):
     from gdr_amd import ops
     d, N = 768, 20000
     lo, hi = np.float32(1 + 2.0 ** -8 - 2.0 ** -14), np.float32(1 + 2.0 ** -8 + 2.0 ** -14)
-    D = (synth.make_corpus(N, d, seed=21) * 0.1).astype(np.float32)
+    # background docs of the SAME norm as A and B (||A|| = 19.7): eps_q scales with max ||d||, so tiny background docs would all fall
+    # inside the band of the sample threshold and overflow the list (status 1 -> the fp32 fallback, which is not what is tested here)
+    D = (synth.make_corpus(N, d, seed=21) * 19.0).astype(np.float32)
     ia, ib = 777, 12345
     D[ia] = 0
     D[ia, :384] = lo
