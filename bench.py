@@ -149,6 +149,7 @@ def parse():
                     help="c3 / c5: queries of the step held against the oracle in stage 1 (beam decode; default 4, 2 above beam 10) "
                          "and stage 2 (rerank; default 64)")
     ap.add_argument("--no-stages", action="store_true", help="skip the stages (other stages of the path, N = 1)")
+    ap.add_argument("--no-c5", action="store_true", help="stages: skip config C5's step (1M x 768 bf16 corpus, beam 30; ~1 min incl. its corpus)")
     ap.add_argument("--sweep", action="store_true",
                     help="stages: also run the two-stage path at 128 / 256 / 1024 / 2048 queries per batch (where the decode chain stops "
                          "being launch-bound); off by default so that the default run stays near 40 s")
@@ -407,6 +408,9 @@ def stages(dev, cfg, D, D_dev, a):
         retr = GDRRetriever(model, D_dev, look, a_r)
         batch = {"source_ids": ids, "source_mask": mask}
         t3 = timed(lambda: retr.validation_step_i(batch), reps=5, warm=2)
+        c3_par = None
+        if B == 64 and not a.no_cpu_baseline and not a.no_parity:   # config C3's step held against the CPU oracle (as --workload c3 does)
+            c3_par = two_stage_parity(retr, batch, mask_np[(B, R)], sd, cfg, look, a_r, D_dev, False, None, nq1=2, nq2=64)
         # ---- stage 2 alone (device cluster lookup + in-cluster rerank, SURVEY §8d: bytes/query = Ncand * 768 * 4)
         st = retr._step_launch(batch)
         dci = retr._device_index()
@@ -442,6 +446,8 @@ def stages(dev, cfg, D, D_dev, a):
             "batch": B, "beams": R, "ms": t3 * 1e3, "queries_per_s": B / t3, "pipelined_depth": depth,
             "pipelined_ms_per_batch": tp * 1e3, "pipelined_queries_per_s": B / tp,
             "generate_ms": t * 1e3, "after_generate_ms": (t3 - t) * 1e3}
+        if c3_par is not None:
+            out[skey]["parity"] = c3_par
     for skey, cb in cpu_two.items():
         out[skey]["cpu_baseline"] = cb
     out["rerank"]["note"] = ("cluster lookup + dot + per-alpha select (3 launches, 20 calls back to back per timing): launch-bound, not "
@@ -526,6 +532,24 @@ def stages(dev, cfg, D, D_dev, a):
                                        "tflops": gflop / t / 1e3, "frac_of_f32_mfma_peak": gflop / t / 1e3 / F32_MFMA_PEAK_TFLOPS,
                                        "corpus_320k_embed_s": 320000 / (256 / t),
                                        "note": "padded form (every one of the 128 positions computed); CLS -> pooler"}
+    del tower
+    torch.cuda.empty_cache()
+    # ---- config C5 on this GPU (1M x 768 bf16 corpus, 512 queries, beam 30, bf16 linears): `--workload c5` for 3 steps, with its
+    # oracle check (stage 1 on 2 queries against the bf16 emulation, stage 2 on 64), so that the default run's one line carries it
+    if not a.no_c5:
+        import torch.distributed as dist5
+        a5 = argparse.Namespace(**vars(a))
+        a5.workload, a5.corpus, a5.batch, a5.beams, a5.dtype, a5.steps, a5.warmup, a5.depth = "c5", 1000000, 512, 30, "bf16", 3, 1, 2
+        a5.constrained, a5.parity_queries = False, None
+        a5.parity_only = not (a.no_cpu_baseline or a.no_parity)
+        a5.no_parity = a.no_cpu_baseline or a.no_parity
+        t5 = time.perf_counter()
+        r5, _d5, v5 = two_stage_measure(a5, 0, 1, dev, dist5)
+        out["c5_two_stage"] = {"queries_per_s": r5["value"], "ms_per_step": r5["ms_per_step"], "workload": r5["config"]["workload"],
+                               "linear_tflops": r5["roofline"]["achieved"], "linear_frac_of_bf16_mfma_peak": r5["roofline"]["frac"],
+                               "linear_launches_per_step": r5["roofline"]["launches_per_step"], "kernels": r5["kernels"],
+                               "parity": r5["parity"], "parity_violations": v5 if r5["parity"] is not None else None,
+                               "stage_wall_s": time.perf_counter() - t5, "corpus_setup_s": r5["config"]["corpus_setup_s"]}
     return out
 
 
@@ -639,7 +663,14 @@ def stages_summary(st):
             "sim_B32_frac_of_hbm_peak": sim["B32"]["frac_of_hbm_peak"],
             "sim_B1_prefilter_ms": st["similarity_topk_f32_prefilter"]["B1"]["ms"],
             "sim_B32_prefilter_ms": st["similarity_topk_f32_prefilter"]["B32"]["ms"],
-            "doc_tower_frac_of_f32_mfma_peak": st["doc_tower_bert_base_L128"]["frac_of_f32_mfma_peak"]}
+            "doc_tower_frac_of_f32_mfma_peak": st["doc_tower_bert_base_L128"]["frac_of_f32_mfma_peak"],
+            "B1_beam100_launches": g["B1_beam100"]["kernel_launches_per_call"],
+            "B1_beam100_frac_of_floor_executed": g["B1_beam100"]["frac_of_floor_executed"],
+            "c3_parity_violations": (lambda p_: None if p_ is None else p_["stage1_rows_violating"] + p_["stage2_rows_violating"])(
+                st["c3_two_stage"].get("parity")),
+            "c5_qps": (st.get("c5_two_stage") or {}).get("queries_per_s"),
+            "c5_linear_frac": (st.get("c5_two_stage") or {}).get("linear_frac_of_bf16_mfma_peak"),
+            "c5_parity_violations": (st.get("c5_two_stage") or {}).get("parity_violations")}
 
 
 def fence(dist):
@@ -699,8 +730,17 @@ def init_ranks(a):
 
 def two_stage_main(a):
     """--workload c3 / c5: the two-stage GDR path (main_models.py:1337-1642) per GPU, stage 2 over the row-sharded corpus."""
-    import types
     rank, world, dev, dist = init_ranks(a)
+    result, detail, violations = two_stage_measure(a, rank, world, dev, dist)
+    if rank == 0:
+        return result, detail, violations
+    return None, None, 0
+
+
+def two_stage_measure(a, rank, world, dev, dist):
+    """One --workload c3 / c5 measurement on this rank: (result, detail, parity violations) on rank 0, (None, None, 0) elsewhere.
+    Also called by stages() of the default run for C5's numbers (1 GPU, a few steps), so that the driver's one line carries them."""
+    import types
     from gdr_amd import codec, ops, synth, _ffi
     from gdr_amd.config import GDRConfig
     from gdr_amd.dist import ShardedIndex, shard_bounds
@@ -715,8 +755,10 @@ def two_stage_main(a):
     model = GDRModel(cfg, sd, dev, ragged=True, prefix_trie=trie, trie=trie if a.constrained else None,
                      dtype=torch.bfloat16 if bf16 else torch.float32)
     lo, hi = shard_bounds(a.corpus, world, rank, cluster_size=12)
-    D = synth.make_corpus(a.corpus, cfg.d_model)
-    D_dev = torch.from_numpy(D[lo:hi]).to(dev)
+    t_c = time.perf_counter()
+    D = synth.make_corpus(a.corpus, cfg.d_model, rows=(lo, hi) if world > 1 else None)   # N > 1: this rank's rows only (bit-identical
+    t_corpus = time.perf_counter() - t_c                                                 # to the slice of the whole corpus)
+    D_dev = torch.from_numpy(D).to(dev)
     if bf16:
         D_dev = ops.to_bf16(D_dev)
     ids_all, mask_all = synth.make_tokens(B * world, L=40, seed=11)
@@ -780,7 +822,7 @@ def two_stage_main(a):
                        "dist_backend": a.backend if dist.is_initialized() else None,
                        "batch_per_gpu": B, "global_batch": B * world, "beams": R, "seq_len": 40, "corpus_rows": a.corpus,
                        "dim": cfg.d_model, "k": R, "alphas": 7, "candidates_per_query": n_cand, "pipeline_depth": max(1, a.depth),
-                       "docid_depth": id_depth},
+                       "docid_depth": id_depth, "corpus_setup_s": round(t_corpus, 2), "corpus_rows_on_host": int(D.shape[0])},
             "roofline": {"bound": "mfma",
                          "kernel": ("every linear of the step (encoder, decoder, adaptor, head): gdr::gemm_nt_bf16_*" if bf16 else
                                     "every linear of the step: gdr::gemm_nt_f32_small_kernel (decode rows) + persistent / stream-K (encoder)"),
@@ -801,7 +843,8 @@ def two_stage_main(a):
                   "roofline_source": f"profiled replay of {n_prof} step(s) after the timed region (hipEvent pairs on the launch streams; "
                                      "summed durations of two overlapping chains can exceed the step's wall time)"}
         violations = 0
-        if world == 1 and not a.no_cpu_baseline and not a.no_parity:
+        parity_only = getattr(a, "parity_only", False)        # stages(): the oracle check without the CPU timing leg
+        if world == 1 and not a.no_parity and (parity_only or not a.no_cpu_baseline):
             tree = None
             if a.constrained:
                 from oracle import beam_ref, codec_ref
@@ -810,15 +853,11 @@ def two_stage_main(a):
                                                 nq1=a.parity_queries[0] if a.parity_queries else (2 if R > 10 else 4),
                                                 nq2=a.parity_queries[1] if a.parity_queries else 64)
             violations = result["parity"]["stage1_rows_violating"] + result["parity"]["stage2_rows_violating"]
-        if world == 1 and not a.no_cpu_baseline and not violations:
+        if world == 1 and not a.no_cpu_baseline and not parity_only and not violations:
             result["cpu_baseline"] = cpu_baseline_two_stage(sd, cfg, ids_all, mask_all, D, look, R, args.score_rate,
                                                             n=1 if R > 10 else 2, reps=1 if R > 10 else 3)
-        emit(result, detail)
-        if violations:
-            raise SystemExit(f"bench: {violations} queries of the step differ from the CPU oracle outside the parity rule")
-    if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+        return result, detail, violations
+    return None, None, 0
 
 
 def main():
@@ -836,9 +875,11 @@ def main():
     sd = synth.make_state_dict(cfg, seed=1234, with_decoder=False)
     bf16 = a.dtype == "bf16"
     enc = ops.T5EncoderHandle(cfg, sd, dev, dtype=torch.bfloat16 if bf16 else torch.float32)
-    D = synth.make_corpus(a.corpus, cfg.d_model)
     lo, hi = shard_bounds(a.corpus, world, rank, cluster_size=12)
-    D_dev = torch.from_numpy(D[lo:hi]).to(dev)
+    t_c = time.perf_counter()
+    D = synth.make_corpus(a.corpus, cfg.d_model, rows=(lo, hi) if world > 1 else None)   # N > 1: this rank's rows only (bit-identical
+    t_corpus = time.perf_counter() - t_c                                                 # to the slice of the whole corpus)
+    D_dev = torch.from_numpy(D).to(dev)
     if bf16:
         D_dev = ops.to_bf16(D_dev)
     if a.sim_prefilter == "bf16" and not bf16:
@@ -919,6 +960,32 @@ def main():
         pre = {"queries_per_s": a.batch * a.steps / dtp, "ms_per_step": dtp / a.steps * 1e3, "flagged_rows": int(outp[2].sum().item()),
                "extra_hbm_mb": P.D16.numel() * 2 / 1e6}
 
+    # ---- the same step with the PADDED encoder (every one of the batch x 40 token rows through all 48 linears, as the reference
+    # computes it): the reference-equivalent-work number beside the headline's exact work elimination; same protocol, own roofline
+    padded = None
+    if world == 1 and not bf16 and ragged and not a.no_stages:
+        def step_pad():
+            _, pooled = enc.forward(ids, mask, want_hidden=False, ragged=False)
+            return index.search(pooled, a.k, return_status=True)
+
+        for _ in range(max(1, a.warmup)):
+            step_pad()
+        _ffi.check(lib.gdr_prof_enable(launches_per_step * a.steps + 16), "gdr_prof_enable")
+        fence(dist)
+        t0q = time.perf_counter()
+        for i in range(a.steps):
+            lib.gdr_prof_gate(1 if i % pe == 0 else 0)
+            step_pad()
+        lib.gdr_prof_gate(1)
+        fence(dist)
+        dtq = time.perf_counter() - t0q
+        n_q, ms_q, w_q = (C.c_int64 * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
+        _ffi.check(lib.gdr_prof_collect(n_q, ms_q, w_q), "gdr_prof_collect")
+        lin_tf = w_q[0] / (ms_q[0] * 1e-3) / 1e12 if ms_q[0] > 0 else 0.0
+        padded = {"queries_per_s": a.batch * a.steps / dtq, "ms_per_step": dtq / a.steps * 1e3, "token_rows": a.batch * 40,
+                  "linear_tflops": lin_tf, "linear_frac_of_f32_mfma_peak": lin_tf / F32_MFMA_PEAK_TFLOPS,
+                  "linear_launches_timed": int(n_q[0])}
+
     total_q = a.batch * world * a.steps
     ms_per_step = dt / a.steps * 1e3
     n_prof_steps = len(range(0, a.steps, max(1, a.prof_every)))
@@ -932,14 +999,19 @@ def main():
                     "tflops": avg_work / (avg_ms * 1e-3) / 1e12, "share_of_step": ms_l[c] / n_prof_steps / (dt / a.steps * 1e3)}
 
         lin, smp, flt, att, red = cls(0), cls(1), cls(2), cls(3), cls(7)
-        traffic = None
+        # roofline.traffic comes from a committed PMC collection (profiles/traffic.json, tools/summarize_profiles.py), not from this
+        # run: it carries the hash of the GEMM source it was counted on, and the line says so when that is no longer the source here
+        traffic, traffic_stale = None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
+                import hashlib
                 tj = json.load(open(tpath))
                 traffic = tj.get("linear_gemm_bytes_per_launch_ragged" if ragged else "linear_gemm_bytes_per_launch")
+                with open(os.path.join(REPO, "gdr_amd", "csrc", "gemm_f32.hip"), "rb") as f:
+                    traffic_stale = tj.get("gemm_f32_sha16") != hashlib.sha256(f.read()).hexdigest()[:16]
             except Exception:
-                traffic = None
+                traffic, traffic_stale = None, None
         peak = BF16_MFMA_PEAK_TFLOPS if bf16 else F32_MFMA_PEAK_TFLOPS
         result = {
             "metric": "queries/sec on NQ-320k (768-d)", "value": total_q / dt, "unit": "queries/s",
@@ -951,13 +1023,15 @@ def main():
                        "dist_backend": a.backend if dist.is_initialized() else None,
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 40,
                        "corpus_rows": a.corpus, "dim": cfg.d_model, "k": a.k,
-                       "encoder_rows": "ragged" if ragged else "padded", "live_token_rows_per_gpu": live_rows},
+                       "encoder_rows": "ragged" if ragged else "padded", "live_token_rows_per_gpu": live_rows,
+                       "corpus_setup_s": round(t_corpus, 2), "corpus_rows_on_host": int(D.shape[0])},
             "roofline": {"bound": "mfma",
                          "kernel": ("gdr::gemm_nt_bf16 (glds / persist256): every encoder linear" if bf16 else
                                     "gdr::gemm_nt_f32_persistent_kernel / gemm_nt_f32_streamk_kernel: every encoder linear"),
                          "achieved": lin["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": lin["tflops"] / peak,
                          "traffic": None if bf16 else traffic,
                          "traffic_source": None if (bf16 or traffic is None) else "static: profiles/traffic.json (rocprofv3 --pmc passes of this command)",
+                         "traffic_stale": None if (bf16 or traffic is None) else bool(traffic_stale),
                          "launches": lin["launches"], "timed_steps": n_prof_steps, "avg_launch_ms": lin["avg_ms"],
                          "algorithmic_gflop_per_launch": lin["gflop_per_launch"], "share_of_step": lin["share_of_step"]},
         }
@@ -1026,6 +1100,10 @@ def main():
                 torch.cuda.empty_cache()
             detail["stages"] = stages(dev, cfg, D, D_dev, a)
             result["stages_summary"] = stages_summary(detail["stages"])
+            if padded is not None:
+                detail["stages"]["c2_step_padded"] = padded
+                result["stages_summary"]["c2_padded_qps"] = padded["queries_per_s"]
+                result["stages_summary"]["c2_padded_linear_frac"] = padded["linear_frac_of_f32_mfma_peak"]
             if pre is not None:
                 detail["stages"]["c2_step_bf16_prefilter"] = pre
                 detail["stages"]["c2_step_bf16_prefilter_note"] = (

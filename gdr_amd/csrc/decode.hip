@@ -1314,8 +1314,10 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   }
 
   static const int fused_mask = [] {
-    const char* e = getenv("GDR_DECODE_FUSED");  // A/B knob, bit mask: 1 self-attention, 2 cross-attention, 4 feed-forward sub-block fused
-    return e ? atoi(e) : 7;                      // (decode_fused.hip); 0 = every phase its own launch (the round-5 chain)
+    const char* e = getenv("GDR_DECODE_FUSED");  // bit mask: 1 self-attention, 2 cross-attention, 4 feed-forward sub-block fused (decode_fused.hip).
+    return e ? atoi(e) : 0;                      // OFF by default: measured slower than the per-phase launches at every decode shape
+                                                 // (profiles/r06_fused_decode_ab.txt: 64 x 10 beams 11.97 -> 14.55 ms, 1 x 100 6.48 -> 7.54 with all three
+                                                 // on; the self-attention form alone is neutral at 640 rows).  Kept exact, tested (test_gpu_decode_knobs.py)
   }();
   static const bool slab_q_on = [] {
     const char* e = getenv("GDR_DECODE_SLAB_Q");  // A/B knob: 0 = reduce the cross-attention q projection in its own launch

@@ -23,6 +23,8 @@
 // unfused kernels; its feed-forward (linear1 -> ReLU -> linear2) is the FFN form with bias1 in phase 1 and bias2 in the reduction.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "decode_fused.h"
 
 namespace gdr {
@@ -126,17 +128,17 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const FusedArgs g) {
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (f32x4f){0.f, 0.f, 0.f, 0.f};
-  float4 pa[NA], pw[NW], qa[NA], qw[NW], ra[NA], rw[NW];
+  f32x4f pa[NA], pw[NW], qa[NA], qw[NW], ra[NA], rw[NW];  // first-class vectors: arrays of HIP's float4 struct stayed in scratch (allocas not promoted)
 #define F_LOAD(R, kt_)                                                                              \
   {                                                                                                 \
     const int t_ = (kt_) < nk ? (kt_) : nk - 1; /* past the end: re-fetch the last chunk */         \
-    _Pragma("unroll") for (int i = 0; i < NA; ++i) R##a[i] = *reinterpret_cast<const float4*>(a_src[i] + t_ * 32); \
-    _Pragma("unroll") for (int i = 0; i < NW; ++i) R##w[i] = *reinterpret_cast<const float4*>(w_src[i] + t_ * 32); \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) R##a[i] = *reinterpret_cast<const f32x4f*>(a_src[i] + t_ * 32); \
+    _Pragma("unroll") for (int i = 0; i < NW; ++i) R##w[i] = *reinterpret_cast<const f32x4f*>(w_src[i] + t_ * 32); \
   }
 #define F_STORE(R, buf_)                                                                            \
   {                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < NA; ++i) if (a_on[i]) *reinterpret_cast<float4*>(As + (buf_)*RM * SLD + a_st[i]) = R##a[i]; \
-    _Pragma("unroll") for (int i = 0; i < NW; ++i) *reinterpret_cast<float4*>(Ws + (buf_)*N1 * SLD + w_st[i]) = R##w[i];              \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) if (a_on[i]) *reinterpret_cast<f32x4f*>(As + (buf_)*RM * SLD + a_st[i]) = R##a[i]; \
+    _Pragma("unroll") for (int i = 0; i < NW; ++i) *reinterpret_cast<f32x4f*>(Ws + (buf_)*N1 * SLD + w_st[i]) = R##w[i];              \
   }
 #define F_COMPUTE(buf_)                                                                             \
   {                                                                                                 \
@@ -161,21 +163,25 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const FusedArgs g) {
   F_STORE(p, 0)
   F_LOAD(p, 3)
   __syncthreads();
-#define F_STEP(kt_, buf_, R)       \
-  F_COMPUTE(buf_)                  \
-  if ((kt_) + 1 < nk) {            \
-    F_STORE(R, 1 - (buf_))         \
-    F_LOAD(R, (kt_) + 4)           \
-  }                                \
+  // No conditional around a load or a store: LLVM sinks a load whose only use sits in a later conditional block down to that use
+  // (measured on the first build: load -> s_waitcnt vmcnt(0) -> ds_write in every step, 78-110 us per launch instead of ~15).  Past the
+  // end the clamped loads re-fetch the last chunk and the extra store lands in the buffer nobody reads again.
+#define F_STEP(kt_, R)             \
+  F_COMPUTE(buf)                   \
+  F_STORE(R, buf ^ 1)              \
+  F_LOAD(R, (kt_) + 4)             \
   __syncthreads();                 \
-  if ((kt_) + 1 >= nk) break;
-  for (int kt = 0;; kt += 6) {
-    F_STEP(kt, 0, q)
-    F_STEP(kt + 1, 1, r)
-    F_STEP(kt + 2, 0, p)
-    F_STEP(kt + 3, 1, q)
-    F_STEP(kt + 4, 0, r)
-    F_STEP(kt + 5, 1, p)
+  if ((kt_) + 1 >= nk) break;      \
+  buf ^= 1;
+  // three steps per trip = the period of the register stages: a stage loaded in step X of one trip is stored in step X of the NEXT
+  // trip, i.e. every staged value is loop-carried.  (With six steps per trip — the period of stages x LDS buffers — half of the
+  // loads had their use later in the SAME trip, and LLVM's machine sink moved those loads down to their use, across the barriers.)
+  // The LDS buffer therefore alternates through a run-time index.
+  int buf = 0;
+  for (int kt = 0;; kt += 3) {
+    F_STEP(kt, q)
+    F_STEP(kt + 1, r)
+    F_STEP(kt + 2, p)
   }
 #undef F_STEP
 #undef F_LOAD
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const FusedArgs g) {
   // W3 chunk j: rows n = j * NC3 .. + NC3 - 1, columns slice * K3 .. + K3 - 1, as [NC3][LD3] in the stage region.
   constexpr int N3 = NC3 * (K3 / 4) / 256;  // float4 per thread per chunk: 16
   constexpr int F4R = K3 / 4;               // float4 per row
-  float4 w3[N3];
+  f32x4f w3[N3];
   const int nchunk3 = (d + NC3 - 1) / NC3;
   auto w3_load = [&](int j) {
 #pragma unroll
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const FusedArgs g) {
       const int e = tid + 256 * i, n = e / F4R, c4 = e % F4R;
       int nn = j * NC3 + n;
       nn = nn < d ? nn : d - 1;
-      w3[i] = *reinterpret_cast<const float4*>(g.W3 + (int64_t)nn * g.ld3 + (int64_t)slice * K3 + 4 * c4);
+      w3[i] = *reinterpret_cast<const f32x4f*>(g.W3 + (int64_t)nn * g.ld3 + (int64_t)slice * K3 + 4 * c4);
     }
   };
   w3_load(0);  // in flight during the middle phase (weights do not depend on it)
@@ -238,55 +244,61 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const FusedArgs g) {
       *reinterpret_cast<float4*>(g.slot + (m0 + r) * g.ld_kv + (part ? g.v_off : g.k_off) + 64 * slice + 4 * cc) = v;
     }
     const int Lk = g.Lk;
+    // every load and every use unconditional (clamped key index, masked with selects): see F_STEP.  MK = key capacity of the form
+    auto attend = [&](auto mk_tag) {
+      constexpr int MK = decltype(mk_tag)::value;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int r = grp + 16 * rt;
-      const bool on = r < rows_here;
-      const int rr = on ? r : 0;
-      float4 kreg[MAXK], vreg[MAXK];
-      const int32_t* kvr = g.kv_rows + (m0 + rr) * Lk;
+      for (int rt = 0; rt < RT; ++rt) {
+        const int r = grp + 16 * rt;
+        const bool on = r < rows_here;
+        const int rr = on ? r : 0;
+        f32x4f kreg[MK], vreg[MK];
+        const int32_t* kvr = g.kv_rows + (m0 + rr) * Lk;
 #pragma unroll
-      for (int j = 0; j < MAXK; ++j) {
-        if (j < Lk - 1) {
-          const int64_t row = kvr[j];
-          kreg[j] = *reinterpret_cast<const float4*>(g.kbase + row * g.ld_kv + 64 * slice + 4 * c);
-          vreg[j] = *reinterpret_cast<const float4*>(g.vbase + row * g.ld_kv + 64 * slice + 4 * c);
+        for (int j = 0; j < MK; ++j) {
+          const int jc = j < Lk - 1 ? j : (Lk > 1 ? Lk - 2 : 0);  // ancestors 0 .. Lk-2; Lk == 1: entry 0 (the row's own slot: valid memory, unused)
+          const int64_t row = kvr[jc];
+          kreg[j] = *reinterpret_cast<const f32x4f*>(g.kbase + row * g.ld_kv + 64 * slice + 4 * c);
+          vreg[j] = *reinterpret_cast<const f32x4f*>(g.vbase + row * g.ld_kv + 64 * slice + 4 * c);
         }
-      }
-      float4 q = *reinterpret_cast<const float4*>(Cs + rr * CLD + 4 * c);
-      q.x *= g.scale, q.y *= g.scale, q.z *= g.scale, q.w *= g.scale;
-      float sc[MAXK];
-      float mx = -INFINITY;
+        float4 q = *reinterpret_cast<const float4*>(Cs + rr * CLD + 4 * c);
+        q.x *= g.scale, q.y *= g.scale, q.z *= g.scale, q.w *= g.scale;
+        const float4 kown = *reinterpret_cast<const float4*>(Cs + rr * CLD + 64 + 4 * c);
+        const float4 vown = *reinterpret_cast<const float4*>(Cs + rr * CLD + 128 + 4 * c);
+        float sc[MK];
+        float mx = -INFINITY;
 #pragma unroll
-      for (int j = 0; j < MAXK; ++j) {
-        if (j < Lk) {
-          const float4 kk = j < Lk - 1 ? kreg[j] : *reinterpret_cast<const float4*>(Cs + rr * CLD + 64 + 4 * c);
+        for (int j = 0; j < MK; ++j) {
+          const bool own = j == Lk - 1;
+          f32x4f kk = kreg[j];
+          kk.x = own ? kown.x : kk.x, kk.y = own ? kown.y : kk.y, kk.z = own ? kown.z : kk.z, kk.w = own ? kown.w : kk.w;
           float part = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
           part = row16_sum(part);
-          sc[j] = part + Add[j];
+          sc[j] = j < Lk ? part + Add[j < Lk ? j : 0] : -INFINITY;
           mx = fmaxf(mx, sc[j]);
         }
-      }
-      float sum = 0.f;
+        float sum = 0.f;
 #pragma unroll
-      for (int j = 0; j < MAXK; ++j) {
-        if (j < Lk) {
-          sc[j] = expf(sc[j] - mx);
+        for (int j = 0; j < MK; ++j) {
+          sc[j] = expf(sc[j] - mx);  // exp(-inf) = 0 for the slots past Lk
           sum += sc[j];
         }
-      }
-      const float inv = 1.0f / sum;
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float inv = 1.0f / sum;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int j = 0; j < MAXK; ++j) {
-        if (j < Lk) {
-          const float4 vv = j < Lk - 1 ? vreg[j] : *reinterpret_cast<const float4*>(Cs + rr * CLD + 128 + 4 * c);
+        for (int j = 0; j < MK; ++j) {
+          const bool own = j == Lk - 1;
+          f32x4f vv = vreg[j];
+          vv.x = own ? vown.x : vv.x, vv.y = own ? vown.y : vv.y, vv.z = own ? vown.z : vv.z, vv.w = own ? vown.w : vv.w;
           const float pj = sc[j] * inv;
           o.x = fmaf(pj, vv.x, o.x), o.y = fmaf(pj, vv.y, o.y), o.z = fmaf(pj, vv.z, o.z), o.w = fmaf(pj, vv.w, o.w);
         }
+        *reinterpret_cast<float4*>(Ctx + r * XLD + 4 * c) = on ? o : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      *reinterpret_cast<float4*>(Ctx + r * XLD + 4 * c) = on ? o : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    };
+    if (Lk <= 4) attend(std::integral_constant<int, 4>{});
+    else if (Lk <= 8) attend(std::integral_constant<int, 8>{});
+    else attend(std::integral_constant<int, MAXK>{});
     __syncthreads();
   } else if (MODE == FUSED_CA) {
     // rows m0 .. m0 + rows_here - 1 belong to queries b_lo .. b_hi (R consecutive rows each); per query: stage its K / V of this
@@ -354,9 +366,9 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const FusedArgs g) {
 #pragma unroll
     for (int i = 0; i < N3; ++i) {
       const int e = tid + 256 * i, n = e / F4R, c4 = e % F4R;
-      *reinterpret_cast<float4*>(B3 + n * LD3 + 4 * c4) = w3[i];
+      *reinterpret_cast<f32x4f*>(B3 + n * LD3 + 4 * c4) = w3[i];
     }
-    if (j + 1 < nchunk3) w3_load(j + 1);
+    w3_load(j + 1 < nchunk3 ? j + 1 : j);  // unconditional (see F_STEP): the last iteration re-fetches its own chunk
     __syncthreads();
     f32x4f o3[RT][CT3];
 #pragma unroll

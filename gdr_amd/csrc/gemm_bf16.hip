@@ -741,3 +741,8 @@ int launch_sim_bf16_glds(const void* D, int64_t N, const void* Q, int B, int d, 
 }
 
 }  // namespace gdr
+
+extern "C" int gdr_linear_bf16_tile_form(int64_t M, int N, int K, int epilogue) {
+  const int has_residual = epilogue == GDR_EPI_RESIDUAL || epilogue == GDR_EPI_BIAS_RESIDUAL;
+  return gdr::linear_bf16_tile_form(M, N, K, has_residual, 0);
+}

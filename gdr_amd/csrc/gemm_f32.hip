@@ -1563,8 +1563,3 @@ extern "C" int gdr_linear_bf16(const void* A, int64_t lda, const void* W, int64_
   return gdr::launch_linear_bf16(A, lda, W, ldw, C, ldc, M, N, K, epilogue, bias, residual, ldr,
                                  static_cast<hipStream_t>(stream));
 }
-
-extern "C" int gdr_linear_bf16_tile_form(int64_t M, int N, int K, int epilogue) {
-  const int has_residual = epilogue == GDR_EPI_RESIDUAL || epilogue == GDR_EPI_BIAS_RESIDUAL;
-  return gdr::linear_bf16_tile_form(M, N, K, has_residual, 0);
-}

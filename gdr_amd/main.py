@@ -144,8 +144,10 @@ def reassemble_spans(per_rank, n_spans, world):
     return [per_rank[i % world][i // world] for i in range(n_spans)]
 
 
-def _load_inputs(args, cfg):
-    """Returns dict(source_ids, source_mask, gt_cluster list[str], gt_doc list[str], index, doc_embed (np or None))."""
+def _load_inputs(args, cfg, shard=None):
+    """Returns dict(source_ids, source_mask, gt_cluster list[str], gt_doc list[str], index, doc_embed (np or None)).
+    shard=(world, rank): a rank of `--n_gpu N` with the synthetic corpus materialises only its own rows (doc_embed = those rows,
+    doc_rows = (lo, hi, N)); files are loaded whole."""
     if args.data_npz:
         z = np.load(args.data_npz, allow_pickle=False)
         index = codec.ClusterIndex([str(x) for x in z["cluster_names"]], z["cluster_offsets"], z["cluster_members"])
@@ -154,11 +156,16 @@ def _load_inputs(args, cfg):
                     gt_doc=[str(x) for x in z["gt_doc"]], index=index, doc_embed=doc)
     N = args.corpus_rows
     names, depth, offsets, members = synth.make_cluster_ids(N, cluster_size=12, V=args.kary)
-    D = synth.make_corpus(N, cfg.d_model)
+    rows = None
+    if shard is not None and shard[0] > 1:
+        from .dist import shard_bounds
+        rows = shard_bounds(N, shard[0], shard[1], cluster_size=12)
+    D = synth.make_corpus(N, cfg.d_model, rows=rows)
     ids, mask = synth.make_tokens(args.n_queries, L=args.max_input_length, seed=11)
-    _, gold = synth.make_queries(D, args.n_queries)
+    gold = synth.make_gold(N, args.n_queries)            # the ids make_queries(D, n) draws (it needs the whole D only for the vectors)
     return dict(source_ids=ids, source_mask=mask, gt_cluster=[names[int(g) // 12] for g in gold],
-                gt_doc=[str(int(g)) for g in gold], index=codec.ClusterIndex(names, offsets, members), doc_embed=D)
+                gt_doc=[str(int(g)) for g in gold], index=codec.ClusterIndex(names, offsets, members), doc_embed=D,
+                doc_rows=(rows[0], rows[1], N) if rows is not None else None)
 
 
 def inference(args):
@@ -188,7 +195,8 @@ def inference(args):
             dist.init_process_group(args.dist_backend)
         world, rank = dist.get_world_size(), dist.get_rank()
     dev = torch.device(args.device)
-    data = _load_inputs(args, cfg)
+    two_stage_wanted = bool(args.is_train_encoder)
+    data = _load_inputs(args, cfg, shard=(world, rank) if two_stage_wanted else None)
     if args.constrain_tree and args.kary != args.output_vocab_size:
         raise SystemExit(f"--constrain_tree 1 needs --kary ({args.kary}) == --output_vocab_size "
                          f"({args.output_vocab_size}): the trie is indexed by the head's digit columns")
@@ -203,9 +211,13 @@ def inference(args):
         # config C5's layout: rank r keeps rows [lo, hi) of the corpus (whole clusters when they are contiguous row blocks,
         # as the synthetic corpus' are; any row split is correct — a candidate is scored by the rank that holds its row)
         from .dist import ShardedIndex, shard_bounds
-        N_rows = data["doc_embed"].shape[0]
-        lo_r, hi_r = shard_bounds(N_rows, world, rank, cluster_size=12 if not args.data_npz else 1)
-        shard = torch.from_numpy(np.ascontiguousarray(data["doc_embed"][lo_r:hi_r], dtype=np.float32)).to(dev)
+        if data.get("doc_rows"):                                 # the synthetic corpus: only this rank's rows were generated
+            lo_r, hi_r, _n = data["doc_rows"]
+            shard = torch.from_numpy(np.ascontiguousarray(data["doc_embed"], dtype=np.float32)).to(dev)
+        else:
+            N_rows = data["doc_embed"].shape[0]
+            lo_r, hi_r = shard_bounds(N_rows, world, rank, cluster_size=12 if not args.data_npz else 1)
+            shard = torch.from_numpy(np.ascontiguousarray(data["doc_embed"][lo_r:hi_r], dtype=np.float32)).to(dev)
         sharded_index = ShardedIndex(shard, lo_r)
         retr = GDRRetriever(model, None, data["index"], args, sharded=sharded_index)
     elif two_stage:

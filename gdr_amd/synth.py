@@ -101,17 +101,40 @@ def make_state_dict(cfg: GDRConfig, seed: int = 1234, with_decoder: bool = True,
 # corpus / queries
 # ----------------------------------------------------------------------------------------------
 def make_corpus(N: int, d: int = 768, cluster_size: int = 12, seed: int = 20240320,
-                chunk: int = 65536):
-    """``D fp32[N,d]``: doc i belongs to cluster i // cluster_size; d = c + noise."""
+                chunk: int = 65536, rows=None):
+    """``D fp32[N,d]``: doc i belongs to cluster i // cluster_size; d = c + noise.
+    rows=(lo, hi): only rows [lo, hi) are materialised — bit-identical to ``make_corpus(N, ...)[lo:hi]`` (a rank of an N-GPU
+    run keeps its shard only: 1/world of the host memory).  The noise is drawn from ONE PCG64 stream whose position cannot be
+    jumped to (the float32 ziggurat consumes a data-dependent number of raw draws per sample), so the chunks in front of `lo`
+    are still drawn (into a scratch chunk that is dropped) — the draws behind `hi` are not."""
+    lo_r, hi_r = (0, N) if rows is None else (int(rows[0]), int(rows[1]))
+    if not 0 <= lo_r <= hi_r <= N:
+        raise ValueError(f"make_corpus: rows={rows} outside [0, {N}]")
     g = np.random.Generator(np.random.PCG64(seed))
     n_clusters = (N + cluster_size - 1) // cluster_size
     s = np.float32(1.0 / math.sqrt(d))
     cent = g.standard_normal((n_clusters, d), dtype=np.float32) * (s * np.float32(0.8))
-    D = np.empty((N, d), dtype=np.float32)
+    D = np.empty((hi_r - lo_r, d), dtype=np.float32)
+    scratch = None
     for lo in range(0, N, chunk):
         hi = min(N, lo + chunk)
-        D[lo:hi] = g.standard_normal((hi - lo, d), dtype=np.float32) * (s * np.float32(0.6))
-        D[lo:hi] += cent[np.arange(lo, hi) // cluster_size]
+        if lo >= hi_r:
+            break
+        if hi <= lo_r:                                   # wholly in front of the shard: advance the stream only
+            if scratch is None:
+                scratch = np.empty((chunk, d), dtype=np.float32)
+            g.standard_normal((hi - lo, d), dtype=np.float32, out=scratch[:hi - lo])
+            continue
+        if lo >= lo_r and hi <= hi_r:                    # wholly inside: drawn in place
+            blk = D[lo - lo_r:hi - lo_r]
+            g.standard_normal((hi - lo, d), dtype=np.float32, out=blk)
+            blk *= s * np.float32(0.6)
+            blk += cent[np.arange(lo, hi) // cluster_size]
+            continue
+        blk = g.standard_normal((hi - lo, d), dtype=np.float32) * (s * np.float32(0.6))
+        blk += cent[np.arange(lo, hi) // cluster_size]
+        a, b = max(lo, lo_r), min(hi, hi_r)
+        D[a - lo_r:b - lo_r] = blk[a - lo:b - lo]
     return D
 
 
@@ -124,6 +147,12 @@ def make_queries(D: np.ndarray, B: int, seed: int = 7):
     dg = dg / np.linalg.norm(dg, axis=1, keepdims=True)
     Q = (np.float32(5.0) * dg + g.standard_normal((B, d), dtype=np.float32)) / np.float32(3.0)
     return Q.astype(np.float32), gold.astype(np.int64)
+
+
+def make_gold(N: int, B: int, seed: int = 7):
+    """The gold doc ids make_queries(D[N, d], B, seed) draws, without D (a rank that holds only a shard of the corpus)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    return g.integers(0, N, size=B).astype(np.int64)
 
 
 def make_tokens(B: int, L: int = 40, vocab_hi: int = 32100, seed: int = 11, min_len: int = 8):

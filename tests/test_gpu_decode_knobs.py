@@ -76,7 +76,10 @@ def test_decode_scheduling_switches_do_not_change_generate():
     # GDR_DECODE_SLAB_Q=0 reduces the cross-attention q projection in a launch of its own; the attention then gets finished q
     # rows and (round 4) takes the MFMA beam-row form instead of the generic kernel that sums the slabs: same scores, another
     # summation order — like the two switches after it
-    for env in (dict(GDR_DECODE_SLAB_Q="0"), dict(GDR_DECODE_FUSE_NORM="0"), dict(GDR_DECODE_DEDUP0="0")):
+    # GDR_DECODE_FUSED=7 (r06, decode_fused.hip; off by default — measured slower): the self-attention, cross-attention and feed-forward
+    # sub-blocks of a decoder block as (row panel, head / d_ff chunk) workgroups + one slab reduction each — the same products in
+    # another fixed summation order
+    for env in (dict(GDR_DECODE_SLAB_Q="0"), dict(GDR_DECODE_FUSE_NORM="0"), dict(GDR_DECODE_DEDUP0="0"), dict(GDR_DECODE_FUSED="7")):
         other = _run(**env)
         other.pop("early_exits"), other.pop("last_done_step")
         for key in base:

@@ -113,6 +113,9 @@ with open(f"profiles/{tag}_bench_pmc_hbm.md", "w") as o:
             "tile fetches its two panels for itself — 8x the fetch per tile.  The tail made every launch faster (the kernel is "
             "MFMA-bound: 26.9 k q/s against 25.3 k, padded 17.1 k against 16.6 k), so this is energy, not time.\n")
 traffic["source"] = f"profiles/{tag}_bench_pmc_hbm.md"
+# the kernels these bytes were counted on: bench.py compares the hash with the source it runs and says "traffic_stale" when they differ
+import hashlib
+traffic["gemm_f32_sha16"] = hashlib.sha256(open("gdr_amd/csrc/gemm_f32.hip", "rb").read()).hexdigest()[:16]
 json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
 
 # ---------------------------------------------------------------------------------------------- MFMA utilisation
