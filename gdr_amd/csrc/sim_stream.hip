@@ -38,6 +38,8 @@ __global__ __launch_bounds__(STREAM_THREADS) void sim_stream_f32_kernel(const St
   extern __shared__ __attribute__((aligned(16))) float qs[];  // [32][d + 4]
   const int d = g.d, QS = d + 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  // sample pass: the tickets of the sliced threshold / select tails (sim_topk.hip sim_sliced_select_kernel) start this call at zero
+  if (MODE == 1 && blockIdx.x == 0 && tid < g.B) g.sim.cand_cnt[tid * CNT_STRIDE + 1] = 0, g.sim.cand_cnt[tid * CNT_STRIDE + 2] = 0;
   for (int e = tid; e < 32 * (d >> 2); e += STREAM_THREADS) {
     const int r = e / (d >> 2), c = e - r * (d >> 2);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -223,6 +225,8 @@ __global__ __launch_bounds__(STREAM_THREADS) void sim_stream_bf16_kernel(const S
   const int d = g.d, QSB = d * 2 + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const char* Qb = reinterpret_cast<const char*>(g.Q);
+  // sample pass: the tickets of the sliced threshold / select tails (sim_topk.hip sim_sliced_select_kernel) start this call at zero
+  if (MODE == 1 && blockIdx.x == 0 && tid < g.B) g.sim.cand_cnt[tid * CNT_STRIDE + 1] = 0, g.sim.cand_cnt[tid * CNT_STRIDE + 2] = 0;
   for (int e = tid; e < 32 * (d >> 3); e += STREAM_THREADS) {
     const int r = e / (d >> 3), c = e - r * (d >> 3);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -393,6 +397,8 @@ __global__ __launch_bounds__(STREAM_THREADS) void sim_stream_sample_splitk_kerne
   const int d = g.d, QS = d + 4;
   float* red = qs + 32 * QS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  // sample pass: the tickets of the sliced threshold / select tails (sim_topk.hip sim_sliced_select_kernel) start this call at zero
+  if (blockIdx.x == 0 && tid < g.B) g.sim.cand_cnt[tid * CNT_STRIDE + 1] = 0, g.sim.cand_cnt[tid * CNT_STRIDE + 2] = 0;
   const int64_t u = blockIdx.x;
   const int64_t t = (u >> 2) * g.sim.tile_stride;
   const int sub = (int)(u & 3);

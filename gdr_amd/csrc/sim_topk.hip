@@ -17,6 +17,8 @@
 //               lower doc id" — then bitonic-sorts them in LDS and writes values + ids.
 //
 // n_sample ≈ sqrt(k·N) balances list length against survivors.  Small corpora take steps 1, 2, 4 only.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gdr {
@@ -30,7 +32,7 @@ struct SimPlan {
   int64_t n_sample_tiles;
   int64_t n_slots;     // n_sample_tiles * TILE
   int64_t cap;         // candidate list capacity per query (multiple of TILE)
-  size_t off_val, off_idx, off_cnt, off_thr, total;
+  size_t off_val, off_idx, off_cnt, off_thr, off_part, total;
 };
 
 static SimPlan make_plan(int B, int64_t N, int k, bool exhaustive) {
@@ -60,6 +62,8 @@ static SimPlan make_plan(int B, int64_t N, int k, bool exhaustive) {
   p.off_idx = o, o += align_up((size_t)B * p.cap * sizeof(int32_t), 256);
   p.off_cnt = o, o += align_up((size_t)B * CNT_STRIDE * sizeof(int32_t), 256);
   p.off_thr = o, o += align_up((size_t)B * sizeof(float), 256);
+  // latency mode (B <= 32): the slices' top-k keys of the sliced threshold / select tails, [B][16 slices][128] x 8 bytes
+  p.off_part = o, o += B <= 32 ? align_up((size_t)B * 16 * 128 * sizeof(unsigned long long), 256) : 0;
   p.total = o;
   return p;
 }
@@ -386,6 +390,223 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
   }
 }
 
+// ---- latency mode (B <= 32, the stream kernels): threshold and select SPREAD over slices (r06) -----------------------------------
+// One workgroup per query left 1 .. 32 workgroups on 256 CUs for the two tails of the call (sim_threshold_kernel 22.6 us +
+// topk_select_kernel 54.0 us = 29 % of a 32-query call, profiles/r05_bench_kernel_stats.csv), and most of their time was same-bin LDS
+// atomics: 5 900 / 11 000 keys of one query counted into one 256-bin histogram, scores bunched just above the threshold.  Here a
+// query's list is cut into NS slices, one 256-thread workgroup each: the slice radix-selects ITS top-k (the global top-k is a subset
+// of the union of the slices' top-k lists), stores the keys write-through, and takes a ticket; the LAST arriver of a query loads the
+// NS x k keys and selects again — then either the k-th largest score (threshold form) or sort + write (select form).  Exact, and
+// deterministic: keys are distinct 64-bit values (score key : 32 | ~id : 32), a top-k set does not depend on arrival order.
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility; the stream-K idiom of gemm_f32.hip): sc1 stores, every wave drains,
+// the workgroup meets, one lane takes the ticket; the last arriver's lane 0 issues ONE agent-scope acquire, the workgroup meets, plain loads.
+constexpr int SL_THREADS = 256, SL_RC = 8, SL_NS_MAX = 16, SL_KPAD_MAX = 128;
+struct SelLds {
+  int hist[256];
+  int scan[256];
+  int res[2];
+  uint32_t red[32];
+  int n_out, last;
+};
+
+// The `k` largest of the workgroup's register-held raw keys (0 = no entry; keys whose score key is below lo_floor do not count)
+// -> outbuf[0 .. want), unsorted, zero-filled up to kpad.  Returns want = min(k, live keys).  topk_select_kernel's passes.
+template <int RC>
+__device__ __forceinline__ int block_select_keys(const unsigned long long (&rk)[RC], int k, int kpad, uint32_t lo_floor, SelLds& L,
+                                                 unsigned long long* outbuf) {
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+  for (int u = 0; u < RC; ++u)
+    if (rk[u] != 0ull) {
+      const uint32_t key = (uint32_t)(rk[u] >> 32);
+      lo = min(lo, key), hi = max(hi, key);
+    }
+  block_minmax(lo, hi, L.red);
+  lo = max(lo, lo_floor);
+  if (hi < lo) hi = lo;
+  const int nbits = hi > lo ? 32 - __clz(hi - lo) : 0;
+  const int lsh = 32 - nbits;
+  auto norm = [&](unsigned long long raw) -> unsigned long long {
+    if (raw == 0ull) return 0ull;
+    const uint32_t sk = (uint32_t)(raw >> 32);
+    if (sk < lo) return 0ull;
+    return ((((unsigned long long)(sk - lo)) << 32) | (raw & 0xFFFFFFFFull)) << lsh;
+  };
+  unsigned long long prefix = 0ull;
+  int need = k, want = k;
+  bool exact = false;
+  for (int pass = 0; pass < 8 && !exact; ++pass) {
+    const int shift = 56 - 8 * pass;
+    L.hist[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < RC; ++u) {
+      const unsigned long long key = norm(rk[u]);
+      const bool match = pass == 0 ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+      if (match && key != 0ull) atomicAdd(&L.hist[(int)((key >> shift) & 255ull)], 1);
+    }
+    __syncthreads();
+    int above;
+    const int b = find_bin(L.hist, L.scan, need, &above, L.res);
+    if (pass == 0) want = need;  // clamped to the live keys
+    need -= above;
+    prefix |= (unsigned long long)b << shift;
+    exact = L.hist[b] == need;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) L.n_out = 0;
+  for (int i = threadIdx.x; i < kpad; i += SL_THREADS) outbuf[i] = 0ull;
+  __syncthreads();
+  if (want > 0) {
+#pragma unroll
+    for (int u = 0; u < RC; ++u) {
+      const unsigned long long key = norm(rk[u]);
+      if (key >= prefix && key != 0ull) {
+        const int p = atomicAdd(&L.n_out, 1);
+        if (p < kpad) outbuf[p] = rk[u];
+      }
+    }
+  }
+  __syncthreads();
+  return want;
+}
+
+struct SlicedArgs {
+  const float* vals;        // [B][cap]
+  const int32_t* idxs;      // [B][cap]
+  int32_t* cnt;             // [B][CNT_STRIDE]: [0] list length, [1] ticket of the threshold form, [2] ticket of the select form
+  int64_t cap;
+  int n_slots;              // threshold form: entries [0, n_slots) are the sample scores
+  int k, kpad, NS;
+  int32_t idx_offset;
+  float* thr;               // threshold form: out; select form: in (lower bound of the live range)
+  const float* sub;         // threshold form, may be null: thr[q] = value - sub[q]
+  unsigned long long* part; // [B][NS][kpad]
+  float* out_val;
+  int32_t* out_idx;
+  int32_t* status;
+};
+
+template <bool THR>
+__global__ __launch_bounds__(SL_THREADS) void sim_sliced_select_kernel(const SlicedArgs a) {
+  __shared__ SelLds L;
+  __shared__ __attribute__((aligned(16))) unsigned long long outbuf[SL_KPAD_MAX];
+  const int q = blockIdx.x / a.NS, s = blockIdx.x % a.NS, tid = threadIdx.x;
+  int count;
+  if (THR) {
+    count = a.n_slots;
+  } else {
+    const int c = a.cnt[(int64_t)q * CNT_STRIDE];
+    count = c < (int)a.cap ? c : (int)a.cap;
+  }
+  const int per = (count + a.NS - 1) / a.NS;  // <= SL_RC * SL_THREADS by the launcher's choice of NS
+  const int i0 = s * per, i1 = min(count, i0 + per);
+  const float* v = a.vals + (int64_t)q * a.cap;
+  const int32_t* ix = a.idxs + (int64_t)q * a.cap;
+  unsigned long long rk[SL_RC];
+#pragma unroll
+  for (int u = 0; u < SL_RC; ++u) {
+    const int i = i0 + tid + u * SL_THREADS;
+    unsigned long long raw = 0ull;
+    if (i < i1) {
+      const float x = v[i];
+      if (THR) {
+        if (x > -INFINITY) raw = ((unsigned long long)fkey(x) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+      } else {
+        const int32_t id = ix[i];
+        if (id >= 0) raw = ((unsigned long long)fkey(x) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+      }
+    }
+    rk[u] = raw;
+  }
+  const uint32_t floor_key = (!THR && a.thr) ? fkey(a.thr[q]) : 0u;
+  block_select_keys<SL_RC>(rk, a.k, a.kpad, floor_key, L, outbuf);
+  // publish this slice's keys write-through, then the ticket
+  unsigned long long* mine = a.part + ((int64_t)q * a.NS + s) * a.kpad;
+  if (tid < a.kpad) {
+    const unsigned long long key = outbuf[tid];
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 w;
+    w[0] = (unsigned int)(key & 0xFFFFFFFFull), w[1] = (unsigned int)(key >> 32);
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(mine, 0, a.kpad * 8, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b64(w, dst, tid * 8, 0, 16);  // aux 16 = sc1: write-through
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int32_t* ticket = a.cnt + (int64_t)q * CNT_STRIDE + (THR ? 1 : 2);
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    L.last = t == a.NS - 1;
+    if (L.last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // one lane: drops this CU's stale L1 lines of `part`
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!L.last) return;  // uniform
+  // ---- the last arriver of query q: NS x kpad keys -> top-k
+  const unsigned long long* all = a.part + (int64_t)q * a.NS * a.kpad;
+  const int n_all = a.NS * a.kpad;  // <= SL_RC * SL_THREADS
+#pragma unroll
+  for (int u = 0; u < SL_RC; ++u) {
+    const int i = tid + u * SL_THREADS;
+    rk[u] = i < n_all ? all[i] : 0ull;
+  }
+  const int want = block_select_keys<SL_RC>(rk, a.k, a.kpad, 0u, L, outbuf);
+  if (THR) {
+    // the k-th largest score = the smallest selected key's score (fewer than k live entries: the smallest of all; none: -inf)
+    unsigned long long m = tid < want ? outbuf[tid] : ~0ull;  // want <= kpad <= 128 <= SL_THREADS
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(m, off);
+      m = o < m ? o : m;
+    }
+    if ((tid & 63) == 0) reinterpret_cast<unsigned long long*>(L.hist)[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned long long* w4 = reinterpret_cast<const unsigned long long*>(L.hist);
+      unsigned long long mm = w4[0];
+      for (int i = 1; i < SL_THREADS / 64; ++i) mm = w4[i] < mm ? w4[i] : mm;
+      const float t = want > 0 ? fkey_inv((uint32_t)(mm >> 32)) : -INFINITY;
+      a.thr[q] = a.sub ? t - a.sub[q] : t;
+      a.cnt[(int64_t)q * CNT_STRIDE] = a.n_slots;  // survivors of the filter pass are appended behind the sample block
+      a.cnt[(int64_t)q * CNT_STRIDE + 1] = 0;      // both tickets ready for their next use (the select form's: this call)
+      a.cnt[(int64_t)q * CNT_STRIDE + 2] = 0;
+    }
+    return;
+  }
+  wave0_bitonic_desc(outbuf, a.kpad);
+  __syncthreads();
+  for (int i = tid; i < a.k; i += SL_THREADS) {
+    const unsigned long long key = outbuf[i];
+    float val = -INFINITY;
+    int32_t id = -1;
+    if (i < want && key != 0ull) {
+      val = fkey_inv((uint32_t)(key >> 32));
+      id = (int32_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) + a.idx_offset;
+    }
+    a.out_val[(int64_t)q * a.k + i] = val;
+    a.out_idx[(int64_t)q * a.k + i] = id;
+  }
+  if (tid == 0) {
+    const int c = a.cnt[(int64_t)q * CNT_STRIDE];
+    if (a.status) a.status[q] = c > (int)a.cap ? 1 : 0;  // list overflowed: result is a subset's top-k
+    a.cnt[(int64_t)q * CNT_STRIDE + 2] = 0;
+  }
+}
+
+// slices for a list of up to `len` entries: ~1 024 entries (4 per thread) each, at most SL_NS_MAX; 0 = not served
+static int sliced_ns(int64_t len, int kpad) {
+  if (kpad > SL_KPAD_MAX || len > (int64_t)SL_NS_MAX * SL_RC * SL_THREADS) return 0;
+  int ns = (int)((len + 1023) / 1024);
+  const int need = (int)((len + SL_RC * SL_THREADS - 1) / (SL_RC * SL_THREADS));
+  if (ns < need) ns = need;
+  if (ns < 1) ns = 1;
+  if (ns > SL_NS_MAX) ns = SL_NS_MAX;
+  while ((int64_t)ns * kpad > SL_RC * SL_THREADS) --ns;  // the merge holds NS x kpad keys in registers
+  return ns >= need ? ns : 0;
+}
+
 static int next_pow2(int x) {
   int p = 1;
   while (p < x) p <<= 1;
@@ -481,15 +702,40 @@ int gdr::sim_topk_impl(const void* Q, int B, const void* D, int64_t N, int d, in
   int rc = stream_mode ? launch_sim_stream(D, N, Q, B, d, ep, bf16, stream) : launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
   if (rc) return rc;
   const int sel_threads = 1024;  // 1024 lanes per query: measured faster than 512 with twice the entries per lane (26.7 vs 37.7 us at 32 queries)
-  hipLaunchKernelGGL(sim_threshold_kernel, dim3(B), dim3(sel_threads), 0, stream, ep.cand_val, p.cap, (int)p.n_slots,
-                     k, thr, ep.cand_cnt, (const float*)nullptr);
-  GDR_CHECK_LAUNCH("sim_threshold_kernel");
+  const int kpad = next_pow2(k);
+  static const bool sliced_on = [] {
+    const char* e = getenv("GDR_SIM_SLICED");  // A/B knob: 0 = one workgroup per query for the threshold / select tails (the r05 form)
+    return e ? atoi(e) != 0 : true;
+  }();
+  // the stream kernels' sample pass zeroes the tickets: only their calls may take the sliced tails
+  SlicedArgs sa{};
+  sa.vals = ep.cand_val, sa.idxs = ep.cand_idx, sa.cnt = ep.cand_cnt, sa.cap = p.cap, sa.n_slots = (int)p.n_slots, sa.k = k, sa.kpad = kpad;
+  sa.idx_offset = idx_offset, sa.thr = thr, sa.sub = nullptr, sa.part = reinterpret_cast<unsigned long long*>(ws + p.off_part);
+  sa.out_val = out_val, sa.out_idx = out_idx, sa.status = status;
+  const int ns_thr = (stream_mode && sliced_on && B <= 32) ? sliced_ns(p.n_slots, kpad) : 0;
+  const int ns_sel = (stream_mode && sliced_on && B <= 32) ? sliced_ns(p.cap, kpad) : 0;
+  if (ns_thr) {
+    sa.NS = ns_thr;
+    ProfScope prof(PROF_SELECT, 0.0, stream);
+    hipLaunchKernelGGL(sim_sliced_select_kernel<true>, dim3(B * ns_thr), dim3(SL_THREADS), 0, stream, sa);
+    GDR_CHECK_LAUNCH("sim_sliced_select_kernel(threshold)");
+  } else {
+    hipLaunchKernelGGL(sim_threshold_kernel, dim3(B), dim3(sel_threads), 0, stream, ep.cand_val, p.cap, (int)p.n_slots,
+                       k, thr, ep.cand_cnt, (const float*)nullptr);
+    GDR_CHECK_LAUNCH("sim_threshold_kernel");
+  }
   if (p.stride > 1) {
     ep.mode = 2;
     rc = stream_mode ? launch_sim_stream(D, N, Q, B, d, ep, bf16, stream) : launch_sim_gemm(D, N, Q, B, d, ep, bf16, stream);
     if (rc) return rc;
   }
-  const int kpad = next_pow2(k);
+  if (ns_sel) {
+    sa.NS = ns_sel;
+    ProfScope prof(PROF_SELECT, 0.0, stream);
+    hipLaunchKernelGGL(sim_sliced_select_kernel<false>, dim3(B * ns_sel), dim3(SL_THREADS), 0, stream, sa);
+    GDR_CHECK_LAUNCH("sim_sliced_select_kernel(select)");
+    return GDR_OK;
+  }
   hipLaunchKernelGGL(topk_select_kernel<false>, dim3(B), dim3(sel_threads), kpad * sizeof(unsigned long long), stream,
                      ep.cand_val, ep.cand_idx, ep.cand_cnt, p.cap, 1, B, k, kpad, idx_offset, (const float*)thr, out_val,
                      out_idx, status, 0, 1);

@@ -116,8 +116,8 @@ def test_latency_mode_filter_lists_local_full_and_direct_agree():
     (workgroup, query).  The lists are an unordered set until the select pass sorts them by (score, id), so the result must be
     bit-identical whether every survivor goes through LDS (default), the LDS lists overflow and the rest is appended directly
     (16 entries per query: the expected load is above that), or LDS is not used at all (0)."""
-    def run(v):
-        r = subprocess.run([sys.executable, "-c", SIM_CHILD, ROOT], env=dict(os.environ, GDR_SIM_LOCAL_LIST=v),
+    def run(v, **extra):
+        r = subprocess.run([sys.executable, "-c", SIM_CHILD, ROOT], env=dict(os.environ, GDR_SIM_LOCAL_LIST=v, **extra),
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
@@ -125,6 +125,10 @@ def test_latency_mode_filter_lists_local_full_and_direct_agree():
     assert all(v["status"] == 0 for v in base.values())
     assert run("16") == base
     assert run("0") == base
+    # r06: the threshold and select tails of these calls run SLICED (sim_sliced_select_kernel: a query's list cut into <= 16 slices, one
+    # workgroup each, the last arriver of a query merges the slices' top-k keys); with one workgroup per query (the r05 kernels,
+    # GDR_SIM_SLICED=0) the result must be the same bits — keys are distinct, a top-k set does not depend on who arrives last
+    assert run("192", GDR_SIM_SLICED="0") == base
 
 
 BF16_CHILD = r"""
