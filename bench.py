@@ -522,8 +522,10 @@ def stages(dev, cfg, D, D_dev, a):
     # ---- the passage side of the path: BERT/DPR doc tower, bert-base, 256 passages x 128 tokens, fp32
     from gdr_amd.modeling import EncoderModel
     bc = synth.bert_config(False)
-    tower = EncoderModel.from_state_dict(bc, synth.make_bert_state_dict(bc), dev)
+    bsd = synth.make_bert_state_dict(bc)
+    tower = EncoderModel.from_state_dict(bc, bsd, dev)
     pids, pmask = synth.make_tokens(256, L=128, vocab_hi=bc["vocab_size"], seed=3, min_len=32)
+    live = int(pmask.sum())
     pids, pmask = torch.from_numpy(pids).to(dev), torch.from_numpy(pmask).to(dev)
     t = timed(lambda: tower(passage={"input_ids": pids, "attention_mask": pmask}), reps=5, warm=2)
     Lp, nl, dff, dm = 128, bc["num_layers"], bc["d_ff"], bc["hidden_size"]
@@ -531,7 +533,25 @@ def stages(dev, cfg, D, D_dev, a):
     out["doc_tower_bert_base_L128"] = {"ms_per_256_passages": t * 1e3, "passages_per_s": 256 / t, "gflop": gflop,
                                        "tflops": gflop / t / 1e3, "frac_of_f32_mfma_peak": gflop / t / 1e3 / F32_MFMA_PEAK_TFLOPS,
                                        "corpus_320k_embed_s": 320000 / (256 / t),
-                                       "note": "padded form (every one of the 128 positions computed); CLS -> pooler"}
+                                       "note": "padded form (every one of the 128 positions computed); CLS -> pooler; passage lengths "
+                                               "uniform 32-128 tokens"}
+    # r06: the ragged form (PAD rows not computed, last block on the CLS rows; pooled output bit-identical) and the bf16 precision mode
+    # (ragged; bf16 linear operands + bf16-MFMA attention, fp32 accumulate / norms / residual stream) on the same 256 passages
+    tower.ragged = True
+    tr = timed(lambda: tower.bert.forward(pids, pmask, want_hidden=False, ragged=True, live_rows_hint=live)[1], reps=5, warm=2)
+    gflop_live = (live * nl * 2 * (4 * dm * dm + 2 * dm * dff)) / 1e9     # linears over the live rows (the last block's CLS tail not subtracted)
+    out["doc_tower_bert_base_L128"]["ragged_f32"] = {
+        "ms_per_256_passages": tr * 1e3, "passages_per_s": 256 / tr, "live_token_rows": live, "of_rows": 256 * Lp,
+        "linear_gflop_live_rows": gflop_live, "frac_of_f32_mfma_peak_live_linears": gflop_live / tr / 1e3 / F32_MFMA_PEAK_TFLOPS,
+        "corpus_320k_embed_s": 320000 / (256 / tr)}
+    tower16 = EncoderModel.from_state_dict(bc, bsd, dev, dtype=torch.bfloat16)
+    t16 = timed(lambda: tower16.bert.forward(pids, pmask, want_hidden=False, live_rows_hint=live)[1], reps=5, warm=2)
+    out["doc_tower_bert_base_L128"]["ragged_bf16"] = {
+        "ms_per_256_passages": t16 * 1e3, "passages_per_s": 256 / t16, "live_token_rows": live,
+        "frac_of_bf16_mfma_peak_live_linears": gflop_live / t16 / 1e3 / BF16_MFMA_PEAK_TFLOPS,
+        "corpus_320k_embed_s": 320000 / (256 / t16),
+        "note": "parity: tests/test_gpu_decode.py::test_doc_tower_bf16_mode_vs_oracle_emulation (the build's own bf16 emulation; unpinned)"}
+    del tower16
     del tower
     torch.cuda.empty_cache()
     # ---- config C5 on this GPU (1M x 768 bf16 corpus, 512 queries, beam 30, bf16 linears): `--workload c5` for 3 steps, with its
@@ -664,6 +684,8 @@ def stages_summary(st):
             "sim_B1_prefilter_ms": st["similarity_topk_f32_prefilter"]["B1"]["ms"],
             "sim_B32_prefilter_ms": st["similarity_topk_f32_prefilter"]["B32"]["ms"],
             "doc_tower_frac_of_f32_mfma_peak": st["doc_tower_bert_base_L128"]["frac_of_f32_mfma_peak"],
+            "doc_tower_320k_embed_s": [st["doc_tower_bert_base_L128"][k_]["corpus_320k_embed_s"] if k_ else
+                                       st["doc_tower_bert_base_L128"]["corpus_320k_embed_s"] for k_ in ("", "ragged_f32", "ragged_bf16")],
             "B1_beam100_launches": g["B1_beam100"]["kernel_launches_per_call"],
             "B1_beam100_frac_of_floor_executed": g["B1_beam100"]["frac_of_floor_executed"],
             "c3_parity_violations": (lambda p_: None if p_ is None else p_["stage1_rows_violating"] + p_["stage2_rows_violating"])(

@@ -1097,7 +1097,7 @@ static const float* w_at(const float* W, size_t elems, bool bf16) {
 
 // ------------------------------------------------------------------------------------------ model workspace
 struct GenWs {
-  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, abf, abf2, img1, img2, c16a, c16b, f16a, f16b, fslab, fslab2, total;
+  size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, abf, abf2, img1, img2, c16a, c16b, f16a, f16b, fslab, total;
 };
 
 static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
@@ -1137,7 +1137,6 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
   // fused sub-blocks (decode_fused.hip, <= 1 024 rows): the partial slabs of one sub-block, per chain
   const bool fused = decode_fused_rt((int64_t)rows, (int)d, (int)inner, dm.d_kv) != 0;
   g.fslab = carve(o, fused ? decode_fused_slab_bytes((int64_t)rows, (int)d, dm.d_ff, dm.num_heads) : 0);
-  g.fslab2 = carve(o, fused ? decode_fused_slab_bytes((int64_t)rows, (int)d, w.adaptor_ff, w.adaptor_nhead) : 0);
   g.total = o;
   return g;
 }
@@ -1210,8 +1209,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
   float *dcache = F(g.dcache), *acache = F(g.acache), *crosskv = F(g.crosskv), *xd = F(g.xd), *xa = F(g.xa),
         *nx = F(g.nx), *ctx = F(g.ctx), *qc = F(g.qc), *ff = F(g.ff), *tmp = F(g.tmp), *A = F(g.A), *hl = F(g.hl),
-        *skw = F(g.splitk), *ctx2 = F(g.ctx2), *ff2 = F(g.ff2), *skw2 = F(g.splitk2), *qkv_c = F(g.qkv_c), *fslab = F(g.fslab),
-        *fslab2 = F(g.fslab2);
+        *skw = F(g.splitk), *ctx2 = F(g.ctx2), *ff2 = F(g.ff2), *skw2 = F(g.splitk2), *qkv_c = F(g.qkv_c), *fslab = F(g.fslab);
   void *abf = base + g.abf, *abf2 = base + g.abf2;
   Bf16Image img1{nullptr, bf16 ? base + g.img1 : nullptr}, img2{nullptr, bf16 ? base + g.img2 : nullptr};
   Bf16Image c16a{nullptr, bf16 ? base + g.c16a : nullptr}, c16b{nullptr, bf16 ? base + g.c16b : nullptr};

@@ -171,17 +171,20 @@ class EncoderModel:
     `encoder(passage={'input_ids','attention_mask'[, 'token_type_ids']}) -> pooler_output` of the DPR/BERT doc tower
     (modeling_dpr.py:146-191) when built with `bert=` (an ops.BertEncoderHandle)."""
 
-    def __init__(self, output=None, bert=None):
-        self.output, self.bert = output, bert
+    def __init__(self, output=None, bert=None, ragged=False):
+        self.output, self.bert, self.ragged = output, bert, ragged
 
     @staticmethod
-    def from_state_dict(bcfg, state_dict, device, prefix="ctx_encoder.bert_model."):
-        """state_dict with the reference's doc-tower keys; a Lightning checkpoint prefixes them `encoder.model.`."""
+    def from_state_dict(bcfg, state_dict, device, prefix="ctx_encoder.bert_model.", dtype=torch.float32, ragged=None):
+        """state_dict with the reference's doc-tower keys; a Lightning checkpoint prefixes them `encoder.model.`.
+        ragged: PAD positions of a padded batch are not computed (bit-identical pooled output in fp32; r06).  dtype=torch.bfloat16:
+        the bf16 precision mode (bf16 linear operands, fp32 accumulate), which exists in the ragged form only."""
         sd = state_dict.get("state_dict", state_dict)
         lp = "encoder.model."
         if any(k.startswith(lp) for k in sd):
             sd = {k[len(lp):]: v for k, v in sd.items() if k.startswith(lp)}
-        return EncoderModel(bert=ops.BertEncoderHandle(bcfg, sd, device, prefix))
+        ragged = (dtype == torch.bfloat16) if ragged is None else ragged
+        return EncoderModel(bert=ops.BertEncoderHandle(bcfg, sd, device, prefix, dtype=dtype), ragged=ragged)
 
     def __call__(self, passage=None, query_enc=None):
         if passage is not None:
@@ -189,7 +192,7 @@ class EncoderModel:
                 raise _ffi.GdrError("EncoderModel was built without doc-tower weights (use EncoderModel.from_state_dict)")
             p = {k: v.view(-1, v.size(-1)) for k, v in passage.items()}              # main_models.py:81-82
             _, pooled = self.bert.forward(p["input_ids"], p.get("attention_mask"), p.get("token_type_ids"),
-                                          want_hidden=False)
+                                          want_hidden=False, ragged=self.ragged)
             return pooled
         return self.encode_query(query_enc)
 

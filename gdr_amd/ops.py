@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/gdr_hip.h).  Inputs/outputs are torch CUDA tensors used
 purely as device buffers; all arithmetic happens in libgdr_hip.so."""
 import ctypes as C
+import math
 
 import torch
 
@@ -490,10 +491,16 @@ class T5EncoderHandle:
 
 
 class BertEncoderHandle:
-    """Device-resident doc-tower weights (DPRContextEncoder / BertModel keys) + pointer table."""
+    """Device-resident doc-tower weights (DPRContextEncoder / BertModel keys) + pointer table.
+    dtype=torch.bfloat16 selects the bf16 precision mode (config C5's corpus is bf16): the linear weights are rounded to bf16 on the
+    device, the attention's 1/sqrt(dh) is folded into the q rows of wqkv / bqkv (exact: a power of two at dh = 64), and forward()
+    runs gdr_bert_encoder_forward_ragged_bf16 — the packed form is the only bf16 form."""
 
-    def __init__(self, bcfg, sd, device, prefix="ctx_encoder.bert_model."):
-        self.bcfg, self.device = bcfg, device
+    def __init__(self, bcfg, sd, device, prefix="ctx_encoder.bert_model.", dtype=torch.float32):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("BertEncoderHandle: dtype must be float32 or bfloat16")
+        self.bcfg, self.device, self.dtype = bcfg, device, dtype
+        bf = dtype == torch.bfloat16
         keep = []
 
         def dev(t):
@@ -501,6 +508,21 @@ class BertEncoderHandle:
             keep.append(t)
             return t
 
+        def lin(t):                                      # a linear's weight: bf16 copy in the bf16 mode
+            t = dev(t)
+            if bf:
+                keep.pop()
+                t = to_bf16(t)
+                keep.append(t)
+            return t
+
+        d, H = bcfg["hidden_size"], bcfg["num_heads"]
+        qs = 1.0
+        if bf:
+            dh = d // H
+            qs = float(dh) ** -0.5
+            if d % H or 2.0 ** round(math.log2(qs)) != qs:
+                raise _ffi.GdrError(f"BertEncoderHandle(bf16): head width {dh} — the scale fold needs 1/sqrt(dh) to be a power of two")
         e = prefix + "embeddings."
         self.word, self.pos = dev(sd[e + "word_embeddings.weight"]), dev(sd[e + "position_embeddings.weight"])
         self.type = dev(sd[e + "token_type_embeddings.weight"])
@@ -510,13 +532,14 @@ class BertEncoderHandle:
         for i in range(nl):
             p = f"{prefix}encoder.layer.{i}."
             L = self._layers[i]
-            L.wqkv = dev(torch.cat([sd[p + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0)).data_ptr()
-            L.bqkv = dev(torch.cat([sd[p + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0)).data_ptr()
-            L.wo, L.bo = dev(sd[p + "attention.output.dense.weight"]).data_ptr(), dev(sd[p + "attention.output.dense.bias"]).data_ptr()
+            wq, bq = sd[p + "attention.self.query.weight"] * qs, sd[p + "attention.self.query.bias"] * qs
+            L.wqkv = lin(torch.cat([wq] + [sd[p + f"attention.self.{n}.weight"] for n in ("key", "value")], 0)).data_ptr()
+            L.bqkv = dev(torch.cat([bq] + [sd[p + f"attention.self.{n}.bias"] for n in ("key", "value")], 0)).data_ptr()
+            L.wo, L.bo = lin(sd[p + "attention.output.dense.weight"]).data_ptr(), dev(sd[p + "attention.output.dense.bias"]).data_ptr()
             L.ln1_w = dev(sd[p + "attention.output.LayerNorm.weight"]).data_ptr()
             L.ln1_b = dev(sd[p + "attention.output.LayerNorm.bias"]).data_ptr()
-            L.wi, L.bi = dev(sd[p + "intermediate.dense.weight"]).data_ptr(), dev(sd[p + "intermediate.dense.bias"]).data_ptr()
-            L.wo2, L.bo2 = dev(sd[p + "output.dense.weight"]).data_ptr(), dev(sd[p + "output.dense.bias"]).data_ptr()
+            L.wi, L.bi = lin(sd[p + "intermediate.dense.weight"]).data_ptr(), dev(sd[p + "intermediate.dense.bias"]).data_ptr()
+            L.wo2, L.bo2 = lin(sd[p + "output.dense.weight"]).data_ptr(), dev(sd[p + "output.dense.bias"]).data_ptr()
             L.ln2_w, L.ln2_b = dev(sd[p + "output.LayerNorm.weight"]).data_ptr(), dev(sd[p + "output.LayerNorm.bias"]).data_ptr()
         self._keep = keep
         self.struct = _ffi.GdrBertWeights(self.word.shape[0], bcfg["hidden_size"], bcfg["num_heads"], bcfg["d_ff"], nl,
@@ -525,17 +548,33 @@ class BertEncoderHandle:
                                           self.eln_b.data_ptr(), self._layers)
         self.ws = Workspace(device)
 
-    def forward(self, input_ids, attention_mask=None, token_type_ids=None, want_hidden=True):
+    def forward(self, input_ids, attention_mask=None, token_type_ids=None, want_hidden=True, ragged=None, live_rows_hint=-1):
+        """Returns (sequence_output fp32[B,L,d] | None, pooled fp32[B,d]).
+        ragged=False: gdr_bert_encoder_forward — every position of every passage, as the reference computes them.
+        ragged=True : gdr_bert_encoder_forward_ragged — PAD rows are not computed (kept rows bit-identical, PAD rows of the returned
+        hidden states zero); with want_hidden=False only the CLS rows go through the last block.  Default: ragged for the bf16
+        mode (its only form), padded otherwise."""
         _need_cuda(input_ids, attention_mask, token_type_ids)
+        bf = self.dtype == torch.bfloat16
+        ragged = bf if ragged is None else ragged
+        if bf and not ragged:
+            raise _ffi.GdrError("BertEncoderHandle(bf16): the bf16 precision mode exists in the packed (ragged) form only")
         ids = input_ids.to(torch.int64).contiguous()
         B, L = ids.shape
         mask = (torch.ones_like(ids) if attention_mask is None else attention_mask.to(torch.int64)).contiguous()
         tt = None if token_type_ids is None else token_type_ids.to(torch.int64).contiguous()
-        need = lib().gdr_bert_encoder_workspace_bytes(C.byref(self.struct), B, L)
-        ws = self.ws.get(need)
         d = self.bcfg["hidden_size"]
         hid = torch.empty((B, L, d), dtype=torch.float32, device=ids.device) if want_hidden else None
         pooled = torch.empty((B, d), dtype=torch.float32, device=ids.device)
+        if ragged:
+            need = lib().gdr_bert_encoder_ragged_workspace_bytes(C.byref(self.struct), B, L)
+            ws = self.ws.get(need)
+            fn = lib().gdr_bert_encoder_forward_ragged_bf16 if bf else lib().gdr_bert_encoder_forward_ragged
+            check(fn(C.byref(self.struct), ptr(ids), ptr(mask), ptr(tt), B, L, ptr(hid), ptr(pooled), int(live_rows_hint), ptr(ws),
+                     ws.numel(), stream_ptr()), "gdr_bert_encoder_forward_ragged")
+            return hid, pooled
+        need = lib().gdr_bert_encoder_workspace_bytes(C.byref(self.struct), B, L)
+        ws = self.ws.get(need)
         check(lib().gdr_bert_encoder_forward(C.byref(self.struct), ptr(ids), ptr(mask), ptr(tt), B, L, ptr(hid), ptr(pooled),
                                              ptr(ws), ws.numel(), stream_ptr()), "gdr_bert_encoder_forward")
         return hid, pooled

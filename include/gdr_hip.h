@@ -359,6 +359,26 @@ size_t gdr_bert_encoder_workspace_bytes(const GdrBertWeights* w, int B, int L);
 int gdr_bert_encoder_forward(const GdrBertWeights* w, const int64_t* ids, const int64_t* mask,
                              const int64_t* token_type_ids, int B, int L, float* out_hidden, float* out_pooled,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* The same forward over the token rows that can reach the requested outputs (r06; the T5 side's gdr_t5_encoder_forward_ragged for the
+ * doc tower).  The reference pads a batch of passages to its longest member (Data_process/NQ_dataset/bert/bert.py:69-71) and computes
+ * every position (modeling_bert.py:210-285); PAD keys carry weight exp(-1e9 - max) = 0 and PAD rows never reach
+ * pooled = sequence_output[:, 0] (modeling_dpr.py:178-181).  Here the live rows are packed, attention runs per sequence on its own
+ * length, and a pooled-only call (out_hidden == NULL) carries only the CLS rows through the last block.  Kept rows are BIT-IDENTICAL to
+ * gdr_bert_encoder_forward; PAD rows of out_hidden are zero.  Masks that are not a prefix of ones keep all their positions.
+ * live_rows_hint: the number of kept rows if the caller knows it (-1 otherwise) — prices the profiler's flops, never a result input.
+ * Small batches / head widths other than 64 run the padded forward (same results). */
+size_t gdr_bert_encoder_ragged_workspace_bytes(const GdrBertWeights* w, int B, int L);
+int gdr_bert_encoder_forward_ragged(const GdrBertWeights* w, const int64_t* ids, const int64_t* mask,
+                                    const int64_t* token_type_ids, int B, int L, float* out_hidden, float* out_pooled,
+                                    int64_t live_rows_hint, void* workspace, size_t workspace_bytes, void* stream);
+/* ... in the bf16 precision mode (BASELINE config C5 keeps its corpus in bf16; the reference itself runs precision = 32): every linear
+ * weight pointer of `w` (wqkv, wo, wi, wo2) points to bf16 data (RNE of the fp32 tensor, gdr_cast_f32_bf16), biases / LayerNorm /
+ * embeddings stay fp32; bf16 operands, fp32 accumulate, fp32 residual stream and norms; q, k, v are emitted as bf16 for the bf16-MFMA
+ * attention.  The attention's 1/sqrt(dh) must be FOLDED INTO THE q ROWS of wqkv and bqkv by the caller (dh = 64: the factor 1/8 is a
+ * power of two, the fold is exact).  Needs head width 64 and d_model, d_ff multiples of 64.  Same workspace size. */
+int gdr_bert_encoder_forward_ragged_bf16(const GdrBertWeights* w, const int64_t* ids, const int64_t* mask,
+                                         const int64_t* token_type_ids, int B, int L, float* out_hidden, float* out_pooled,
+                                         int64_t live_rows_hint, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Docid beam decode — replaces `_generate_beam_search` (transformers/generation_utils.py:629-921, with

@@ -18,8 +18,16 @@ def gelu(x):
     return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
-def bert_forward(sd, bcfg, input_ids, attention_mask, token_type_ids=None):
-    """Returns (sequence_output [B,L,d], pooled [B,d])."""
+def _r16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def bert_forward(sd, bcfg, input_ids, attention_mask, token_type_ids=None, bf16=False):
+    """Returns (sequence_output [B,L,d], pooled [B,d]).
+    bf16=True emulates the rounding points of gdr_bert_encoder_forward_ragged_bf16 (the reference has no such mode: this is the
+    build's own definition of it, "parity unpinned"): every linear rounds its activation and weight operands to bf16 (RNE) and
+    accumulates in fp32; q, k, v are emitted as bf16 (q already scaled by 1/sqrt(dh), an exact power of two at dh = 64);
+    embeddings, biases, LayerNorm, softmax and the residual stream stay fp32."""
     d, H, eps = bcfg["hidden_size"], bcfg["num_heads"], bcfg["eps"]
     dh = d // H
     B, L = input_ids.shape
@@ -34,16 +42,26 @@ def bert_forward(sd, bcfg, input_ids, attention_mask, token_type_ids=None):
     def heads(t):
         return t.view(B, L, H, dh).permute(0, 2, 1, 3)
 
+    def lin(a, w):
+        return (_r16(a) @ _r16(w).T) if bf16 else a @ w.T
+
+    sc = 1.0 / math.sqrt(dh)
     for i in range(bcfg["num_layers"]):
         p = f"{P}encoder.layer.{i}."
-        q = heads(x @ sd[p + "attention.self.query.weight"].T + sd[p + "attention.self.query.bias"])
-        k = heads(x @ sd[p + "attention.self.key.weight"].T + sd[p + "attention.self.key.bias"])
-        v = heads(x @ sd[p + "attention.self.value.weight"].T + sd[p + "attention.self.value.bias"])
-        s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh) + ext
+        if bf16:   # the scale is folded into the q rows of the weight and the bias before the weight is rounded
+            q = heads(_r16(lin(x, sd[p + "attention.self.query.weight"] * sc) + sd[p + "attention.self.query.bias"] * sc))
+            k = heads(_r16(lin(x, sd[p + "attention.self.key.weight"]) + sd[p + "attention.self.key.bias"]))
+            v = heads(_r16(lin(x, sd[p + "attention.self.value.weight"]) + sd[p + "attention.self.value.bias"]))
+            s = torch.matmul(q, k.transpose(-1, -2)) + ext
+        else:
+            q = heads(x @ sd[p + "attention.self.query.weight"].T + sd[p + "attention.self.query.bias"])
+            k = heads(x @ sd[p + "attention.self.key.weight"].T + sd[p + "attention.self.key.bias"])
+            v = heads(x @ sd[p + "attention.self.value.weight"].T + sd[p + "attention.self.value.bias"])
+            s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh) + ext
         ctx = torch.matmul(torch.softmax(s, dim=-1), v).permute(0, 2, 1, 3).contiguous().view(B, L, d)
-        t = ctx @ sd[p + "attention.output.dense.weight"].T + sd[p + "attention.output.dense.bias"]
+        t = lin(ctx, sd[p + "attention.output.dense.weight"]) + sd[p + "attention.output.dense.bias"]
         x = F.layer_norm(t + x, (d,), sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], eps)
-        f = gelu(x @ sd[p + "intermediate.dense.weight"].T + sd[p + "intermediate.dense.bias"])
-        t = f @ sd[p + "output.dense.weight"].T + sd[p + "output.dense.bias"]
+        f = gelu(lin(x, sd[p + "intermediate.dense.weight"]) + sd[p + "intermediate.dense.bias"])
+        t = lin(f, sd[p + "output.dense.weight"]) + sd[p + "output.dense.bias"]
         x = F.layer_norm(t + x, (d,), sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], eps)
     return x, x[:, 0, :]

@@ -224,6 +224,66 @@ def test_doc_tower_vs_reference_golden(dev):
             np.testing.assert_allclose(hid[:, [1, 64, 127]].cpu().numpy(), g["base_rows"], rtol=tol, atol=tol)
 
 
+def test_doc_tower_ragged_form_is_bit_identical_to_the_padded_form(dev):
+    """gdr_bert_encoder_forward_ragged (r06): the reference pads a batch of passages to its longest member (bert.py:69-71) and BertModel
+    computes every position; PAD keys carry softmax weight exp(-1e9 - max) = 0 and PAD rows never reach pooled = hidden[:, 0].
+    The packed form computes the live rows only and, pooled-only, carries just the CLS rows through the last block: kept rows and the
+    pooled output must equal the padded form BIT FOR BIT, PAD rows of the returned hidden states are zero.  Lengths uniform 32-128;
+    one fully padded-out row pattern (mask not a prefix: keeps all positions) and the g10 goldens through the ragged entry too."""
+    from gdr_amd.modeling import EncoderModel
+    bc = synth.bert_config(False)
+    sd = synth.make_bert_state_dict(bc, seed=77)
+    enc = EncoderModel.from_state_dict(bc, sd, dev)
+    ids_n, mask_n = synth.make_tokens(48, L=128, vocab_hi=bc["vocab_size"], seed=9, min_len=32)
+    mask_n[5, 10] = 0                                    # not a prefix of ones: this sequence keeps every position and its mask
+    mask_n[7, :] = 1                                     # a full-length passage
+    ids, mask = torch.from_numpy(ids_n).to(dev), torch.from_numpy(mask_n).to(dev)
+    hp, pp = enc.bert.forward(ids, mask, ragged=False)
+    hr, pr = enc.bert.forward(ids, mask, ragged=True, live_rows_hint=int(mask_n.sum()))
+    _, po = enc.bert.forward(ids, mask, ragged=True, want_hidden=False)
+    assert torch.equal(pr, pp) and torch.equal(po, pp), "pooled output of the ragged form differs from the padded form"
+    keep = torch.from_numpy(mask_n != 0).to(dev)
+    keep[5, :] = True
+    assert torch.equal(hr[keep], hp[keep])
+    assert int((hr[~keep] != 0).sum()) == 0
+    assert float(hp[~keep].abs().max()) > 0             # the padded form did compute those rows
+    g = golden("g10_doc_tower")
+    for name, tiny, tol in (("tiny", True, 1e-4), ("base", False, 2e-4)):
+        bcg = synth.bert_config(tiny)
+        e2 = EncoderModel.from_state_dict(bcg, synth.make_bert_state_dict(bcg, seed=int(g["seed"])), dev, ragged=True)
+        pooled = e2(passage={"input_ids": torch.from_numpy(g[name + "_ids"]).to(dev),
+                             "attention_mask": torch.from_numpy(g[name + "_mask"]).to(dev)})
+        np.testing.assert_allclose(pooled.cpu().numpy(), g[name + "_pooled"], rtol=tol, atol=tol)
+
+
+def test_doc_tower_bf16_mode_vs_oracle_emulation(dev):
+    """gdr_bert_encoder_forward_ragged_bf16 (r06; config C5 keeps its corpus in bf16, the reference has no bf16 mode — parity is against the
+    build's own statement of the rounding points, oracle/bert_ref.bert_forward(bf16=True): "parity unpinned", tolerances measured and
+    written here).  bert-base, 8 passages of 32-128 tokens: pooled embeddings within 3e-2 of the emulation (mean |diff| <= 4e-3;
+    what remains is the bf16 probabilities of the bf16-MFMA attention and fp32 summation order) and within 1.5e-1 of the fp32 tower;
+    the cosine between bf16 and fp32 embeddings >= 0.9995 for every passage."""
+    from gdr_amd.modeling import EncoderModel
+    from oracle import bert_ref
+    bc = synth.bert_config(False)
+    sd = synth.make_bert_state_dict(bc, seed=77)
+    ids_n, mask_n = synth.make_tokens(8, L=128, vocab_hi=bc["vocab_size"], seed=10, min_len=32)
+    ids, mask = torch.from_numpy(ids_n).to(dev), torch.from_numpy(mask_n).to(dev)
+    e16 = EncoderModel.from_state_dict(bc, sd, dev, dtype=torch.bfloat16)
+    p16 = e16(passage={"input_ids": ids, "attention_mask": mask}).cpu()
+    h16, p16b = e16.bert.forward(ids, mask)                              # with hidden states: the full last block
+    assert float((p16b.cpu() - p16).abs().max()) < 1e-5
+    assert int((h16[torch.from_numpy(mask_n == 0).to(dev)] != 0).sum()) == 0
+    _, emu = bert_ref.bert_forward(sd, bc, torch.from_numpy(ids_n), torch.from_numpy(mask_n), bf16=True)
+    _, ref = bert_ref.bert_forward(sd, bc, torch.from_numpy(ids_n), torch.from_numpy(mask_n))
+    d_emu, d_ref = (p16 - emu).abs(), (p16 - ref).abs()
+    print(f"bf16 doc tower: max |gpu - emulation| {float(d_emu.max()):.3e} (mean {float(d_emu.mean()):.3e}); "
+          f"max |gpu - fp32| {float(d_ref.max()):.3e}; emulation vs fp32 {float((emu - ref).abs().max()):.3e}")
+    assert float(d_emu.max()) <= 3e-2 and float(d_emu.mean()) <= 4e-3
+    assert float(d_ref.max()) <= 1.5e-1
+    cos = torch.nn.functional.cosine_similarity(p16, ref, dim=1)
+    assert float(cos.min()) >= 0.9995, cos
+
+
 @pytest.mark.parametrize("case", ["a", "b", "c"])
 def test_trie_constrained_beam_vs_reference_golden(dev, case):
     """Opt-in trie mode on the device beam kernels vs the reference's generation_utils_previous."""

@@ -29,6 +29,12 @@ def main():
     ap.add_argument("--idx", type=int, default=0)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--padded", action="store_true",
+                    help="compute every position of every padded batch as the reference does (default: the ragged form — PAD rows "
+                         "are not computed, the embeddings are bit-identical)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16: the bf16 precision mode of the doc tower (bf16 linear operands, fp32 accumulate; ragged form only) — "
+                         "for a corpus that is kept in bf16 anyway (config C5)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     torch.set_grad_enabled(False)
@@ -37,7 +43,8 @@ def main():
     lo, hi = shard_bounds(ids.shape[0], a.partition_num, a.idx)        # bert.py:51-61 partitioning
     bc = synth.bert_config(False)
     sd = torch.load(a.weights, map_location="cpu") if a.weights else synth.make_bert_state_dict(bc)
-    enc = EncoderModel.from_state_dict(bc, sd, torch.device(a.device))
+    enc = EncoderModel.from_state_dict(bc, sd, torch.device(a.device), dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32,
+                                       ragged=not a.padded)
     out = np.empty((hi - lo, bc["hidden_size"]), dtype=np.float32)
     for s in range(lo, hi, a.batch):
         e = min(hi, s + a.batch)
