@@ -1008,6 +1008,45 @@ def main():
                   "linear_tflops": lin_tf, "linear_frac_of_f32_mfma_peak": lin_tf / F32_MFMA_PEAK_TFLOPS,
                   "linear_launches_timed": int(n_q[0])}
 
+    # ---- EXPLORATORY, beside the headline and never instead of it: the same step with every encoder linear in the
+    # split-bf16 form (gdr_t5_encoder_forward_ragged_split: fp32 operands carried as three bf16 planes, six bf16 MFMA products, fp32
+    # accumulate — the fp32 linear's error against float64, not its bits).  Its top-k lists are held to the fp32 step's by the top-k rule.
+    split = None
+    if world == 1 and not bf16 and ragged and not a.no_stages:
+        enc_s = ops.T5EncoderHandle(cfg, sd, dev, split=True)
+
+        def step_s():
+            _, pooled = enc_s.forward(ids, mask, want_hidden=False, ragged=True, live_rows_hint=live_rows)
+            return pooled, index.search(pooled, a.k, return_status=True)
+
+        for _ in range(max(1, a.warmup)):
+            step_s()
+        _ffi.check(lib.gdr_prof_enable(launches_per_step * a.steps + 16), "gdr_prof_enable")
+        fence(dist)
+        t0s = time.perf_counter()
+        for i in range(a.steps):
+            lib.gdr_prof_gate(1 if i % pe == 0 else 0)
+            p_s, out_s = step_s()
+        lib.gdr_prof_gate(1)
+        fence(dist)
+        dts = time.perf_counter() - t0s
+        n_s, ms_s, w_s = (C.c_int64 * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
+        _ffi.check(lib.gdr_prof_collect(n_s, ms_s, w_s), "gdr_prof_collect")
+        _, p_f = enc.forward(ids, mask, want_hidden=False, ragged=True, live_rows_hint=live_rows)
+        out_f = index.search(p_f, a.k, return_status=True)
+        ident, perm, bad_s = topk_parity(out_f[0].cpu().numpy(), out_f[1].cpu().numpy(), out_s[0].cpu().numpy(), out_s[1].cpu().numpy())
+        lin_eq = w_s[0] / (ms_s[0] * 1e-3) / 1e12 if ms_s[0] > 0 else 0.0      # fp32-equivalent flops (2 M N K) per second
+        split = {"queries_per_s": a.batch * a.steps / dts, "ms_per_step": dts / a.steps * 1e3,
+                 "linear_fp32_equiv_tflops": lin_eq, "linear_bf16_mfma_tflops": 6.0 * lin_eq,
+                 "linear_frac_of_bf16_mfma_peak": 6.0 * lin_eq / BF16_MFMA_PEAK_TFLOPS,
+                 "pooled_max_abs_diff_vs_fp32": float((p_s - p_f).abs().max()), "pooled_mean_abs": float(p_f.abs().mean()),
+                 "topk_vs_fp32_step": {"rows": a.batch, "ids_identical_rows": ident, "permuted_slots_inside_1e-4_ties": perm,
+                                       "rows_violating_tie_rule": bad_s},
+                 "note": "encoder linears as 3 x bf16 planes (24 significand bits), 6 products on the bf16 MFMA path, fp32 accumulate; "
+                         "norms / attention / residual stream / similarity are the fp32 path's; tests: test_encoder_split_bf16_form_…"}
+        del enc_s
+        torch.cuda.empty_cache()
+
     total_q = a.batch * world * a.steps
     ms_per_step = dt / a.steps * 1e3
     n_prof_steps = len(range(0, a.steps, max(1, a.prof_every)))
@@ -1126,6 +1165,10 @@ def main():
                 detail["stages"]["c2_step_padded"] = padded
                 result["stages_summary"]["c2_padded_qps"] = padded["queries_per_s"]
                 result["stages_summary"]["c2_padded_linear_frac"] = padded["linear_frac_of_f32_mfma_peak"]
+            if split is not None:
+                detail["stages"]["c2_step_split_bf16"] = split
+                result["stages_summary"]["c2_split_bf16_qps"] = split["queries_per_s"]
+                result["stages_summary"]["c2_split_bf16_tie_rule_violations"] = split["topk_vs_fp32_step"]["rows_violating_tie_rule"]
             if pre is not None:
                 detail["stages"]["c2_step_bf16_prefilter"] = pre
                 detail["stages"]["c2_step_bf16_prefilter_note"] = (

@@ -11,6 +11,8 @@
 //                 pad mask (1-m)*-1e9 + fp32 softmax + PV                           (:384-413, :290-314)
 // The position bias is never materialised as a [B,H,L,L] tensor: the kernel re-derives it from the
 // [buckets,H] table (layer 0's, shared by all layers as in :790-795).
+#include <stdlib.h>
+
 #include "layers.h"
 
 namespace gdr {
@@ -405,6 +407,159 @@ static int ragged_impl(const GdrT5EncoderWeights* w, const int64_t* ids, const i
   return GDR_OK;
 }
 }  // namespace gdr
+
+// ------------------------------------------------------------------------------------------------ split form (r06, exploratory)
+// The ragged forward with every linear in the split-bf16 form (gemm_bf16.hip: fp32 operands carried as three bf16 planes, the six
+// leading products on the bf16 MFMA path, fp32 accumulate — the fp32 linear's error against float64, not its bits).  Everything
+// else — embedding, T5LayerNorm, attention (fp32 MFMA), residual stream, CLS tail — is the fp32 path's.  The linear weights of `w`
+// point to plane-form bf16 rows [N, gdr_split_row_elems(K)]; activations are split by their producers' followers
+// (split_f32_bf16x3_kernel) into one plane buffer.  Beside gdr_t5_encoder_forward_ragged, never instead of it.
+namespace gdr {
+// two plane buffers: one for the d_model / inner wide operands (normed rows, attention context), one for the d_ff wide ReLU output,
+// which the wi GEMM's epilogue writes while it still reads the first
+static size_t split_ws_a_bytes(const GdrT5Dims& dm, int64_t M) {
+  const int inner = dm.num_heads * dm.d_kv;
+  int ld = split_row_elems(dm.d_model);
+  if (split_row_elems(inner) > ld) ld = split_row_elems(inner);
+  return align_up((size_t)M * ld * 2, 256);
+}
+static size_t split_ws_bytes(const GdrT5Dims& dm, int64_t M) {
+  return split_ws_a_bytes(dm, M) + align_up((size_t)M * split_row_elems(dm.d_ff) * 2, 256);
+}
+
+static int ragged_split_impl(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L, float* out_hidden,
+                             float* out_pooled, int64_t live_rows_hint, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (B == 0) return GDR_OK;
+  GDR_CHECK_ARG(w && ids && mask && workspace && (out_hidden || out_pooled), "t5_encoder_split: null pointer");
+  const GdrT5Dims& dm = w->dims;
+  GDR_CHECK_ARG(B > 0 && L > 0 && L <= 128, "t5_encoder_split: B=%d L=%d (L must be in [1,128])", B, L);
+  GDR_CHECK_ARG(w->embed && w->rel_bias && w->final_ln && w->layers, "t5_encoder_split: null weight pointer");
+  const int d = dm.d_model, H = dm.num_heads, dk = dm.d_kv, inner = H * dk, dff = dm.d_ff;
+  GDR_CHECK_ARG(dk == 64 && d % 64 == 0 && inner % 64 == 0 && dff % 64 == 0,
+                "t5_encoder_split: needs d_kv = 64 and d_model, inner, d_ff multiples of 64 (the packed attention and the LDS-DMA linear)");
+  const int64_t M = (int64_t)B * L;
+  const EncWs ws = enc_ws(dm, M, true);
+  const RagWs rw = rag_ws(dm, B, L, ws.total);
+  const size_t planes_off = rw.total, total = planes_off + split_ws_bytes(dm, M);
+  if (workspace_bytes < total) {
+    set_error("t5_encoder_split: workspace %zu < required %zu", workspace_bytes, total);
+    return GDR_ENOSPC;
+  }
+  GDR_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "t5_encoder_split: workspace must be 256-byte aligned");
+  char* base = static_cast<char*>(workspace);
+  int rc;
+  int32_t* seq_len = reinterpret_cast<int32_t*>(base + rw.seq_len);
+  int32_t* seq_off = reinterpret_cast<int32_t*>(base + rw.seq_off);
+  int32_t* row_src = reinterpret_cast<int32_t*>(base + rw.row_src);
+  int64_t* rows_dev = reinterpret_cast<int64_t*>(base + rw.rows_total);
+  if ((rc = launch_pack_plan(mask, B, L, seq_len, seq_off, row_src, rows_dev, stream))) return rc;
+  float* h = reinterpret_cast<float*>(base + ws.off_h);
+  float* nx = reinterpret_cast<float*>(base + ws.off_nx);
+  float* qkv = reinterpret_cast<float*>(base + ws.off_qkv);
+  float* ctx = reinterpret_cast<float*>(base + ws.off_ctx);
+  float* ff = reinterpret_cast<float*>(base + ws.off_ff);
+  float* ctx_cls = reinterpret_cast<float*>(base + rw.ctx_cls);
+  float* h_cls = reinterpret_cast<float*>(base + rw.h_cls);
+  float* nx_cls = reinterpret_cast<float*>(base + rw.nx_cls);
+  float* ff_cls = reinterpret_cast<float*>(base + rw.ff_cls);
+  void* planes = base + planes_off;                                  // d_model / inner wide operands
+  void* planes_ff = base + planes_off + split_ws_a_bytes(dm, M);     // the d_ff wide ReLU output of wi
+  static const bool fuse_on = [] {
+    const char* e = getenv("GDR_SPLIT_FUSE");  // A/B knob: 0 = every operand split by a launch of its own (split_f32_bf16x3_kernel)
+    return e ? atoi(e) != 0 : true;
+  }();
+  // the split GEMM over plane rows P [rows, split_row_elems(K)]; out_planes: the output leaves as plane rows (row stride ldc elements)
+  auto gemm = [&](const void* P, const float* W, void* C, int64_t ldc, int64_t rows, const int64_t* md, int N, int K, int act,
+                  const float* residual, int out_planes) -> int {
+    const int ld = split_row_elems(K);
+    ProfScope prof(PROF_LINEAR, 2.0 * (double)(md && live_rows_hint >= 0 ? live_rows_hint : rows) * (double)N * (double)K, stream);
+    const int rc_ = launch_linear_bf16_glds(P, ld, W, ld, static_cast<float*>(C), ldc, rows, N, K, 0, residual != nullptr, act, nullptr, residual,
+                                            ldc, out_planes ? 2 : 0, stream, md, 1);
+    if (rc_ > 0) {
+      set_error("t5_encoder_split: shape not served by the LDS-DMA linear");
+      return GDR_EINVAL;
+    }
+    return rc_;
+  };
+  // one linear over `rows` fp32 rows (md: their device-side count, or null): split the operand into planes, then the split GEMM
+  auto linear = [&](const float* A, const float* W, float* C, int64_t ldc, int64_t rows, const int64_t* md, int N, int K, int act,
+                    const float* residual) -> int {
+    void* P = K == dff ? planes_ff : planes;
+    if (int rc_ = launch_split_f32_bf16x3(A, K, P, split_row_elems(K), rows, K, md, stream)) return rc_;
+    return gemm(P, W, C, ldc, rows, md, N, K, act, residual, 0);
+  };
+  // the wi GEMM's plane epilogue lives in the 256-row tile kernel, which serves >= 8 192 rows
+  const bool fuse = fuse_on && M >= 8192;
+  const int ld_d = split_row_elems(d), ld_ff = split_row_elems(dff);
+  if ((rc = launch_embed_packed(w->embed, ids, row_src, rows_dev, M, d, dm.vocab_size, h, stream))) return rc;
+  AttnArgs at{};
+  at.q = qkv, at.k = qkv + inner, at.v = qkv + 2 * inner, at.out = ctx;
+  at.ldq = at.ldk = at.ldv = 3 * inner, at.ldo = inner;
+  at.q_bstride = at.k_bstride = at.o_bstride = L;
+  at.B = B, at.H = H, at.dk = dk, at.Lq = L, at.Lk = L;
+  at.q_pos0 = 0, at.scale = 1.0f;
+  at.rel_bias = w->rel_bias, at.bidirectional = 1, at.num_buckets = dm.rel_buckets;
+  at.lut = make_bucket_lut(dm.rel_buckets / 2, dm.rel_max_distance);
+  at.key_mask = mask, at.mask_bstride = L, at.causal = 0, at.causal_neg_inf = 0;
+  at.kv_rows = nullptr, at.kv_group = 1;
+  at.seq_off = seq_off, at.seq_len = seq_len;
+  const bool pooled_only = out_hidden == nullptr;
+  for (int i = 0; i < dm.num_layers; ++i) {
+    const GdrT5EncLayer& ly = w->layers[i];
+    GDR_CHECK_ARG(ly.ln_attn && ly.wqkv && ly.wo && ly.ln_ff && ly.wi && ly.wo_ff, "t5_encoder_split: layer %d null weight", i);
+    if (fuse) {  // the norm writes the operand's planes itself (no fp32 copy, no split launch)
+      if ((rc = launch_rmsnorm_planes(h, ly.ln_attn, nullptr, planes, ld_d, rows_dev, M, d, dm.eps, stream))) return rc;
+      if ((rc = gemm(planes, ly.wqkv, qkv, 3 * inner, M, rows_dev, 3 * inner, d, 0, nullptr, 0))) return rc;
+    } else {
+      if ((rc = launch_rmsnorm_dev(h, ly.ln_attn, nx, rows_dev, M, d, dm.eps, stream))) return rc;
+      if ((rc = linear(nx, ly.wqkv, qkv, 3 * inner, M, rows_dev, 3 * inner, d, 0, nullptr))) return rc;
+    }
+    if ((rc = launch_attention(at, stream))) return rc;
+    if (pooled_only && i == dm.num_layers - 1) {
+      if ((rc = launch_gather_rows(ctx, seq_off, B, inner, ctx_cls, stream))) return rc;
+      if ((rc = launch_gather_rows(h, seq_off, B, d, h_cls, stream))) return rc;
+      if ((rc = linear(ctx_cls, ly.wo, h_cls, d, B, nullptr, d, inner, 0, h_cls))) return rc;
+      if ((rc = launch_rmsnorm(h_cls, ly.ln_ff, nx_cls, B, d, dm.eps, nullptr, 1, stream))) return rc;
+      if ((rc = linear(nx_cls, ly.wi, ff_cls, dff, B, nullptr, dff, d, 1, nullptr))) return rc;
+      if ((rc = linear(ff_cls, ly.wo_ff, h_cls, d, B, nullptr, d, dff, 0, h_cls))) return rc;
+      return launch_rmsnorm(h_cls, w->final_ln, out_pooled, B, d, dm.eps, nullptr, 1, stream);
+    }
+    if ((rc = linear(ctx, ly.wo, h, d, M, rows_dev, d, inner, 0, h))) return rc;
+    if (fuse) {  // norm -> planes; wi's ReLU epilogue writes the planes of wo_ff's operand
+      if ((rc = launch_rmsnorm_planes(h, ly.ln_ff, nullptr, planes, ld_d, rows_dev, M, d, dm.eps, stream))) return rc;
+      if ((rc = gemm(planes, ly.wi, planes_ff, ld_ff, M, rows_dev, dff, d, 1, nullptr, 1))) return rc;
+      if ((rc = gemm(planes_ff, ly.wo_ff, h, d, M, rows_dev, d, dff, 0, h, 0))) return rc;
+    } else {
+      if ((rc = launch_rmsnorm_dev(h, ly.ln_ff, nx, rows_dev, M, d, dm.eps, stream))) return rc;
+      if ((rc = linear(nx, ly.wi, ff, dff, M, rows_dev, dff, d, 1, nullptr))) return rc;
+      if ((rc = linear(ff, ly.wo_ff, h, d, M, rows_dev, d, dff, 0, h))) return rc;
+    }
+  }
+  if ((rc = launch_rmsnorm_dev(h, w->final_ln, nx, rows_dev, M, d, dm.eps, stream))) return rc;
+  if (out_pooled && (rc = launch_gather_rows(nx, seq_off, B, d, out_pooled, stream))) return rc;
+  if (out_hidden) {
+    if (hipMemsetAsync(out_hidden, 0, (size_t)M * d * sizeof(float), stream) != hipSuccess) {
+      set_error("t5_encoder_split: memset failed");
+      return GDR_EHIP;
+    }
+    if ((rc = launch_scatter_rows(nx, row_src, rows_dev, M, d, out_hidden, stream))) return rc;
+  }
+  return GDR_OK;
+}
+}  // namespace gdr
+
+extern "C" size_t gdr_t5_encoder_split_workspace_bytes(const GdrT5Dims* dims, int B, int L) {
+  if (!dims || B <= 0 || L <= 0) return 0;
+  const int64_t M = (int64_t)B * L;
+  return gdr::rag_ws(*dims, B, L, gdr::enc_ws(*dims, M, true).total).total + gdr::split_ws_bytes(*dims, M);
+}
+
+extern "C" int gdr_t5_encoder_forward_ragged_split(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L,
+                                                   float* out_hidden, float* out_pooled, int64_t live_rows_hint, void* workspace,
+                                                   size_t workspace_bytes, void* stream_) {
+  return gdr::ragged_split_impl(w, ids, mask, B, L, out_hidden, out_pooled, live_rows_hint, workspace, workspace_bytes,
+                                static_cast<hipStream_t>(stream_));
+}
 
 extern "C" int gdr_t5_encoder_forward_ragged(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B,
                                              int L, float* out_hidden, float* out_pooled, int64_t live_rows_hint,

@@ -29,6 +29,10 @@ struct Bf16GemmArgs {
   int has_bias, has_residual, act;  // act: 0 none, 1 relu, 2 gelu
   int out_bf16;
   const int64_t* m_dev;  // linear only, may be null: live row count on the device (<= M); tiles past it exit at once
+  // split form (r06, "fp32 carried as three bf16 planes"): split_k0 = K0 != 0 -> a row of A / W holds the planes [hi | mid | lo], K0
+  // elements each (lda, ldw >= 3 K0), and the contraction runs over K = 6 K0 virtual elements: block p of K0 pairs plane colA(p) of A
+  // with plane colW(p) of W — hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid, the six leading terms of (hi+mid+lo).(hi+mid+lo)
+  int split_k0;
   // EPI 3 (the decode head, see launch_linear_bf16_headdot): nothing is stored; per output row m and vocabulary entry c = n / dot_d
   // the tile leaves  sum_i (h[dot_rows[m]][i] * dot_scale) * (acc[m][c*dot_d + i] + dot_e[c][i])  over its 64 columns per wave in
   // dot_out[(m * (N / dot_d) + c) * (dot_d / 64) + (n % dot_d) / 64]
@@ -46,10 +50,25 @@ struct Bf16GemmArgs {
 
 __device__ __forceinline__ float gelu_erf_b(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Byte offsets of virtual K-tile kt (64 elements) inside a row of A resp. W: plain rows kt * 128; split rows (three planes of k0 elements):
+// block p = kt / (k0 / 64) reads plane {0,0,1,0,2,1}[p] of A and {0,1,0,2,0,1}[p] of W.  kt is wave-uniform: scalar arithmetic;
+// SPLIT is a template parameter of the kernels so that the plain forms keep their K loops untouched; inv = ceil(2^16 / (k0 / 64)).
+template <bool SPLIT>
+__device__ __forceinline__ void ktile_offsets(int kt, int split_k0, int inv, int& off_a, int& off_w) {
+  if (!SPLIT) {
+    off_a = off_w = kt * 128;
+    return;
+  }
+  const int nk0 = split_k0 >> 6;
+  const int p = (kt * inv) >> 16, k0 = kt - p * nk0;  // exact for kt < 6 * nk0 <= 6 * 1024
+  off_a = (((0x120100 >> (4 * p)) & 3) * split_k0 + k0 * 64) * 2;
+  off_w = (((0x102010 >> (4 * p)) & 3) * split_k0 + k0 * 64) * 2;
+}
+
 // BM = rows of A per tile: 128, or 64 for the linears of a few thousand rows (the decode legs of config C5: 1 920 beam rows x
 // N = 768 are 90 tiles of 128 x 128 on 256 CUs; 64-row tiles double the workgroups — the W operand is re-read twice as often,
 // which L2 absorbs at these sizes — and halve the accumulators, 32 x 64 per wave).  The similarity forms use 128.
-template <int EPI, int BM = 128>  // EPI: 0 linear, 1 similarity sample, 2 similarity filter, 3 linear whose output is only dotted with h
+template <int EPI, int BM = 128, bool SPLIT = false>  // EPI: 0 linear, 1 similarity sample, 2 similarity filter, 3 linear whose output is only dotted with h
 __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16GemmArgs g) {
   constexpr bool LIN = EPI == 0 || EPI == 3;
   static_assert(BM == 128 || (BM == 64 && LIN), "64-row tiles serve the linear forms only");
@@ -154,14 +173,16 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4b){0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K >> 6;
+  const int split_inv = SPLIT ? (65536 + (g.split_k0 >> 6) - 1) / (g.split_k0 >> 6) : 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int koff = kt * 128;
+    int koff, koff_w;
+    ktile_offsets<SPLIT>(kt, g.split_k0, split_inv, koff, koff_w);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < AI)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + koff),
                                          (__attribute__((address_space(3))) void*)(As + (wave * AI + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + koff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + koff_w),
                                        (__attribute__((address_space(3))) void*)(Bs + (wave * 4 + i) * 1024), 16, 0, 0);
     }
     __syncthreads();  // emits vmcnt(0): the DMA writes are complete and visible
@@ -349,7 +370,7 @@ constexpr int OFF_A_LO = 0, OFF_A_HI = HALF_BYTES, OFF_B_LO = 2 * HALF_BYTES, OF
 // BN = 256, or 192 (each wave column 48 wide: a "lo" half of two 16-column blocks and a "hi" half of one): the tile WIDTH is chosen
 // per launch so that the tile count quantises well on 256 CUs — 15 360 beam rows x N = 768 are 180 tiles of 256 x 256 (70 % of one
 // round) but 240 of 256 x 192 (94 %); N = 2 304: 540 tiles = 3 rounds at 70 % against 720 = 3 rounds at 94 %.  Same k order.
-template <int BN>
+template <int BN, bool SPLIT = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16GemmArgs g) {
   static_assert(BN == 256 || BN == 192, "tile width");
   constexpr int WCOLS = BN / 4;           // columns per wave column: 64 or 48
@@ -413,16 +434,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
   }
   const unsigned st_dst = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 2048;  // + i*1024 + half offset + buffer offset
   const unsigned st_dst1 = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024;  // the one-instruction half-tile (B hi, BN = 192)
-#define STAGE(src_, half_off_, buf_, kt_)                                                   \
+  // koff_: the K-tile's byte offset inside a row (plain form kt * 128; split form: KTile below — A's and W's plane schedules differ)
+#define STAGE(src_, half_off_, buf_, koff_)                                                 \
   {                                                                                         \
-    const int koff_ = (kt_) * 128;                                                          \
-    GLDS16(src_[0] + koff_, st_dst + (buf_)*BUF_BYTES + (half_off_));                       \
-    GLDS16(src_[1] + koff_, st_dst + (buf_)*BUF_BYTES + (half_off_) + 1024);                \
+    GLDS16(src_[0] + (koff_), st_dst + (buf_)*BUF_BYTES + (half_off_));                     \
+    GLDS16(src_[1] + (koff_), st_dst + (buf_)*BUF_BYTES + (half_off_) + 1024);              \
   }
-#define STAGE_BHI(buf_, kt_)                                                                \
+#define STAGE_BHI(buf_, koff_)                                                              \
   {                                                                                         \
-    if (NBH == 2) STAGE(b_hi_src, OFF_B_HI, buf_, kt_)                                      \
-    else GLDS16(b_hi_src[0] + (kt_) * 128, st_dst1 + (buf_)*BUF_BYTES + OFF_B_HI);          \
+    if (NBH == 2) STAGE(b_hi_src, OFF_B_HI, buf_, koff_)                                    \
+    else GLDS16(b_hi_src[0] + (koff_), st_dst1 + (buf_)*BUF_BYTES + OFF_B_HI);              \
   }
   // ---- fragment reads
   const int sw = (r16 >> 1) & 7;
@@ -470,24 +491,47 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
 #define WAIT_3HALVES() \
   { if (NBH == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
   const int nk = g.K >> 6;  // even (launcher)
+  // The K-tile walker: byte offsets (A row, W row) of K-tile `t`, advanced one tile at a time and parked on the last tile (the loop's
+  // clamped prefetches).  Plain form: t * 128 for both.  Split form: block p = t / nk0 pairs plane colA(p) of A with colW(p) of W; kept as
+  // running scalars (p, k0) — a division per staged half-tile cost the 8-phase loop 15 % (profiles/r06_split_bf16.txt).
+  struct KTile {
+    int t, p, k0, a, w;
+  } kw{0, 0, 0, 0, 0};
+  const int nk0 = SPLIT ? g.split_k0 >> 6 : nk;
+  auto k_next = [&]() {
+    if (kw.t + 1 >= nk) return;
+    ++kw.t;
+    if (!SPLIT) {
+      kw.a = kw.w = kw.t * 128;
+      return;
+    }
+    if (++kw.k0 == nk0) kw.k0 = 0, ++kw.p;
+    kw.a = (((0x120100 >> (4 * kw.p)) & 3) * g.split_k0 + kw.k0 * 64) * 2;
+    kw.w = (((0x102010 >> (4 * kw.p)) & 3) * g.split_k0 + kw.k0 * 64) * 2;
+  };
   // prologue: K-tile 0 whole, K-tile 1 without A_hi
   STAGE(b_lo_src, OFF_B_LO, 0, 0)
   STAGE(a_src[0], OFF_A_LO, 0, 0)
   STAGE_BHI(0, 0)
   STAGE(a_src[1], OFF_A_HI, 0, 0)
-  STAGE(b_lo_src, OFF_B_LO, 1, 1)
-  STAGE(a_src[0], OFF_A_LO, 1, 1)
-  STAGE_BHI(1, 1)
+  k_next();
+  int a_o1 = kw.a;  // A offset of K-tile kt + 1 (its A_hi half is staged in phase 1)
+  STAGE(b_lo_src, OFF_B_LO, 1, kw.w)
+  STAGE(a_src[0], OFF_A_LO, 1, kw.a)
+  STAGE_BHI(1, kw.w)
   WAIT_3HALVES()
   BAR()
   if (wr == 1) BAR()
   for (int kt = 0; kt < nk; kt += 2) {
-    const int e2 = kt + 2 < nk ? kt + 2 : nk - 1, o1 = kt + 1, o3 = kt + 3 < nk ? kt + 3 : nk - 1;
+    k_next();
+    const int a_e2 = kw.a, w_e2 = kw.w;  // K-tile min(kt + 2, nk - 1)
+    k_next();
+    const int a_o3 = kw.a, w_o3 = kw.w;  // K-tile min(kt + 3, nk - 1)
     // p1
     READ_BL(0)
     __builtin_amdgcn_sched_barrier(0);
     READ_A(0, OFF_A_LO)
-    STAGE(a_src[1], OFF_A_HI, 1, o1)
+    STAGE(a_src[1], OFF_A_HI, 1, a_o1)
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
     BAR()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -496,7 +540,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
     BAR()
     // p2
     READ_BH(0)
-    STAGE(b_lo_src, OFF_B_LO, 0, e2)
+    STAGE(b_lo_src, OFF_B_LO, 0, w_e2)
     BAR()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -504,14 +548,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
     BAR()
     // p3
     READ_A(0, OFF_A_HI)
-    STAGE(a_src[0], OFF_A_LO, 0, e2)
+    STAGE(a_src[0], OFF_A_LO, 0, a_e2)
     BAR()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     MFMA_Q(1, 2, NBH, fbh)
     BAR()
     // p4
-    STAGE_BHI(0, e2)
+    STAGE_BHI(0, w_e2)
     WAIT_3HALVES()
     BAR()
     MFMA_Q(1, 0, 2, fbl)
@@ -520,7 +564,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
     READ_BL(1)
     __builtin_amdgcn_sched_barrier(0);
     READ_A(1, OFF_A_LO)
-    STAGE(a_src[1], OFF_A_HI, 0, e2)
+    STAGE(a_src[1], OFF_A_HI, 0, a_e2)
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
     BAR()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -529,7 +573,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
     BAR()
     // p6
     READ_BH(1)
-    STAGE(b_lo_src, OFF_B_LO, 1, o3)
+    STAGE(b_lo_src, OFF_B_LO, 1, w_o3)
     BAR()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -537,18 +581,19 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
     BAR()
     // p7
     READ_A(1, OFF_A_HI)
-    STAGE(a_src[0], OFF_A_LO, 1, o3)
+    STAGE(a_src[0], OFF_A_LO, 1, a_o3)
     BAR()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     MFMA_Q(1, 2, NBH, fbh)
     BAR()
     // p8
-    STAGE_BHI(1, o3)
+    STAGE_BHI(1, w_o3)
     WAIT_3HALVES()
     BAR()
     MFMA_Q(1, 0, 2, fbl)
     BAR()
+    a_o1 = a_o3;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (wr == 0) BAR()
@@ -575,7 +620,23 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
         if (g.act == 1) v[j] = fmaxf(v[j], 0.f);
         if (g.act == 2) v[j] = gelu_erf_b(v[j]);
       }
-      if (g.out_bf16) {
+      if (g.out_bf16 == 2) {  // three bf16 planes [hi | mid | lo] per row (row stride ldc elements, plane stride N): a split-form operand
+        union {
+          __bf16 h[4];
+          uint2 u;
+        } hi, mid, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hi.h[j] = (__bf16)v[j];
+          const float r1 = v[j] - (float)hi.h[j];
+          mid.h[j] = (__bf16)r1;
+          lo.h[j] = (__bf16)(r1 - (float)mid.h[j]);
+        }
+        __bf16* pl = reinterpret_cast<__bf16*>(g.C) + m * g.ldc + n;
+        *reinterpret_cast<uint2*>(pl) = hi.u;
+        *reinterpret_cast<uint2*>(pl + g.N) = mid.u;
+        *reinterpret_cast<uint2*>(pl + 2 * (int64_t)g.N) = lo.u;
+      } else if (g.out_bf16) {
         union {
           __bf16 h[4];
           uint2 u;
@@ -640,8 +701,13 @@ int linear_bf16_tile_form(int64_t M, int N, int K, int has_residual, int out_bf1
 // Returns 1 if the shape is not served here (caller falls back to the generic core), 0 on launch, < 0 on error.
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
-                            int64_t ldr, int out_bf16, hipStream_t stream, const int64_t* m_dev) {
+                            int64_t ldr, int out_bf16, hipStream_t stream, const int64_t* m_dev, int split) {
   if (K % 64 != 0 || lda % 8 != 0 || ldw % 8 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return 1;  // 16-byte DMA pieces
+  const int split_k0 = split ? K : 0;  // split form: K is the real contraction length K0, rows hold [hi | mid | lo]; 6 K0 virtual elements
+  if (split) {
+    if (lda < 3 * (int64_t)K || ldw < 3 * (int64_t)K) return 1;
+    K *= 6;
+  }
   if (((uintptr_t)C & 15) || (has_bias && ((uintptr_t)bias & 15)) || (has_residual && ((uintptr_t)residual & 15))) return 1;
   Bf16GemmArgs g{};
   g.A = static_cast<const char*>(A), g.W = static_cast<const char*>(W), g.C = C, g.bias = bias, g.residual = residual;
@@ -649,6 +715,7 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
   g.tiles_n = (N + 127) / 128;
   g.has_bias = has_bias, g.has_residual = has_residual, g.act = act, g.out_bf16 = out_bf16;
   g.m_dev = m_dev;
+  g.split_k0 = split_k0;
   int64_t blocks = ((M + 127) / 128) * g.tiles_n;
   if (blocks <= 0) return 0;
   if (blocks > 0x7fffffffLL) {
@@ -664,13 +731,17 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
     if (sel) {
       const int bn = sel == 1 ? 256 : 192;
       const int64_t b256 = ((M + 255) / 256) * (int64_t)((N + bn - 1) / bn);
+#define LAUNCH256(BN_, SP_)                                                                                                        \
+  {                                                                                                                              \
+    if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_nt_bf16_tile256_kernel<BN_, SP_>), 2 * BUF_BYTES, "linear_bf16")) return rc__; \
+    hipLaunchKernelGGL((gemm_nt_bf16_tile256_kernel<BN_, SP_>), dim3((unsigned)b256), dim3(512), 2 * BUF_BYTES, stream, g);      \
+  }
       if (sel == 1) {
-        if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_nt_bf16_tile256_kernel<256>), 2 * BUF_BYTES, "linear_bf16")) return rc__;
-        hipLaunchKernelGGL(gemm_nt_bf16_tile256_kernel<256>, dim3((unsigned)b256), dim3(512), 2 * BUF_BYTES, stream, g);
+        if (split) LAUNCH256(256, true) else LAUNCH256(256, false)
       } else {
-        if (int rc__ = ensure_dyn_lds(reinterpret_cast<const void*>(gemm_nt_bf16_tile256_kernel<192>), 2 * BUF_BYTES, "linear_bf16")) return rc__;
-        hipLaunchKernelGGL(gemm_nt_bf16_tile256_kernel<192>, dim3((unsigned)b256), dim3(512), 2 * BUF_BYTES, stream, g);
+        if (split) LAUNCH256(192, true) else LAUNCH256(192, false)
       }
+#undef LAUNCH256
       GDR_CHECK_LAUNCH("gemm_nt_bf16_tile256_kernel");
       return 0;
     }
@@ -680,11 +751,17 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
   // 19.9, wo 57.4 -> 43.6; 4 096 rows o 23.2 -> 17.5, wo 58.5 -> 46.2; from ~2 tiles per CU on the 128-row form is as fast or faster)
   if (blocks < 512) {
     blocks = ((M + 63) / 64) * g.tiles_n;
-    hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 64>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+    if (split)
+      hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 64, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+    else
+      hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 64>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
     GDR_CHECK_LAUNCH("gemm_nt_bf16_glds_kernel<64-row tiles>");
     return 0;
   }
-  hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 128>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  if (split)
+    hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 128, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  else
+    hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 128>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
   GDR_CHECK_LAUNCH("gemm_nt_bf16_glds_kernel");
   return 0;
 }
@@ -745,4 +822,92 @@ int launch_sim_bf16_glds(const void* D, int64_t N, const void* Q, int B, int d, 
 extern "C" int gdr_linear_bf16_tile_form(int64_t M, int N, int K, int epilogue) {
   const int has_residual = epilogue == GDR_EPI_RESIDUAL || epilogue == GDR_EPI_BIAS_RESIDUAL;
   return gdr::linear_bf16_tile_form(M, N, K, has_residual, 0);
+}
+
+// ---- fp32 carried as three bf16 planes (r06, exploratory: VERDICT r05 #8) --------------------------------------------------------
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (RNE; the two differences are exact in fp32): 24
+// significand bits.  A linear over such operands keeps the six leading products hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid on the
+// bf16 MFMA path with fp32 accumulate (the dropped ones are below 2^-24 of the product): measured error against float64 on the
+// encoder's shapes 7e-6 .. 1.3e-5 of mean |c| — the strict-fp32 MFMA linear's own 6e-6 .. 1.5e-5 (tools/exp_split_bf16.py) — at 1/16 x 6
+// of the fp32 MFMA cost.  NOT bit-identical to the fp32 chain: an opt-in mode beside the fp32 path, never its replacement.
+namespace gdr {
+__global__ __launch_bounds__(256) void split_f32_bf16x3_kernel(const float* __restrict__ in, int64_t ld_in, __bf16* __restrict__ out,
+                                                              int64_t ld_out, int64_t rows, int K, const int64_t* __restrict__ rows_dev) {
+  const int k4 = K >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = i / k4;
+  const int c = (int)(i - r * k4) * 4;
+  if (r >= (rows_dev ? *rows_dev : rows)) return;
+  const float4 v = *reinterpret_cast<const float4*>(in + r * ld_in + c);
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  union {
+    __bf16 h[4];
+    uint2 u;
+  } hi, mid, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi.h[j] = (__bf16)x[j];
+    const float r1 = x[j] - (float)hi.h[j];
+    mid.h[j] = (__bf16)r1;
+    lo.h[j] = (__bf16)(r1 - (float)mid.h[j]);
+  }
+  __bf16* o = out + r * ld_out + c;
+  *reinterpret_cast<uint2*>(o) = hi.u;
+  *reinterpret_cast<uint2*>(o + K) = mid.u;
+  *reinterpret_cast<uint2*>(o + 2 * (int64_t)K) = lo.u;
+}
+
+int launch_split_f32_bf16x3(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int K, const int64_t* rows_dev,
+                            hipStream_t stream) {
+  if (rows == 0) return GDR_OK;
+  GDR_CHECK_ARG(in && out && K > 0 && K % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_out >= 3 * (int64_t)K && ((uintptr_t)in & 15) == 0 &&
+                    ((uintptr_t)out & 7) == 0,
+                "split_f32_bf16x3: bad arguments (K %% 4 == 0, ld_out >= 3 K)");
+  const int64_t n = rows * (K / 4);
+  hipLaunchKernelGGL(split_f32_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, ld_in, static_cast<__bf16*>(out),
+                     ld_out, rows, K, rows_dev);
+  GDR_CHECK_LAUNCH("split_f32_bf16x3_kernel");
+  return GDR_OK;
+}
+}  // namespace gdr
+
+namespace gdr {
+// Elements per row of a plane-form operand with contraction length K: 3 K rounded up to a row stride the LDS-DMA staging likes.
+// Measured (tools/exp_split_pad.py, M = 12 308, N = 2 304, K = 768): row stride 4 608 B (= 4 096 + 512) 254 us, + 128 B 233, + 256 B 218,
+// + 512 B 210, 5 248 B (= 4 096 + 1 152) and every larger tested stride 203 us — rows a near-multiple of 4 KiB apart collide in the
+// memory system.  The rule: the stride in bytes modulo 4 096 lies in [1 152, 2 944]; multiples of 64 elements.
+int split_row_elems(int K) {
+  int ld = 3 * K;
+  ld = (ld + 63) / 64 * 64;
+  for (;;) {
+    const int m = (2 * ld) % 4096;
+    if (m >= 1152 && m <= 2944) return ld;
+    ld += 64;
+  }
+}
+}  // namespace gdr
+
+extern "C" int gdr_split_row_elems(int K) { return K > 0 ? gdr::split_row_elems(K) : 0; }
+
+extern "C" int gdr_split_f32_bf16x3(const float* in, void* out_planes, int64_t rows, int K, int64_t ld_out, void* stream) {
+  return gdr::launch_split_f32_bf16x3(in, K, out_planes, ld_out, rows, K, nullptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gdr_linear_split_bf16(const void* A3, int64_t lda, const void* W3, int64_t ldw, float* C, int64_t ldc, int64_t M, int N, int K,
+                                     int epilogue, const float* bias, const float* residual, int64_t ldr, void* stream) {
+  using namespace gdr;
+  GDR_CHECK_ARG(A3 && W3 && C && M >= 0 && N > 0 && K > 0, "linear_split_bf16: bad arguments");
+  if (M == 0) return GDR_OK;
+  const bool nb = epilogue == GDR_EPI_BIAS || epilogue == GDR_EPI_BIAS_RELU || epilogue == GDR_EPI_BIAS_RESIDUAL || epilogue == GDR_EPI_BIAS_GELU;
+  const bool nr = epilogue == GDR_EPI_RESIDUAL || epilogue == GDR_EPI_BIAS_RESIDUAL;
+  const int act = (epilogue == GDR_EPI_RELU || epilogue == GDR_EPI_BIAS_RELU) ? 1 : epilogue == GDR_EPI_BIAS_GELU ? 2 : 0;
+  GDR_CHECK_ARG((!nb || bias) && (!nr || residual), "linear_split_bf16: the epilogue's bias / residual pointer is null");
+  ProfScope prof(PROF_LINEAR, 2.0 * (double)M * (double)N * (double)K, static_cast<hipStream_t>(stream));
+  const int rc = launch_linear_bf16_glds(A3, lda, W3, ldw, C, ldc, M, N, K, nb, nr, act, bias, residual, ldr, 0, static_cast<hipStream_t>(stream),
+                                         nullptr, 1);
+  if (rc > 0) {
+    set_error("linear_split_bf16: shape not served (K %% 64 == 0, lda / ldw >= 3 K and multiples of 8, 16-byte aligned operands)");
+    return GDR_EINVAL;
+  }
+  return rc;
 }

@@ -80,6 +80,9 @@ int launch_zero_dead_rows(float* x, const int32_t* seq_len, int B, int L, int d,
 // same over the first *rows_dev rows (a device-side count; the grid is sized for max_rows)
 int launch_rmsnorm_dev(const float* x, const float* w, float* y, const int64_t* rows_dev, int64_t max_rows, int d, float eps,
                        hipStream_t stream, void* y16 = nullptr);
+// the split-bf16 form's operand: y (nullable) fp32 rows; planes bf16 [rows, ld >= 3 d], a row = [hi | mid | lo] of the normed row
+int launch_rmsnorm_planes(const float* x, const float* w, float* y, void* planes, int64_t ld, const int64_t* rows_dev, int64_t max_rows,
+                          int d, float eps, hipStream_t stream);
 // same, output rounded to bf16 (RNE): the activation operand of a bf16-mode linear
 int launch_rmsnorm_bf16(const float* x, const float* w, void* y_bf16, int64_t rows, int d, float eps, hipStream_t stream);
 int launch_rmsnorm_bf16_dev(const float* x, const float* w, void* y_bf16, const int64_t* rows_dev, int64_t max_rows, int d,

@@ -217,7 +217,10 @@ template <bool BF16OUT>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       float* __restrict__ y, int64_t rows, int d4, float eps,
                                                       float* __restrict__ pooled, int pool_every,
-                                                      const int64_t* __restrict__ rows_dev, uint2* __restrict__ y16 = nullptr) {
+                                                      const int64_t* __restrict__ rows_dev, uint2* __restrict__ y16 = nullptr,
+                                                      int planes_ld = 0) {
+  // planes_ld != 0 (the split-bf16 form, r06): y16 receives the row as three bf16 planes [hi | mid | lo] (row stride planes_ld
+  // elements, plane stride d) instead of one rounded image, and y may be null (the fp32 copy is not written)
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (rows_dev) rows = *rows_dev;
   if (row >= rows) return;
@@ -257,9 +260,28 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     if (BF16OUT) {
       (reinterpret_cast<uint2*>(y) + row * d4)[c] = pack_bf16x4(o.x, o.y, o.z, o.w);
     } else {
-      yr[c] = o;
+      if (y) yr[c] = o;
       if (pr) pr[c] = o;
-      if (y16) (y16 + row * d4)[c] = pack_bf16x4(o.x, o.y, o.z, o.w);  // the same values, rounded: a bf16 linear's operand
+      if (y16 && planes_ld) {
+        __bf16* pl = reinterpret_cast<__bf16*>(y16) + row * planes_ld + 4 * c;
+        const float v4[4] = {o.x, o.y, o.z, o.w};
+        union {
+          __bf16 h[4];
+          uint2 u;
+        } hi, mid, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hi.h[j] = (__bf16)v4[j];
+          const float r1 = v4[j] - (float)hi.h[j];
+          mid.h[j] = (__bf16)r1;
+          lo.h[j] = (__bf16)(r1 - (float)mid.h[j]);
+        }
+        *reinterpret_cast<uint2*>(pl) = hi.u;
+        *reinterpret_cast<uint2*>(pl + 4 * d4) = mid.u;
+        *reinterpret_cast<uint2*>(pl + 8 * d4) = lo.u;
+      } else if (y16) {
+        (y16 + row * d4)[c] = pack_bf16x4(o.x, o.y, o.z, o.w);  // the same values, rounded: a bf16 linear's operand
+      }
     }
   };
   if (in_regs) {
@@ -288,6 +310,17 @@ int launch_rmsnorm_dev(const float* x, const float* w, float* y, const int64_t* 
   hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((unsigned)((max_rows + 3) / 4)), dim3(256), 0, stream, x, w, y, max_rows,
                      d / 4, eps, (float*)nullptr, 1, rows_dev, static_cast<uint2*>(y16));
   GDR_CHECK_LAUNCH("rmsnorm_kernel(dev rows)");
+  return GDR_OK;
+}
+
+// y (nullable) fp32 rows; planes: bf16 [rows, ld] rows = [hi | mid | lo] of the normed row (split-bf16 operand); rows_dev may be null
+int launch_rmsnorm_planes(const float* x, const float* w, float* y, void* planes, int64_t ld, const int64_t* rows_dev, int64_t max_rows,
+                          int d, float eps, hipStream_t stream) {
+  GDR_CHECK_ARG(d % 4 == 0 && ld >= 3 * (int64_t)d && ld % 4 == 0, "rmsnorm(planes): d %% 4 != 0 or ld < 3 d");
+  if (max_rows == 0) return GDR_OK;
+  hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((unsigned)((max_rows + 3) / 4)), dim3(256), 0, stream, x, w, y, max_rows, d / 4, eps,
+                     (float*)nullptr, 1, rows_dev, static_cast<uint2*>(planes), (int)ld);
+  GDR_CHECK_LAUNCH("rmsnorm_kernel(planes)");
   return GDR_OK;
 }
 

@@ -63,6 +63,36 @@ def linear_bf16(a, w, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None
     return out.view(*a.shape[:-1], N)
 
 
+def split_bf16x3(x, padded=True):
+    """fp32 [rows, K] -> bf16 [rows, ld] with ld = gdr_split_row_elems(K) >= 3K (padded=False: exactly 3K), a row = [hi | mid | lo | pad]
+    with x = hi + mid + lo to 24 bits — gdr_split_f32_bf16x3."""
+    _need_cuda(x)
+    x = _f32c(x)
+    K = x.shape[-1]
+    ld = lib().gdr_split_row_elems(K) if padded else 3 * K
+    out = torch.zeros(x.shape[:-1] + (ld,), dtype=torch.bfloat16, device=x.device)
+    check(lib().gdr_split_f32_bf16x3(ptr(x), ptr(out), x.numel() // K, K, ld, stream_ptr()), "gdr_split_f32_bf16x3")
+    return out
+
+
+def linear_split_bf16(a3, w3, K, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None):
+    """out[M,N] fp32 = epilogue(a @ w.T) with a [M,K], w [N,K] given as three bf16 planes per row (split_bf16x3; rows may be padded
+    beyond 3K) — gdr_linear_split_bf16: the six leading products of the 24-bit operands on the bf16 MFMA path, fp32 accumulate.
+    Exploratory, beside ops.linear."""
+    _need_cuda(a3, w3, bias, residual)
+    if a3.dtype != torch.bfloat16 or w3.dtype != torch.bfloat16 or a3.shape[-1] < 3 * K or w3.shape[-1] < 3 * K:
+        raise _ffi.GdrError("linear_split_bf16: operands must be bf16 plane rows of at least 3K elements")
+    a3, w3 = a3.contiguous(), w3.contiguous()
+    a2 = a3.view(-1, a3.shape[-1])
+    M, N = a2.shape[0], w3.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a3.device)
+    res2 = _f32c(residual).view(-1, N) if residual is not None else None
+    check(lib().gdr_linear_split_bf16(ptr(a2), a2.shape[1], ptr(w3), w3.shape[1], ptr(out), N, M, N, K, epilogue,
+                                      ptr(_f32c(bias)) if bias is not None else None, ptr(res2), N, stream_ptr()), "gdr_linear_split_bf16")
+    return out.view(*a3.shape[:-1], N)
+
+
 def l2_normalize(x, eps=1e-12):
     """x / max(||x||_2, eps) over the last dim — gdr_l2_normalize (torch.nn.functional.normalize, dense.py:24-25)."""
     _need_cuda(x)
@@ -410,10 +440,14 @@ class T5EncoderHandle:
     dtype=torch.bfloat16 selects the C5 precision mode: the linear weights are rounded to bf16 on the device
     (gdr_cast_f32_bf16) and forward() calls gdr_t5_encoder_forward_bf16; everything else stays fp32."""
 
-    def __init__(self, cfg, sd, device, prefix="encoder.", dtype=torch.float32):
+    def __init__(self, cfg, sd, device, prefix="encoder.", dtype=torch.float32, split=False):
+        """split=True (r06, exploratory; dtype float32): every linear weight is stored as three bf16 planes (split_bf16x3) and forward()
+        runs gdr_t5_encoder_forward_ragged_split — fp32 operands carried through bf16 MFMAs with fp32-level error, not fp32 bits."""
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("T5EncoderHandle: dtype must be float32 or bfloat16")
-        self.cfg, self.device, self.dtype = cfg, device, dtype
+        if split and dtype != torch.float32:
+            raise ValueError("T5EncoderHandle: split=True is a form of the float32 mode")
+        self.cfg, self.device, self.dtype, self.split = cfg, device, dtype, bool(split)
         keep = []
 
         def dev(t):
@@ -421,11 +455,15 @@ class T5EncoderHandle:
             keep.append(t)
             return t
 
-        def lin(t):                                      # a linear's weight: bf16 copy in the C5 mode
+        def lin(t):                                      # a linear's weight: bf16 copy in the C5 mode, three bf16 planes in the split form
             t = dev(t)
             if dtype == torch.bfloat16:
                 keep.pop()
                 t = to_bf16(t)
+                keep.append(t)
+            elif split:
+                keep.pop()
+                t = split_bf16x3(t)
                 keep.append(t)
             return t
 
@@ -472,6 +510,16 @@ class T5EncoderHandle:
             raise ValueError("T5EncoderHandle.forward: nothing requested")
         d = self.cfg.d_model
         pooled = torch.empty((B, d), dtype=torch.float32, device=ids.device) if want_pooled else None
+        if self.split:
+            if not ragged:
+                raise _ffi.GdrError("T5EncoderHandle(split=True): the split form exists for the ragged forward only")
+            need = lib().gdr_t5_encoder_split_workspace_bytes(C.byref(self.dims), B, L)
+            ws = self.ws.get(need)
+            out = torch.empty((B, L, d), dtype=torch.float32, device=ids.device) if want_hidden else None
+            check(lib().gdr_t5_encoder_forward_ragged_split(C.byref(self.struct), ptr(ids), ptr(mask), B, L, ptr(out), ptr(pooled),
+                                                            int(live_rows_hint), ptr(ws), ws.numel(), stream_ptr()),
+                  "gdr_t5_encoder_forward_ragged_split")
+            return out, pooled
         if ragged:
             need = lib().gdr_t5_encoder_ragged_workspace_bytes(C.byref(self.dims), B, L)
             ws = self.ws.get(need)

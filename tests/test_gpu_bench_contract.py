@@ -61,11 +61,33 @@ def test_bench_line_contract_fp32():
     assert "static" in r["traffic_source"] or r["traffic"] is None
     assert c["cpu_model"]
     ss = j["stages_summary"]                           # a dozen scalars of the other stages; the full object is on the #stages line
-    assert len(ss) <= 16 and all(isinstance(v, (int, float)) and v > 0 for v in ss.values()), ss
+    assert len(ss) <= 32, ss
+    for k_, v in ss.items():                           # positive numbers; the *_violations counts are zero; one triple of embed times
+        if k_.endswith("violations"):
+            assert v == 0, (k_, v)
+        elif isinstance(v, list):
+            assert len(v) == 3 and all(x > 0 for x in v), (k_, v)
+        else:
+            assert isinstance(v, (int, float)) and v > 0, (k_, v)
     for key in ("c3_B64_beam10_qps", "B64_beam10_decode_ms", "B64_beam10_frac_of_floor_executed", "B1_beam100_decode_ms",
                 "c3_best_sustained_qps", "bf16_c2_qps", "bf16_B64_beam30_generate_ms", "sim_B32_ms", "sim_B32_frac_of_hbm_peak",
                 "doc_tower_frac_of_f32_mfma_peak", "c2_prefilter_qps", "sim_B32_prefilter_ms", "sim_B1_prefilter_ms", "B64_beam10_launches"):
         assert key in ss, key
+    # r06: the driver's one line carries the reference-equivalent-work number, config C5, the C3 / C5 oracle checks, the doc tower's three
+    # forms and the exploratory split-bf16 step
+    for key in ("c2_padded_qps", "c2_padded_linear_frac", "c3_parity_violations", "c5_qps", "c5_linear_frac", "c5_parity_violations",
+                "B1_beam100_launches", "B1_beam100_frac_of_floor_executed", "doc_tower_320k_embed_s", "c2_split_bf16_qps",
+                "c2_split_bf16_tie_rule_violations"):
+        assert key in ss, key
+    assert ss["c2_padded_qps"] < j["value"] and 0 < ss["c2_padded_linear_frac"] < 1 and 0 < ss["c5_linear_frac"] < 1
+    emb = ss["doc_tower_320k_embed_s"]                # padded fp32 > ragged fp32 > ragged bf16
+    assert emb[0] > emb[1] > emb[2]
+    assert "traffic_stale" in j["roofline"]
+    sp = det["stages"]["c2_step_split_bf16"]
+    assert sp["topk_vs_fp32_step"]["rows_violating_tie_rule"] == 0 and sp["pooled_max_abs_diff_vs_fp32"] < 1e-4
+    c5 = det["stages"]["c5_two_stage"]
+    assert c5["parity"]["stage1_rows_violating"] == 0 and c5["parity"]["stage2_rows_violating"] == 0 and c5["queries_per_s"] > 0
+    assert det["stages"]["c3_two_stage"]["parity"]["stage2_queries"] == 64
     wp = j["with_bf16_prefilter"]                     # reported beside the headline, never as `value`
     assert wp["value"] > 0 and wp["rows_violating_tie_rule"] == 0 and wp["recall"] == rec["gpu"]
     pre = det["stages"]["c2_step_bf16_prefilter"]      # the same step through the bf16 pre-filter: same fp32 top-k, held to the oracle

@@ -259,6 +259,69 @@ def test_encoder_base_vs_reference_golden(dev):
     np.testing.assert_allclose(h.cpu().numpy()[rc[:, 0], rc[:, 1]], g["sample_rows"], rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (4100, 2304, 768), (9000, 768, 3072), (12308, 3072, 768)])
+def test_linear_split_bf16_carries_fp32_operands(dev, M, N, K):
+    """gdr_linear_split_bf16 (r06, exploratory — beside the fp32 linear): operands as three bf16 planes (x = hi + mid + lo to 24 bits,
+    gdr_split_f32_bf16x3), the six leading products on the bf16 MFMA path, fp32 accumulate.  (a) the planes reconstruct the fp32 value
+    to <= 2^-23 relative; (b) against float64 the result is as close as the strict-fp32 MFMA linear's (both <= 3e-5 of mean |c|, and
+    the split form within 3x of the fp32 form's own error); (c) epilogues; (d) rows of a big launch (256-row tiles, plane rows padded
+    by gdr_split_row_elems) equal the same rows of a small launch (64-row tiles) bit for bit — one k order per output element."""
+    from gdr_amd import ops, _ffi
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    r, b = torch.randn(M, N, generator=g), torch.randn(N, generator=g)
+    A, W, R, Bv = a.to(dev), w.to(dev), r.to(dev), b.to(dev)
+    Ap, Wp = ops.split_bf16x3(A), ops.split_bf16x3(W)
+    ld = _ffi.lib().gdr_split_row_elems(K)
+    assert Ap.shape == (M, ld) and ld >= 3 * K and ld % 64 == 0
+    rec = Ap[:, :K].float() + Ap[:, K:2 * K].float() + Ap[:, 2 * K:3 * K].float()
+    assert float(((rec - A).abs() / A.abs().clamp_min(1e-30)).max()) <= 2.0 ** -22
+    c = ops.linear_split_bf16(Ap, Wp, K)
+    c32 = ops.linear(A, W)
+    rows = torch.arange(0, M, max(1, M // 48))[:48]
+    ref = a[rows].double() @ w.double().T
+    scale = float(ref.abs().mean())
+    e_split = float((c[rows.to(dev)].cpu().double() - ref).abs().max()) / scale
+    e_f32 = float((c32[rows.to(dev)].cpu().double() - ref).abs().max()) / scale
+    assert e_split <= 3e-5 and e_f32 <= 3e-5 and e_split <= 3.0 * e_f32 + 1e-6, (e_split, e_f32)
+    got = ops.linear_split_bf16(Ap, Wp, K, epilogue=_ffi.EPI_BIAS_RESIDUAL, bias=Bv, residual=R)
+    torch.testing.assert_close(got, c + Bv + R, rtol=1e-6, atol=1e-5)
+    torch.testing.assert_close(ops.linear_split_bf16(Ap, Wp, K, epilogue=_ffi.EPI_RELU), torch.relu(c), rtol=0, atol=0)
+    small = min(M, 130)
+    part = ops.linear_split_bf16(Ap[:small].contiguous(), Wp, K)
+    assert torch.equal(c[:small], part)
+
+
+def test_encoder_split_bf16_form_vs_reference_golden_and_the_fp32_form(dev):
+    """gdr_t5_encoder_forward_ragged_split (r06, exploratory): the ragged encoder with every linear in the split-bf16 form.  Held to the
+    SAME golden and tolerance as the fp32 encoder (g1, 2e-4 — measured 6e-6), and at the bench batch (512 queries: the 256-row tiles,
+    the norm's and the wi epilogue's plane outputs) the pooled vectors stay within 1e-4 of the fp32 form's (measured 1e-5)."""
+    from gdr_amd import ops
+    g = golden("g1_encoder_base")
+    cfg = GDRConfig.base()
+    sd = synth.make_state_dict(cfg, seed=int(g["seed"]), with_decoder=False)
+    esp = ops.T5EncoderHandle(cfg, sd, dev, split=True)
+    ids, mask = torch.from_numpy(g["input_ids"]).to(dev), torch.from_numpy(g["attention_mask"]).to(dev)
+    h, pooled = esp.forward(ids, mask, ragged=True)
+    np.testing.assert_allclose(pooled.cpu().numpy(), g["pooled"], rtol=2e-4, atol=2e-4)
+    rc = g["sample_rc"]
+    live = g["attention_mask"][rc[:, 0], rc[:, 1]] != 0                    # the ragged form zeroes PAD rows
+    np.testing.assert_allclose(h.cpu().numpy()[rc[:, 0], rc[:, 1]][live], g["sample_rows"][live], rtol=2e-4, atol=2e-4)
+    with pytest.raises(Exception):
+        esp.forward(ids, mask, ragged=False)                               # the split form exists for the ragged forward only
+    e32 = ops.T5EncoderHandle(cfg, sd, dev)
+    ids_n, mask_n = synth.make_tokens(512, L=40, seed=11)
+    ids, mask = torch.from_numpy(ids_n).to(dev), torch.from_numpy(mask_n).to(dev)
+    _, p32 = e32.forward(ids, mask, want_hidden=False, ragged=True)
+    _, psp = esp.forward(ids, mask, want_hidden=False, ragged=True, live_rows_hint=int(mask_n.sum()))
+    hsp, psp2 = esp.forward(ids, mask, ragged=True)
+    diff = float((psp - p32).abs().max())
+    print(f"split-bf16 encoder, 512 queries: max |pooled - fp32 pooled| = {diff:.2e}")
+    assert diff <= 1e-4
+    assert float((psp2 - psp).abs().max()) <= 1e-5                          # with hidden states: the full last block, same numbers
+    assert int((hsp[torch.from_numpy(mask_n == 0).to(dev)] != 0).sum()) == 0
+
+
 @pytest.mark.parametrize("B,L", [(1, 1), (3, 5), (7, 40), (2, 128)])
 def test_encoder_tiny_vs_oracle_ragged(dev, B, L):
     from gdr_amd import ops

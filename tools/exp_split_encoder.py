@@ -1,0 +1,56 @@
+"""Exploratory: the C2 step with the encoder's linears in the split-bf16 form (gdr_t5_encoder_forward_ragged_split)
+beside the strict-fp32 step: error of the hidden states against the reference golden and against the fp32 kernels, pooled-vector
+differences at the bench batch, q/s of the step (encoder 512 queries ragged + Q.D^T top-100 over 320k docs), and the top-k lists of both."""
+import json, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from gdr_amd import ops, synth
+from gdr_amd.config import GDRConfig
+torch.set_grad_enabled(False)
+dev = torch.device("cuda:0")
+cfg = GDRConfig.base()
+g = np.load(os.path.join(ROOT, "tests", "golden", "g1_encoder_base.npz"))
+sd = synth.make_state_dict(cfg, seed=int(g["seed"]), with_decoder=False)
+e32, esp = ops.T5EncoderHandle(cfg, sd, dev), ops.T5EncoderHandle(cfg, sd, dev, split=True)
+ids, mask = torch.from_numpy(g["input_ids"]).to(dev), torch.from_numpy(g["attention_mask"]).to(dev)
+h32, p32 = e32.forward(ids, mask, ragged=True)
+hsp, psp = esp.forward(ids, mask, ragged=True)
+rc = g["sample_rc"]
+out = {"golden_hidden_max_abs_err": {"fp32": float(np.abs(h32.cpu().numpy()[rc[:, 0], rc[:, 1]] - g["sample_rows"]).max()),
+                                     "split": float(np.abs(hsp.cpu().numpy()[rc[:, 0], rc[:, 1]] - g["sample_rows"]).max())},
+       "golden_pooled_max_abs_err": {"fp32": float(np.abs(p32.cpu().numpy() - g["pooled"]).max()),
+                                     "split": float(np.abs(psp.cpu().numpy() - g["pooled"]).max())},
+       "split_vs_fp32_hidden_max_abs": float((hsp - h32).abs().max())}
+# the bench step
+sd2 = synth.make_state_dict(cfg, seed=1234, with_decoder=False)
+e32, esp = ops.T5EncoderHandle(cfg, sd2, dev), ops.T5EncoderHandle(cfg, sd2, dev, split=True)
+Dn = synth.make_corpus(320000, cfg.d_model)
+D = torch.from_numpy(Dn).to(dev)
+ids_n, mask_n = synth.make_tokens(512, L=40, seed=11)
+ids, mask = torch.from_numpy(ids_n).to(dev), torch.from_numpy(mask_n).to(dev)
+live = int(mask_n.sum())
+ws = ops.Workspace(dev)
+
+
+def step(enc):
+    _, pooled = enc.forward(ids, mask, want_hidden=False, ragged=True, live_rows_hint=live)
+    return pooled, ops.sim_topk(pooled, D, 100, workspace=ws, exact_on_overflow=False)
+
+
+def timed(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
+
+
+p_a, (v_a, i_a) = step(e32)
+p_b, (v_b, i_b) = step(esp)
+t_a, t_b = timed(lambda: step(e32)), timed(lambda: step(esp))
+te_a = timed(lambda: e32.forward(ids, mask, want_hidden=False, ragged=True, live_rows_hint=live))
+te_b = timed(lambda: esp.forward(ids, mask, want_hidden=False, ragged=True, live_rows_hint=live))
+out.update({"c2_step_fp32_qps": 512 / t_a, "c2_step_split_qps": 512 / t_b, "encoder_ms": {"fp32": te_a * 1e3, "split": te_b * 1e3},
+            "pooled_max_abs_diff": float((p_a - p_b).abs().max()), "pooled_scale": float(p_a.abs().mean()),
+            "topk_rows_identical_ids": int((i_a == i_b).all(dim=1).sum()), "topk_max_score_diff": float((v_a - v_b).abs().max())})
+print(json.dumps(out, indent=1))
