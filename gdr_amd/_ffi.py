@@ -94,7 +94,7 @@ SIGNATURES = {
     "gdr_linear_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "gdr_split_row_elems": (_i, [_i]),
     "gdr_split_f32_bf16x3": (_i, [_vp, _vp, _i64, _i, _i64, _vp]),
-    "gdr_linear_split_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    "gdr_linear_split_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "gdr_linear_bf16_tile_form": (_i, [_i64, _i, _i, _i]),
     "gdr_linear_f32_splitk": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "gdr_l2_normalize": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
@@ -105,7 +105,7 @@ SIGNATURES = {
     "gdr_t5_encoder_forward_ragged": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "gdr_t5_encoder_forward_ragged_bf16": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "gdr_t5_encoder_split_workspace_bytes": (_sz, [C.POINTER(GdrT5Dims), _i, _i]),
-    "gdr_t5_encoder_forward_ragged_split": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "gdr_t5_encoder_forward_ragged_split": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _i64, _i, _vp, _sz, _vp]),
     "gdr_t5_encoder_bf16_workspace_bytes": (_sz, [C.POINTER(GdrT5Dims), _i, _i]),
     "gdr_t5_encoder_forward_bf16": (_i, [C.POINTER(GdrT5EncoderWeights), _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "gdr_sim_topk_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i]),

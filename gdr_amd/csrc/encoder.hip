@@ -428,8 +428,10 @@ static size_t split_ws_bytes(const GdrT5Dims& dm, int64_t M) {
 }
 
 static int ragged_split_impl(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L, float* out_hidden,
-                             float* out_pooled, int64_t live_rows_hint, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                             float* out_pooled, int64_t live_rows_hint, int terms, void* workspace, size_t workspace_bytes,
+                             hipStream_t stream) {
   if (B == 0) return GDR_OK;
+  GDR_CHECK_ARG(terms == 6 || terms == 3, "t5_encoder_split: terms must be 6 or 3");
   GDR_CHECK_ARG(w && ids && mask && workspace && (out_hidden || out_pooled), "t5_encoder_split: null pointer");
   const GdrT5Dims& dm = w->dims;
   GDR_CHECK_ARG(B > 0 && L > 0 && L <= 128, "t5_encoder_split: B=%d L=%d (L must be in [1,128])", B, L);
@@ -474,7 +476,7 @@ static int ragged_split_impl(const GdrT5EncoderWeights* w, const int64_t* ids, c
     const int ld = split_row_elems(K);
     ProfScope prof(PROF_LINEAR, 2.0 * (double)(md && live_rows_hint >= 0 ? live_rows_hint : rows) * (double)N * (double)K, stream);
     const int rc_ = launch_linear_bf16_glds(P, ld, W, ld, static_cast<float*>(C), ldc, rows, N, K, 0, residual != nullptr, act, nullptr, residual,
-                                            ldc, out_planes ? 2 : 0, stream, md, 1);
+                                            ldc, out_planes ? 2 : 0, stream, md, terms);
     if (rc_ > 0) {
       set_error("t5_encoder_split: shape not served by the LDS-DMA linear");
       return GDR_EINVAL;
@@ -555,9 +557,9 @@ extern "C" size_t gdr_t5_encoder_split_workspace_bytes(const GdrT5Dims* dims, in
 }
 
 extern "C" int gdr_t5_encoder_forward_ragged_split(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L,
-                                                   float* out_hidden, float* out_pooled, int64_t live_rows_hint, void* workspace,
-                                                   size_t workspace_bytes, void* stream_) {
-  return gdr::ragged_split_impl(w, ids, mask, B, L, out_hidden, out_pooled, live_rows_hint, workspace, workspace_bytes,
+                                                   float* out_hidden, float* out_pooled, int64_t live_rows_hint, int terms,
+                                                   void* workspace, size_t workspace_bytes, void* stream_) {
+  return gdr::ragged_split_impl(w, ids, mask, B, L, out_hidden, out_pooled, live_rows_hint, terms, workspace, workspace_bytes,
                                 static_cast<hipStream_t>(stream_));
 }
 

@@ -703,10 +703,12 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, int out_bf16, hipStream_t stream, const int64_t* m_dev, int split) {
   if (K % 64 != 0 || lda % 8 != 0 || ldw % 8 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return 1;  // 16-byte DMA pieces
-  const int split_k0 = split ? K : 0;  // split form: K is the real contraction length K0, rows hold [hi | mid | lo]; 6 K0 virtual elements
+  // split form: K is the real contraction length K0, rows hold [hi | mid | lo]; `split` = number of plane-pair blocks of K0 virtual
+  // elements each: 6 = the fp32-level form; 3 = hi.hi + hi.mid + mid.hi only (16 significand bits: a measured, narrower knob)
+  const int split_k0 = split ? K : 0;
   if (split) {
-    if (lda < 3 * (int64_t)K || ldw < 3 * (int64_t)K) return 1;
-    K *= 6;
+    if ((split != 3 && split != 6) || lda < 3 * (int64_t)K || ldw < 3 * (int64_t)K) return 1;
+    K *= split;
   }
   if (((uintptr_t)C & 15) || (has_bias && ((uintptr_t)bias & 15)) || (has_residual && ((uintptr_t)residual & 15))) return 1;
   Bf16GemmArgs g{};
@@ -872,19 +874,11 @@ int launch_split_f32_bf16x3(const float* in, int64_t ld_in, void* out, int64_t l
 }  // namespace gdr
 
 namespace gdr {
-// Elements per row of a plane-form operand with contraction length K: 3 K rounded up to a row stride the LDS-DMA staging likes.
-// Measured (tools/exp_split_pad.py, M = 12 308, N = 2 304, K = 768): row stride 4 608 B (= 4 096 + 512) 254 us, + 128 B 233, + 256 B 218,
-// + 512 B 210, 5 248 B (= 4 096 + 1 152) and every larger tested stride 203 us — rows a near-multiple of 4 KiB apart collide in the
-// memory system.  The rule: the stride in bytes modulo 4 096 lies in [1 152, 2 944]; multiples of 64 elements.
-int split_row_elems(int K) {
-  int ld = 3 * K;
-  ld = (ld + 63) / 64 * 64;
-  for (;;) {
-    const int m = (2 * ld) % 4096;
-    if (m >= 1152 && m <= 2944) return ld;
-    ld += 64;
-  }
-}
+// Elements per row of a plane-form operand with contraction length K: 3 K rounded up to 64 elements (128 B, the DMA's row piece).
+// (A first measurement suggested a sensitivity to the row stride — 254 us at 4 608 B against 203 us at 5 248 B; repeated in a fixed
+// order it was the clock ramp of the first seconds of a process, tools/exp_split_pad.py: 255 / 254 / 235 / 225 / 216 / 211 us for pads
+// 0 / 320 / 0 / 320 / 1024 / 320 — so no padding rule is kept.)
+int split_row_elems(int K) { return (3 * K + 63) / 64 * 64; }
 }  // namespace gdr
 
 extern "C" int gdr_split_row_elems(int K) { return K > 0 ? gdr::split_row_elems(K) : 0; }
@@ -894,9 +888,9 @@ extern "C" int gdr_split_f32_bf16x3(const float* in, void* out_planes, int64_t r
 }
 
 extern "C" int gdr_linear_split_bf16(const void* A3, int64_t lda, const void* W3, int64_t ldw, float* C, int64_t ldc, int64_t M, int N, int K,
-                                     int epilogue, const float* bias, const float* residual, int64_t ldr, void* stream) {
+                                     int terms, int epilogue, const float* bias, const float* residual, int64_t ldr, void* stream) {
   using namespace gdr;
-  GDR_CHECK_ARG(A3 && W3 && C && M >= 0 && N > 0 && K > 0, "linear_split_bf16: bad arguments");
+  GDR_CHECK_ARG(A3 && W3 && C && M >= 0 && N > 0 && K > 0 && (terms == 6 || terms == 3), "linear_split_bf16: bad arguments (terms: 6 or 3)");
   if (M == 0) return GDR_OK;
   const bool nb = epilogue == GDR_EPI_BIAS || epilogue == GDR_EPI_BIAS_RELU || epilogue == GDR_EPI_BIAS_RESIDUAL || epilogue == GDR_EPI_BIAS_GELU;
   const bool nr = epilogue == GDR_EPI_RESIDUAL || epilogue == GDR_EPI_BIAS_RESIDUAL;
@@ -904,7 +898,7 @@ extern "C" int gdr_linear_split_bf16(const void* A3, int64_t lda, const void* W3
   GDR_CHECK_ARG((!nb || bias) && (!nr || residual), "linear_split_bf16: the epilogue's bias / residual pointer is null");
   ProfScope prof(PROF_LINEAR, 2.0 * (double)M * (double)N * (double)K, static_cast<hipStream_t>(stream));
   const int rc = launch_linear_bf16_glds(A3, lda, W3, ldw, C, ldc, M, N, K, nb, nr, act, bias, residual, ldr, 0, static_cast<hipStream_t>(stream),
-                                         nullptr, 1);
+                                         nullptr, terms);
   if (rc > 0) {
     set_error("linear_split_bf16: shape not served (K %% 64 == 0, lda / ldw >= 3 K and multiples of 8, 16-byte aligned operands)");
     return GDR_EINVAL;

@@ -75,7 +75,7 @@ def split_bf16x3(x, padded=True):
     return out
 
 
-def linear_split_bf16(a3, w3, K, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None):
+def linear_split_bf16(a3, w3, K, epilogue=_ffi.EPI_NONE, bias=None, residual=None, out=None, terms=6):
     """out[M,N] fp32 = epilogue(a @ w.T) with a [M,K], w [N,K] given as three bf16 planes per row (split_bf16x3; rows may be padded
     beyond 3K) — gdr_linear_split_bf16: the six leading products of the 24-bit operands on the bf16 MFMA path, fp32 accumulate.
     Exploratory, beside ops.linear."""
@@ -88,7 +88,7 @@ def linear_split_bf16(a3, w3, K, epilogue=_ffi.EPI_NONE, bias=None, residual=Non
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a3.device)
     res2 = _f32c(residual).view(-1, N) if residual is not None else None
-    check(lib().gdr_linear_split_bf16(ptr(a2), a2.shape[1], ptr(w3), w3.shape[1], ptr(out), N, M, N, K, epilogue,
+    check(lib().gdr_linear_split_bf16(ptr(a2), a2.shape[1], ptr(w3), w3.shape[1], ptr(out), N, M, N, K, int(terms), epilogue,
                                       ptr(_f32c(bias)) if bias is not None else None, ptr(res2), N, stream_ptr()), "gdr_linear_split_bf16")
     return out.view(*a3.shape[:-1], N)
 
@@ -447,7 +447,9 @@ class T5EncoderHandle:
             raise ValueError("T5EncoderHandle: dtype must be float32 or bfloat16")
         if split and dtype != torch.float32:
             raise ValueError("T5EncoderHandle: split=True is a form of the float32 mode")
-        self.cfg, self.device, self.dtype, self.split = cfg, device, dtype, bool(split)
+        if split not in (False, True, 0, 3, 6):
+            raise ValueError("T5EncoderHandle: split must be False, True (= 6 terms) or 3 / 6")
+        self.cfg, self.device, self.dtype, self.split = cfg, device, dtype, (6 if split is True else int(split))
         keep = []
 
         def dev(t):
@@ -517,7 +519,7 @@ class T5EncoderHandle:
             ws = self.ws.get(need)
             out = torch.empty((B, L, d), dtype=torch.float32, device=ids.device) if want_hidden else None
             check(lib().gdr_t5_encoder_forward_ragged_split(C.byref(self.struct), ptr(ids), ptr(mask), B, L, ptr(out), ptr(pooled),
-                                                            int(live_rows_hint), ptr(ws), ws.numel(), stream_ptr()),
+                                                            int(live_rows_hint), self.split, ptr(ws), ws.numel(), stream_ptr()),
                   "gdr_t5_encoder_forward_ragged_split")
             return out, pooled
         if ragged:

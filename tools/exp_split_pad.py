@@ -11,11 +11,11 @@ def timed(fn, n=20):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
 M, N, K = 12308, 2304, 768
 A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * K ** -0.5
-Ap, Wp = ops.split_bf16x3(A), ops.split_bf16x3(W)
+Ap, Wp = ops.split_bf16x3(A, padded=False), ops.split_bf16x3(W, padded=False)
 C = torch.empty(M, N, device=dev)
-for pad in (0, 64, 128, 192, 256, 320, 1024, 2304):
+for pad in (0, 320, 0, 320, 1024, 320):
     lda = 3 * K + pad
     Ab = torch.zeros(M, lda, dtype=torch.bfloat16, device=dev); Ab[:, :3 * K] = Ap
     Wb = torch.zeros(N, lda, dtype=torch.bfloat16, device=dev); Wb[:, :3 * K] = Wp
-    f = lambda: check(lib().gdr_linear_split_bf16(ptr(Ab), lda, ptr(Wb), lda, ptr(C), N, M, N, K, 0, None, None, 0, stream_ptr()), "x")
+    f = lambda: check(lib().gdr_linear_split_bf16(ptr(Ab), lda, ptr(Wb), lda, ptr(C), N, M, N, K, 6, 0, None, None, 0, stream_ptr()), "x")
     print(pad, round(timed(f) * 1e6, 1), "us")
