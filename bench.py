@@ -1033,7 +1033,9 @@ def main():
         _, p_f = enc.forward(ids, mask, want_hidden=False, ragged=True, live_rows_hint=live_rows)
         out_f = index.search(p_f, a.k, return_status=True)
         split = {}
-        for terms in (6, 3):     # 6: 24 significand bits carried (fp32-level error); 3: hi.hi + hi.mid + mid.hi, 16 bits — NARROWER than fp32
+        # 2: fp16 x 2 planes, 22 bits carried, three blocks (hi.hi + 2^-11 (hi.lo' + lo'.hi)): error against float64 BELOW the fp32 MFMA
+        # linear's own; 6: bf16 x 3, 24 bits, six blocks; 3: the first three bf16 blocks, 16 bits — NARROWER than fp32
+        for terms in (2, 6, 3):
             enc_s = ops.T5EncoderHandle(cfg, sd, dev, split=terms)
 
             def step_s():
@@ -1055,18 +1057,19 @@ def main():
             _ffi.check(lib.gdr_prof_collect(n_s, ms_s, w_s), "gdr_prof_collect")
             ident, perm, bad_s = topk_parity(out_f[0].cpu().numpy(), out_f[1].cpu().numpy(), out_s[0].cpu().numpy(), out_s[1].cpu().numpy())
             lin_eq = w_s[0] / (ms_s[0] * 1e-3) / 1e12 if ms_s[0] > 0 else 0.0      # fp32-equivalent flops (2 M N K) per second
-            split[f"terms{terms}"] = {
-                "queries_per_s": a.batch * a.steps / dts, "ms_per_step": dts / a.steps * 1e3, "significand_bits_carried": 24 if terms == 6 else 16,
-                "linear_fp32_equiv_tflops": lin_eq, "linear_bf16_mfma_tflops": terms * lin_eq,
-                "linear_frac_of_bf16_mfma_peak": terms * lin_eq / BF16_MFMA_PEAK_TFLOPS,
+            split["f16x2" if terms == 2 else f"terms{terms}"] = {
+                "queries_per_s": a.batch * a.steps / dts, "ms_per_step": dts / a.steps * 1e3, "significand_bits_carried": {2: 22, 6: 24, 3: 16}[terms],
+                "linear_fp32_equiv_tflops": lin_eq, "linear_16bit_mfma_tflops": (3 if terms == 2 else terms) * lin_eq,
+                "linear_frac_of_16bit_mfma_peak": (3 if terms == 2 else terms) * lin_eq / BF16_MFMA_PEAK_TFLOPS,
                 "pooled_max_abs_diff_vs_fp32": float((p_s - p_f).abs().max()), "pooled_mean_abs": float(p_f.abs().mean()),
                 "topk_vs_fp32_step": {"rows": a.batch, "ids_identical_rows": ident, "permuted_slots_inside_1e-4_ties": perm,
                                       "rows_violating_tie_rule": bad_s}}
             del enc_s
             torch.cuda.empty_cache()
-        split["note"] = ("EXPLORATORY, never the headline: encoder linears with fp32 operands as bf16 planes on the bf16 MFMA path, fp32 accumulate; "
-                         "terms6 = hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid (24 bits: the fp32 linear's error against float64, not its "
-                         "bits); terms3 = the first three (16 bits: narrower than fp32, inside the path's 2e-4 / 1e-4 parity tolerances here); "
+        split["note"] = ("EXPLORATORY, never the headline: encoder linears with fp32 operands as 16-bit planes on the bf16 / fp16 MFMA path, fp32 "
+                         "accumulate; f16x2 = fp16 hi + fp16 (x - hi) * 2^11 (22 bits; hi.hi + 2^-11 (hi.lo' + lo'.hi): against float64 the error is "
+                         "BELOW the fp32 MFMA linear's own, tools/exp_split_bf16.py); terms6 = bf16 hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid "
+                         "(24 bits); terms3 = the first three (16 bits: narrower than fp32, inside the path's 2e-4 / 1e-4 parity tolerances here); "
                          "norms / attention / residual stream / similarity are the headline's; tests: test_encoder_split_bf16_form_…")
 
     total_q = a.batch * world * a.steps
@@ -1193,6 +1196,9 @@ def main():
                 result["stages_summary"]["c2_split_bf16_tie_rule_violations"] = split["terms6"]["topk_vs_fp32_step"]["rows_violating_tie_rule"]
                 result["stages_summary"]["c2_split3_16bit_qps"] = split["terms3"]["queries_per_s"]
                 result["stages_summary"]["c2_split3_16bit_tie_rule_violations"] = split["terms3"]["topk_vs_fp32_step"]["rows_violating_tie_rule"]
+                result["stages_summary"]["c2_split_f16x2_qps"] = split["f16x2"]["queries_per_s"]
+                result["stages_summary"]["c2_split_f16x2_tie_rule_violations"] = split["f16x2"]["topk_vs_fp32_step"]["rows_violating_tie_rule"]
+                result["stages_summary"]["c2_split_f16x2_pooled_max_abs_diff"] = split["f16x2"]["pooled_max_abs_diff_vs_fp32"]
             if pre is not None:
                 # beside the headline, never instead of it: the same step with the other similarity form (same fp32 top-k for every
                 # input; held to the same oracle lists by the same rule)

@@ -92,7 +92,8 @@ SIGNATURES = {
     "gdr_prof_collect": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gdr_linear_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "gdr_linear_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64, _vp]),
-    "gdr_split_row_elems": (_i, [_i]),
+    "gdr_split_row_elems": (_i, [_i, _i]),
+    "gdr_split_f32_f16x2": (_i, [_vp, _vp, _i64, _i, _i64, _vp]),
     "gdr_split_f32_bf16x3": (_i, [_vp, _vp, _i64, _i, _i64, _vp]),
     "gdr_linear_split_bf16": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "gdr_linear_bf16_tile_form": (_i, [_i64, _i, _i, _i]),

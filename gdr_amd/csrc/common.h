@@ -133,11 +133,11 @@ int linear_bf16_tile_form(int64_t M, int N, int K, int has_residual, int out_bf1
 int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int64_t M, int N,
                             int K, int has_bias, int has_residual, int act, const float* bias, const float* residual,
                             int64_t ldr, int out_bf16, hipStream_t stream, const int64_t* m_dev = nullptr,
-                            int split = 0);  // split = 6 (or 3): K is K0, rows of A / W hold the three bf16 planes [hi | mid | lo] (gemm_bf16.hip)
+                            int split = 0);  // split = 6 / 3: K is K0, rows of A / W hold the three bf16 planes [hi | mid | lo]; 2: fp16 x 2 rows [hi | lo'] (gemm_bf16.hip)
 // x -> [bf16(x) | bf16(x - hi) | bf16(x - hi - mid)] per row (ld_out >= 3 K elements); rows_dev may be null
-int split_row_elems(int K);  // row length (elements) of a plane-form operand: 3 K rounded up to 64
+int split_row_elems(int K, int f16x2 = 0);  // row length (elements) of a plane-form operand: 3 K (bf16 x 3) or 2 K (fp16 x 2), rounded up to 64
 int launch_split_f32_bf16x3(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int K, const int64_t* rows_dev,
-                            hipStream_t stream);
+                            hipStream_t stream, int f16x2 = 0);  // f16x2: rows [fp16 hi | fp16 (x - hi) * 2^11]
 int launch_sim_bf16_glds(const void* D, int64_t N, const void* Q, int B, int d, const SimEpilogue& ep, int64_t n_doc_tiles,
                          hipStream_t stream);
 int launch_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, hipStream_t stream);

@@ -417,7 +417,7 @@ static int ragged_impl(const GdrT5EncoderWeights* w, const int64_t* ids, const i
 namespace gdr {
 // two plane buffers: one for the d_model / inner wide operands (normed rows, attention context), one for the d_ff wide ReLU output,
 // which the wi GEMM's epilogue writes while it still reads the first
-static size_t split_ws_a_bytes(const GdrT5Dims& dm, int64_t M) {
+static size_t split_ws_a_bytes(const GdrT5Dims& dm, int64_t M) {  // sized for the bf16 x 3 form (the fp16 x 2 rows are shorter)
   const int inner = dm.num_heads * dm.d_kv;
   int ld = split_row_elems(dm.d_model);
   if (split_row_elems(inner) > ld) ld = split_row_elems(inner);
@@ -431,7 +431,8 @@ static int ragged_split_impl(const GdrT5EncoderWeights* w, const int64_t* ids, c
                              float* out_pooled, int64_t live_rows_hint, int terms, void* workspace, size_t workspace_bytes,
                              hipStream_t stream) {
   if (B == 0) return GDR_OK;
-  GDR_CHECK_ARG(terms == 6 || terms == 3, "t5_encoder_split: terms must be 6 or 3");
+  GDR_CHECK_ARG(terms == 6 || terms == 3 || terms == 2, "t5_encoder_split: terms must be 6 or 3 (bf16 planes) or 2 (fp16 x 2)");
+  const int f16 = terms == 2 ? 1 : 0;
   GDR_CHECK_ARG(w && ids && mask && workspace && (out_hidden || out_pooled), "t5_encoder_split: null pointer");
   const GdrT5Dims& dm = w->dims;
   GDR_CHECK_ARG(B > 0 && L > 0 && L <= 128, "t5_encoder_split: B=%d L=%d (L must be in [1,128])", B, L);
@@ -473,10 +474,10 @@ static int ragged_split_impl(const GdrT5EncoderWeights* w, const int64_t* ids, c
   // the split GEMM over plane rows P [rows, split_row_elems(K)]; out_planes: the output leaves as plane rows (row stride ldc elements)
   auto gemm = [&](const void* P, const float* W, void* C, int64_t ldc, int64_t rows, const int64_t* md, int N, int K, int act,
                   const float* residual, int out_planes) -> int {
-    const int ld = split_row_elems(K);
+    const int ld = split_row_elems(K, f16);
     ProfScope prof(PROF_LINEAR, 2.0 * (double)(md && live_rows_hint >= 0 ? live_rows_hint : rows) * (double)N * (double)K, stream);
     const int rc_ = launch_linear_bf16_glds(P, ld, W, ld, static_cast<float*>(C), ldc, rows, N, K, 0, residual != nullptr, act, nullptr, residual,
-                                            ldc, out_planes ? 2 : 0, stream, md, terms);
+                                            ldc, out_planes ? (f16 ? 3 : 2) : 0, stream, md, terms);
     if (rc_ > 0) {
       set_error("t5_encoder_split: shape not served by the LDS-DMA linear");
       return GDR_EINVAL;
@@ -487,12 +488,12 @@ static int ragged_split_impl(const GdrT5EncoderWeights* w, const int64_t* ids, c
   auto linear = [&](const float* A, const float* W, float* C, int64_t ldc, int64_t rows, const int64_t* md, int N, int K, int act,
                     const float* residual) -> int {
     void* P = K == dff ? planes_ff : planes;
-    if (int rc_ = launch_split_f32_bf16x3(A, K, P, split_row_elems(K), rows, K, md, stream)) return rc_;
+    if (int rc_ = launch_split_f32_bf16x3(A, K, P, split_row_elems(K, f16), rows, K, md, stream, f16)) return rc_;
     return gemm(P, W, C, ldc, rows, md, N, K, act, residual, 0);
   };
   // the wi GEMM's plane epilogue lives in the 256-row tile kernel, which serves >= 8 192 rows
   const bool fuse = fuse_on && M >= 8192;
-  const int ld_d = split_row_elems(d), ld_ff = split_row_elems(dff);
+  const int ld_d = split_row_elems(d, f16), ld_ff = split_row_elems(dff, f16);
   if ((rc = launch_embed_packed(w->embed, ids, row_src, rows_dev, M, d, dm.vocab_size, h, stream))) return rc;
   AttnArgs at{};
   at.q = qkv, at.k = qkv + inner, at.v = qkv + 2 * inner, at.out = ctx;
@@ -510,7 +511,7 @@ static int ragged_split_impl(const GdrT5EncoderWeights* w, const int64_t* ids, c
     const GdrT5EncLayer& ly = w->layers[i];
     GDR_CHECK_ARG(ly.ln_attn && ly.wqkv && ly.wo && ly.ln_ff && ly.wi && ly.wo_ff, "t5_encoder_split: layer %d null weight", i);
     if (fuse) {  // the norm writes the operand's planes itself (no fp32 copy, no split launch)
-      if ((rc = launch_rmsnorm_planes(h, ly.ln_attn, nullptr, planes, ld_d, rows_dev, M, d, dm.eps, stream))) return rc;
+      if ((rc = launch_rmsnorm_planes(h, ly.ln_attn, nullptr, planes, ld_d, rows_dev, M, d, dm.eps, stream, f16))) return rc;
       if ((rc = gemm(planes, ly.wqkv, qkv, 3 * inner, M, rows_dev, 3 * inner, d, 0, nullptr, 0))) return rc;
     } else {
       if ((rc = launch_rmsnorm_dev(h, ly.ln_attn, nx, rows_dev, M, d, dm.eps, stream))) return rc;
@@ -528,7 +529,7 @@ static int ragged_split_impl(const GdrT5EncoderWeights* w, const int64_t* ids, c
     }
     if ((rc = linear(ctx, ly.wo, h, d, M, rows_dev, d, inner, 0, h))) return rc;
     if (fuse) {  // norm -> planes; wi's ReLU epilogue writes the planes of wo_ff's operand
-      if ((rc = launch_rmsnorm_planes(h, ly.ln_ff, nullptr, planes, ld_d, rows_dev, M, d, dm.eps, stream))) return rc;
+      if ((rc = launch_rmsnorm_planes(h, ly.ln_ff, nullptr, planes, ld_d, rows_dev, M, d, dm.eps, stream, f16))) return rc;
       if ((rc = gemm(planes, ly.wi, planes_ff, ld_ff, M, rows_dev, dff, d, 1, nullptr, 1))) return rc;
       if ((rc = gemm(planes_ff, ly.wo_ff, h, d, M, rows_dev, d, dff, 0, h, 0))) return rc;
     } else {

@@ -15,6 +15,7 @@ namespace gdr {
 
 typedef float f32x4b __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8b __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8b __attribute__((ext_vector_type(8)));
 
 struct Bf16GemmArgs {
   const char* A;  // bf16 [M, lda]
@@ -50,25 +51,75 @@ struct Bf16GemmArgs {
 
 __device__ __forceinline__ float gelu_erf_b(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// Byte offsets of virtual K-tile kt (64 elements) inside a row of A resp. W: plain rows kt * 128; split rows (three planes of k0 elements):
-// block p = kt / (k0 / 64) reads plane {0,0,1,0,2,1}[p] of A and {0,1,0,2,0,1}[p] of W.  kt is wave-uniform: scalar arithmetic;
-// SPLIT is a template parameter of the kernels so that the plain forms keep their K loops untouched; inv = ceil(2^16 / (k0 / 64)).
-template <bool SPLIT>
+// SPLIT (template parameter of the linear kernels, so that the plain forms keep their K loops untouched):
+//   0  plain bf16 rows.
+//   1  bf16 planes: a row holds [hi | mid | lo] of k0 elements each; block p of k0 virtual elements pairs plane {0,0,1,0,2,1}[p] of A with
+//      plane {0,1,0,2,0,1}[p] of W (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid; the first 3 blocks alone = the 16-bit form).
+//   2  fp16 x 2: a row holds [hi | lo'] with hi = fp16(x), lo' = fp16((x - hi) * 2^11) — 22 significand bits, lo' in hi's range (no
+//      subnormal loss) — on v_mfma_f32_16x16x32_f16; blocks (hi, lo'), (lo', hi) first, the accumulators are then scaled by 2^-11
+//      (kt == 2 k0 / 64), then (hi, hi): c = hi.hi + 2^-11 (hi.lo' + lo'.hi), the dropped lo'.lo' term is 2^-22 of the product.
+template <int SPLIT>
+__device__ __forceinline__ int plane_of(int p, bool is_w) {
+  if (SPLIT == 1) return ((is_w ? 0x102010 : 0x120100) >> (4 * p)) & 3;
+  return ((is_w ? 0x001 : 0x010) >> (4 * p)) & 3;
+}
+// Byte offsets of virtual K-tile kt (64 elements) inside a row of A resp. W.  kt is wave-uniform: scalar arithmetic; inv = ceil(2^16 / (k0 / 64)).
+template <int SPLIT>
 __device__ __forceinline__ void ktile_offsets(int kt, int split_k0, int inv, int& off_a, int& off_w) {
-  if (!SPLIT) {
+  if (SPLIT == 0) {
     off_a = off_w = kt * 128;
     return;
   }
   const int nk0 = split_k0 >> 6;
   const int p = (kt * inv) >> 16, k0 = kt - p * nk0;  // exact for kt < 6 * nk0 <= 6 * 1024
-  off_a = (((0x120100 >> (4 * p)) & 3) * split_k0 + k0 * 64) * 2;
-  off_w = (((0x102010 >> (4 * p)) & 3) * split_k0 + k0 * 64) * 2;
+  off_a = (plane_of<SPLIT>(p, false) * split_k0 + k0 * 64) * 2;
+  off_w = (plane_of<SPLIT>(p, true) * split_k0 + k0 * 64) * 2;
+}
+template <int SPLIT>
+__device__ __forceinline__ f32x4b mfma16(const float4 fb, const float4 fa, const f32x4b acc) {
+  if constexpr (SPLIT == 2)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8b, fb), __builtin_bit_cast(f16x8b, fa), acc, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, fb), __builtin_bit_cast(bf16x8b, fa), acc, 0, 0, 0);
+}
+// v -> the 4 + 4 (+ 4) plane values of one output quad, stored at pl (plane stride `ps` elements): form 2 = bf16 x 3, form 3 = fp16 x 2
+__device__ __forceinline__ void store_planes(void* base, int64_t elem_off, int64_t ps, const float (&v)[4], int form) {
+  if (form == 3) {
+    union {
+      _Float16 h[4];
+      uint2 u;
+    } hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hi.h[j] = (_Float16)v[j];
+      lo.h[j] = (_Float16)((v[j] - (float)hi.h[j]) * 2048.0f);
+    }
+    _Float16* pl = static_cast<_Float16*>(base) + elem_off;
+    *reinterpret_cast<uint2*>(pl) = hi.u;
+    *reinterpret_cast<uint2*>(pl + ps) = lo.u;
+    return;
+  }
+  union {
+    __bf16 h[4];
+    uint2 u;
+  } hi, mid, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi.h[j] = (__bf16)v[j];
+    const float r1 = v[j] - (float)hi.h[j];
+    mid.h[j] = (__bf16)r1;
+    lo.h[j] = (__bf16)(r1 - (float)mid.h[j]);
+  }
+  __bf16* pl = static_cast<__bf16*>(base) + elem_off;
+  *reinterpret_cast<uint2*>(pl) = hi.u;
+  *reinterpret_cast<uint2*>(pl + ps) = mid.u;
+  *reinterpret_cast<uint2*>(pl + 2 * ps) = lo.u;
 }
 
 // BM = rows of A per tile: 128, or 64 for the linears of a few thousand rows (the decode legs of config C5: 1 920 beam rows x
 // N = 768 are 90 tiles of 128 x 128 on 256 CUs; 64-row tiles double the workgroups — the W operand is re-read twice as often,
 // which L2 absorbs at these sizes — and halve the accumulators, 32 x 64 per wave).  The similarity forms use 128.
-template <int EPI, int BM = 128, bool SPLIT = false>  // EPI: 0 linear, 1 similarity sample, 2 similarity filter, 3 linear whose output is only dotted with h
+template <int EPI, int BM = 128, int SPLIT = 0>  // EPI: 0 linear, 1 similarity sample, 2 similarity filter, 3 linear whose output is only dotted with h
 __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16GemmArgs g) {
   constexpr bool LIN = EPI == 0 || EPI == 3;
   static_assert(BM == 128 || (BM == 64 && LIN), "64-row tiles serve the linear forms only");
@@ -177,6 +228,12 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
   for (int kt = 0; kt < nk; ++kt) {
     int koff, koff_w;
     ktile_offsets<SPLIT>(kt, g.split_k0, split_inv, koff, koff_w);
+    if (SPLIT == 2 && kt == 2 * (g.split_k0 >> 6)) {  // the two cross blocks are in: scale them by 2^-11 before the hi.hi block
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] *= 0.00048828125f;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < AI)
@@ -198,8 +255,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_bf16_glds_kernel(const Bf16Gem
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8b, fb[ni]),
-                                                                __builtin_bit_cast(bf16x8b, fa[mi]), acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = mfma16<SPLIT>(fb[ni], fa[mi], acc[mi][ni]);
     }
     __syncthreads();  // every fragment read done before the next K-step's DMA overwrites the buffer
   }
@@ -370,7 +426,7 @@ constexpr int OFF_A_LO = 0, OFF_A_HI = HALF_BYTES, OFF_B_LO = 2 * HALF_BYTES, OF
 // BN = 256, or 192 (each wave column 48 wide: a "lo" half of two 16-column blocks and a "hi" half of one): the tile WIDTH is chosen
 // per launch so that the tile count quantises well on 256 CUs — 15 360 beam rows x N = 768 are 180 tiles of 256 x 256 (70 % of one
 // round) but 240 of 256 x 192 (94 %); N = 2 304: 540 tiles = 3 rounds at 70 % against 720 = 3 rounds at 94 %.  Same k order.
-template <int BN, bool SPLIT = false>
+template <int BN, int SPLIT = 0>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16GemmArgs g) {
   static_assert(BN == 256 || BN == 192, "tile width");
   constexpr int WCOLS = BN / 4;           // columns per wave column: 64 or 48
@@ -477,8 +533,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
     __builtin_amdgcn_s_setprio(1);                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < (nbn_); ++j)               \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
-            acc[(mh_)*4 + i][(nb0_) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                \
-                __builtin_bit_cast(bf16x8b, fb_[j][kk]), __builtin_bit_cast(bf16x8b, fa[i][kk]), acc[(mh_)*4 + i][(nb0_) + j], 0, 0, 0); \
+            acc[(mh_)*4 + i][(nb0_) + j] = mfma16<SPLIT>(fb_[j][kk], fa[i][kk], acc[(mh_)*4 + i][(nb0_) + j]);    \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
   }
 #define BAR()                              \
@@ -506,14 +561,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
       return;
     }
     if (++kw.k0 == nk0) kw.k0 = 0, ++kw.p;
-    kw.a = (((0x120100 >> (4 * kw.p)) & 3) * g.split_k0 + kw.k0 * 64) * 2;
-    kw.w = (((0x102010 >> (4 * kw.p)) & 3) * g.split_k0 + kw.k0 * 64) * 2;
+    kw.a = (plane_of<SPLIT>(kw.p, false) * g.split_k0 + kw.k0 * 64) * 2;
+    kw.w = (plane_of<SPLIT>(kw.p, true) * g.split_k0 + kw.k0 * 64) * 2;
   };
+  if (SPLIT) kw.a = plane_of<SPLIT>(0, false) * g.split_k0 * 2, kw.w = plane_of<SPLIT>(0, true) * g.split_k0 * 2;  // K-tile 0 of block 0
   // prologue: K-tile 0 whole, K-tile 1 without A_hi
-  STAGE(b_lo_src, OFF_B_LO, 0, 0)
-  STAGE(a_src[0], OFF_A_LO, 0, 0)
-  STAGE_BHI(0, 0)
-  STAGE(a_src[1], OFF_A_HI, 0, 0)
+  STAGE(b_lo_src, OFF_B_LO, 0, kw.w)
+  STAGE(a_src[0], OFF_A_LO, 0, kw.a)
+  STAGE_BHI(0, kw.w)
+  STAGE(a_src[1], OFF_A_HI, 0, kw.a)
   k_next();
   int a_o1 = kw.a;  // A offset of K-tile kt + 1 (its A_hi half is staged in phase 1)
   STAGE(b_lo_src, OFF_B_LO, 1, kw.w)
@@ -523,6 +579,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
   BAR()
   if (wr == 1) BAR()
   for (int kt = 0; kt < nk; kt += 2) {
+    if (SPLIT == 2 && kt == 2 * nk0) {  // fp16 x 2: the two cross blocks are in — scale them by 2^-11 before the hi.hi block (nk0 even)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] *= 0.00048828125f;
+    }
     k_next();
     const int a_e2 = kw.a, w_e2 = kw.w;  // K-tile min(kt + 2, nk - 1)
     k_next();
@@ -620,22 +682,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_tile256_kernel(const Bf16
         if (g.act == 1) v[j] = fmaxf(v[j], 0.f);
         if (g.act == 2) v[j] = gelu_erf_b(v[j]);
       }
-      if (g.out_bf16 == 2) {  // three bf16 planes [hi | mid | lo] per row (row stride ldc elements, plane stride N): a split-form operand
-        union {
-          __bf16 h[4];
-          uint2 u;
-        } hi, mid, lo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          hi.h[j] = (__bf16)v[j];
-          const float r1 = v[j] - (float)hi.h[j];
-          mid.h[j] = (__bf16)r1;
-          lo.h[j] = (__bf16)(r1 - (float)mid.h[j]);
-        }
-        __bf16* pl = reinterpret_cast<__bf16*>(g.C) + m * g.ldc + n;
-        *reinterpret_cast<uint2*>(pl) = hi.u;
-        *reinterpret_cast<uint2*>(pl + g.N) = mid.u;
-        *reinterpret_cast<uint2*>(pl + 2 * (int64_t)g.N) = lo.u;
+      if (g.out_bf16 >= 2) {  // plane rows of a split-form operand (row stride ldc elements, plane stride N): 2 = bf16 x 3, 3 = fp16 x 2
+        store_planes(g.C, m * g.ldc + n, g.N, v, g.out_bf16);
       } else if (g.out_bf16) {
         union {
           __bf16 h[4];
@@ -705,10 +753,14 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
   if (K % 64 != 0 || lda % 8 != 0 || ldw % 8 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return 1;  // 16-byte DMA pieces
   // split form: K is the real contraction length K0, rows hold [hi | mid | lo]; `split` = number of plane-pair blocks of K0 virtual
   // elements each: 6 = the fp32-level form; 3 = hi.hi + hi.mid + mid.hi only (16 significand bits: a measured, narrower knob)
+  // split = 2: the fp16 x 2 form — rows hold [hi | lo'] (2 K0 elements), three blocks (SPLIT = 2 of the kernels)
   const int split_k0 = split ? K : 0;
+  const int kform = split == 2 ? 2 : split ? 1 : 0;
   if (split) {
-    if ((split != 3 && split != 6) || lda < 3 * (int64_t)K || ldw < 3 * (int64_t)K) return 1;
-    K *= split;
+    const int planes = split == 2 ? 2 : 3;
+    if ((split != 2 && split != 3 && split != 6) || lda < planes * (int64_t)K || ldw < planes * (int64_t)K) return 1;
+    if (split == 2 && K % 128 != 0) return 1;  // the scale point must fall between two K-tile pairs
+    K *= split == 2 ? 3 : split;
   }
   if (((uintptr_t)C & 15) || (has_bias && ((uintptr_t)bias & 15)) || (has_residual && ((uintptr_t)residual & 15))) return 1;
   Bf16GemmArgs g{};
@@ -739,9 +791,9 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
     hipLaunchKernelGGL((gemm_nt_bf16_tile256_kernel<BN_, SP_>), dim3((unsigned)b256), dim3(512), 2 * BUF_BYTES, stream, g);      \
   }
       if (sel == 1) {
-        if (split) LAUNCH256(256, true) else LAUNCH256(256, false)
+        if (kform == 2) LAUNCH256(256, 2) else if (kform == 1) LAUNCH256(256, 1) else LAUNCH256(256, 0)
       } else {
-        if (split) LAUNCH256(192, true) else LAUNCH256(192, false)
+        if (kform == 2) LAUNCH256(192, 2) else if (kform == 1) LAUNCH256(192, 1) else LAUNCH256(192, 0)
       }
 #undef LAUNCH256
       GDR_CHECK_LAUNCH("gemm_nt_bf16_tile256_kernel");
@@ -753,15 +805,19 @@ int launch_linear_bf16_glds(const void* A, int64_t lda, const void* W, int64_t l
   // 19.9, wo 57.4 -> 43.6; 4 096 rows o 23.2 -> 17.5, wo 58.5 -> 46.2; from ~2 tiles per CU on the 128-row form is as fast or faster)
   if (blocks < 512) {
     blocks = ((M + 63) / 64) * g.tiles_n;
-    if (split)
-      hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 64, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+    if (kform == 2)
+      hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 64, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+    else if (kform == 1)
+      hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 64, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
     else
       hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 64>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
     GDR_CHECK_LAUNCH("gemm_nt_bf16_glds_kernel<64-row tiles>");
     return 0;
   }
-  if (split)
-    hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 128, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  if (kform == 2)
+    hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 128, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  else if (kform == 1)
+    hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 128, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
   else
     hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<0, 128>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
   GDR_CHECK_LAUNCH("gemm_nt_bf16_glds_kernel");
@@ -834,7 +890,8 @@ extern "C" int gdr_linear_bf16_tile_form(int64_t M, int N, int K, int epilogue) 
 // of the fp32 MFMA cost.  NOT bit-identical to the fp32 chain: an opt-in mode beside the fp32 path, never its replacement.
 namespace gdr {
 __global__ __launch_bounds__(256) void split_f32_bf16x3_kernel(const float* __restrict__ in, int64_t ld_in, __bf16* __restrict__ out,
-                                                              int64_t ld_out, int64_t rows, int K, const int64_t* __restrict__ rows_dev) {
+                                                              int64_t ld_out, int64_t rows, int K, const int64_t* __restrict__ rows_dev,
+                                                              int form) {
   const int k4 = K >> 2;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t r = i / k4;
@@ -842,32 +899,18 @@ __global__ __launch_bounds__(256) void split_f32_bf16x3_kernel(const float* __re
   if (r >= (rows_dev ? *rows_dev : rows)) return;
   const float4 v = *reinterpret_cast<const float4*>(in + r * ld_in + c);
   const float x[4] = {v.x, v.y, v.z, v.w};
-  union {
-    __bf16 h[4];
-    uint2 u;
-  } hi, mid, lo;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    hi.h[j] = (__bf16)x[j];
-    const float r1 = x[j] - (float)hi.h[j];
-    mid.h[j] = (__bf16)r1;
-    lo.h[j] = (__bf16)(r1 - (float)mid.h[j]);
-  }
-  __bf16* o = out + r * ld_out + c;
-  *reinterpret_cast<uint2*>(o) = hi.u;
-  *reinterpret_cast<uint2*>(o + K) = mid.u;
-  *reinterpret_cast<uint2*>(o + 2 * (int64_t)K) = lo.u;
+  store_planes(out, r * ld_out + c, K, x, form);  // form 2: bf16 x 3 [hi | mid | lo]; 3: fp16 x 2 [hi | lo']
 }
 
 int launch_split_f32_bf16x3(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int K, const int64_t* rows_dev,
-                            hipStream_t stream) {
+                            hipStream_t stream, int f16x2) {
   if (rows == 0) return GDR_OK;
-  GDR_CHECK_ARG(in && out && K > 0 && K % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_out >= 3 * (int64_t)K && ((uintptr_t)in & 15) == 0 &&
-                    ((uintptr_t)out & 7) == 0,
-                "split_f32_bf16x3: bad arguments (K %% 4 == 0, ld_out >= 3 K)");
+  GDR_CHECK_ARG(in && out && K > 0 && K % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_out >= (f16x2 ? 2 : 3) * (int64_t)K &&
+                    ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 7) == 0,
+                "split: bad arguments (K %% 4 == 0, ld_out >= 3 K (bf16 x 3) or 2 K (fp16 x 2))");
   const int64_t n = rows * (K / 4);
   hipLaunchKernelGGL(split_f32_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, ld_in, static_cast<__bf16*>(out),
-                     ld_out, rows, K, rows_dev);
+                     ld_out, rows, K, rows_dev, f16x2 ? 3 : 2);
   GDR_CHECK_LAUNCH("split_f32_bf16x3_kernel");
   return GDR_OK;
 }
@@ -878,19 +921,24 @@ namespace gdr {
 // (A first measurement suggested a sensitivity to the row stride — 254 us at 4 608 B against 203 us at 5 248 B; repeated in a fixed
 // order it was the clock ramp of the first seconds of a process, tools/exp_split_pad.py: 255 / 254 / 235 / 225 / 216 / 211 us for pads
 // 0 / 320 / 0 / 320 / 1024 / 320 — so no padding rule is kept.)
-int split_row_elems(int K) { return (3 * K + 63) / 64 * 64; }
+int split_row_elems(int K, int f16x2) { return ((f16x2 ? 2 : 3) * K + 63) / 64 * 64; }
 }  // namespace gdr
 
-extern "C" int gdr_split_row_elems(int K) { return K > 0 ? gdr::split_row_elems(K) : 0; }
+extern "C" int gdr_split_row_elems(int K, int terms) { return K > 0 ? gdr::split_row_elems(K, terms == 2) : 0; }
 
 extern "C" int gdr_split_f32_bf16x3(const float* in, void* out_planes, int64_t rows, int K, int64_t ld_out, void* stream) {
-  return gdr::launch_split_f32_bf16x3(in, K, out_planes, ld_out, rows, K, nullptr, static_cast<hipStream_t>(stream));
+  return gdr::launch_split_f32_bf16x3(in, K, out_planes, ld_out, rows, K, nullptr, static_cast<hipStream_t>(stream), 0);
+}
+
+extern "C" int gdr_split_f32_f16x2(const float* in, void* out_planes, int64_t rows, int K, int64_t ld_out, void* stream) {
+  return gdr::launch_split_f32_bf16x3(in, K, out_planes, ld_out, rows, K, nullptr, static_cast<hipStream_t>(stream), 1);
 }
 
 extern "C" int gdr_linear_split_bf16(const void* A3, int64_t lda, const void* W3, int64_t ldw, float* C, int64_t ldc, int64_t M, int N, int K,
                                      int terms, int epilogue, const float* bias, const float* residual, int64_t ldr, void* stream) {
   using namespace gdr;
-  GDR_CHECK_ARG(A3 && W3 && C && M >= 0 && N > 0 && K > 0 && (terms == 6 || terms == 3), "linear_split_bf16: bad arguments (terms: 6 or 3)");
+  GDR_CHECK_ARG(A3 && W3 && C && M >= 0 && N > 0 && K > 0 && (terms == 6 || terms == 3 || terms == 2),
+                "linear_split_bf16: bad arguments (terms: 6 or 3 = bf16 planes, 2 = fp16 x 2)");
   if (M == 0) return GDR_OK;
   const bool nb = epilogue == GDR_EPI_BIAS || epilogue == GDR_EPI_BIAS_RELU || epilogue == GDR_EPI_BIAS_RESIDUAL || epilogue == GDR_EPI_BIAS_GELU;
   const bool nr = epilogue == GDR_EPI_RESIDUAL || epilogue == GDR_EPI_BIAS_RESIDUAL;

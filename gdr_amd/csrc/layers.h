@@ -82,7 +82,7 @@ int launch_rmsnorm_dev(const float* x, const float* w, float* y, const int64_t* 
                        hipStream_t stream, void* y16 = nullptr);
 // the split-bf16 form's operand: y (nullable) fp32 rows; planes bf16 [rows, ld >= 3 d], a row = [hi | mid | lo] of the normed row
 int launch_rmsnorm_planes(const float* x, const float* w, float* y, void* planes, int64_t ld, const int64_t* rows_dev, int64_t max_rows,
-                          int d, float eps, hipStream_t stream);
+                          int d, float eps, hipStream_t stream, int f16x2 = 0);  // f16x2: rows [fp16 hi | fp16 (x - hi) * 2^11], ld >= 2 d
 // same, output rounded to bf16 (RNE): the activation operand of a bf16-mode linear
 int launch_rmsnorm_bf16(const float* x, const float* w, void* y_bf16, int64_t rows, int d, float eps, hipStream_t stream);
 int launch_rmsnorm_bf16_dev(const float* x, const float* w, void* y_bf16, const int64_t* rows_dev, int64_t max_rows, int d,

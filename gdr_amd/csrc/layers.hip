@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     } else {
       if (y) yr[c] = o;
       if (pr) pr[c] = o;
-      if (y16 && planes_ld) {
+      if (y16 && planes_ld > 0) {  // bf16 x 3 planes [hi | mid | lo]
         __bf16* pl = reinterpret_cast<__bf16*>(y16) + row * planes_ld + 4 * c;
         const float v4[4] = {o.x, o.y, o.z, o.w};
         union {
@@ -279,6 +279,20 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
         *reinterpret_cast<uint2*>(pl) = hi.u;
         *reinterpret_cast<uint2*>(pl + 4 * d4) = mid.u;
         *reinterpret_cast<uint2*>(pl + 8 * d4) = lo.u;
+      } else if (y16 && planes_ld < 0) {  // fp16 x 2 planes [hi | (x - hi) * 2^11], row stride -planes_ld
+        _Float16* pl = reinterpret_cast<_Float16*>(y16) + row * (int64_t)(-planes_ld) + 4 * c;
+        const float v4[4] = {o.x, o.y, o.z, o.w};
+        union {
+          _Float16 h[4];
+          uint2 u;
+        } hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hi.h[j] = (_Float16)v4[j];
+          lo.h[j] = (_Float16)((v4[j] - (float)hi.h[j]) * 2048.0f);
+        }
+        *reinterpret_cast<uint2*>(pl) = hi.u;
+        *reinterpret_cast<uint2*>(pl + 4 * d4) = lo.u;
       } else if (y16) {
         (y16 + row * d4)[c] = pack_bf16x4(o.x, o.y, o.z, o.w);  // the same values, rounded: a bf16 linear's operand
       }
@@ -315,11 +329,11 @@ int launch_rmsnorm_dev(const float* x, const float* w, float* y, const int64_t* 
 
 // y (nullable) fp32 rows; planes: bf16 [rows, ld] rows = [hi | mid | lo] of the normed row (split-bf16 operand); rows_dev may be null
 int launch_rmsnorm_planes(const float* x, const float* w, float* y, void* planes, int64_t ld, const int64_t* rows_dev, int64_t max_rows,
-                          int d, float eps, hipStream_t stream) {
-  GDR_CHECK_ARG(d % 4 == 0 && ld >= 3 * (int64_t)d && ld % 4 == 0, "rmsnorm(planes): d %% 4 != 0 or ld < 3 d");
+                          int d, float eps, hipStream_t stream, int f16x2) {
+  GDR_CHECK_ARG(d % 4 == 0 && ld >= (f16x2 ? 2 : 3) * (int64_t)d && ld % 4 == 0, "rmsnorm(planes): d %% 4 != 0 or the plane row is too short");
   if (max_rows == 0) return GDR_OK;
   hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3((unsigned)((max_rows + 3) / 4)), dim3(256), 0, stream, x, w, y, max_rows, d / 4, eps,
-                     (float*)nullptr, 1, rows_dev, static_cast<uint2*>(planes), (int)ld);
+                     (float*)nullptr, 1, rows_dev, static_cast<uint2*>(planes), f16x2 ? -(int)ld : (int)ld);
   GDR_CHECK_LAUNCH("rmsnorm_kernel(planes)");
   return GDR_OK;
 }

@@ -69,9 +69,20 @@ def split_bf16x3(x, padded=True):
     _need_cuda(x)
     x = _f32c(x)
     K = x.shape[-1]
-    ld = lib().gdr_split_row_elems(K) if padded else 3 * K
+    ld = lib().gdr_split_row_elems(K, 6) if padded else 3 * K
     out = torch.zeros(x.shape[:-1] + (ld,), dtype=torch.bfloat16, device=x.device)
     check(lib().gdr_split_f32_bf16x3(ptr(x), ptr(out), x.numel() // K, K, ld, stream_ptr()), "gdr_split_f32_bf16x3")
+    return out
+
+
+def split_f16x2(x):
+    """fp32 [rows, K] -> fp16 [rows, 2K], a row = [hi | lo'] with hi = fp16(x), lo' = fp16((x - hi) * 2^11): 22 bits — gdr_split_f32_f16x2."""
+    _need_cuda(x)
+    x = _f32c(x)
+    K = x.shape[-1]
+    ld = lib().gdr_split_row_elems(K, 2)
+    out = torch.zeros(x.shape[:-1] + (ld,), dtype=torch.float16, device=x.device)
+    check(lib().gdr_split_f32_f16x2(ptr(x), ptr(out), x.numel() // K, K, ld, stream_ptr()), "gdr_split_f32_f16x2")
     return out
 
 
@@ -80,8 +91,10 @@ def linear_split_bf16(a3, w3, K, epilogue=_ffi.EPI_NONE, bias=None, residual=Non
     beyond 3K) — gdr_linear_split_bf16: the six leading products of the 24-bit operands on the bf16 MFMA path, fp32 accumulate.
     Exploratory, beside ops.linear."""
     _need_cuda(a3, w3, bias, residual)
-    if a3.dtype != torch.bfloat16 or w3.dtype != torch.bfloat16 or a3.shape[-1] < 3 * K or w3.shape[-1] < 3 * K:
-        raise _ffi.GdrError("linear_split_bf16: operands must be bf16 plane rows of at least 3K elements")
+    want = torch.float16 if terms == 2 else torch.bfloat16
+    planes = 2 if terms == 2 else 3
+    if a3.dtype != want or w3.dtype != want or a3.shape[-1] < planes * K or w3.shape[-1] < planes * K:
+        raise _ffi.GdrError("linear_split_bf16: operands must be plane rows (bf16 x 3 for terms 6 / 3, fp16 x 2 for terms 2) of the same K")
     a3, w3 = a3.contiguous(), w3.contiguous()
     a2 = a3.view(-1, a3.shape[-1])
     M, N = a2.shape[0], w3.shape[0]
@@ -447,8 +460,8 @@ class T5EncoderHandle:
             raise ValueError("T5EncoderHandle: dtype must be float32 or bfloat16")
         if split and dtype != torch.float32:
             raise ValueError("T5EncoderHandle: split=True is a form of the float32 mode")
-        if split not in (False, True, 0, 3, 6):
-            raise ValueError("T5EncoderHandle: split must be False, True (= 6 terms) or 3 / 6")
+        if split not in (False, True, 0, 2, 3, 6):
+            raise ValueError("T5EncoderHandle: split must be False, True (= 6 terms), 3 / 6 (bf16 planes) or 2 (fp16 x 2)")
         self.cfg, self.device, self.dtype, self.split = cfg, device, dtype, (6 if split is True else int(split))
         keep = []
 
@@ -465,7 +478,7 @@ class T5EncoderHandle:
                 keep.append(t)
             elif split:
                 keep.pop()
-                t = split_bf16x3(t)
+                t = split_f16x2(t) if int(split) == 2 else split_bf16x3(t)
                 keep.append(t)
             return t
 

@@ -99,9 +99,13 @@ int gdr_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, floa
  * and a linear that keeps the six leading products hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid on the bf16 MFMA path, fp32 accumulate
  * (the call sites of gdr_linear_f32: modeling_t5.py:360-364,413,182-185).  24 significand bits are carried: the error against float64 is
  * that of the strict-fp32 MFMA linear (tools/exp_split_bf16.py), the bits are not.  A3 [M, lda >= 3K], W3 [N, ldw >= 3K] bf16; K % 64 == 0. */
-int gdr_split_row_elems(int K);   /* row length (elements) of a plane-form operand: 3 K rounded up to 64 */
+int gdr_split_row_elems(int K, int terms);   /* row length (elements) of a plane-form operand: 3 K (terms 6 / 3) or 2 K (terms 2), rounded up to 64 */
 int gdr_split_f32_bf16x3(const float* in, void* out_planes, int64_t rows, int K, int64_t ld_out, void* stream);
-/* terms = 6: the form above.  terms = 3: hi.hi + hi.mid + mid.hi only — 16 significand bits, NARROWER than fp32 (error ~3e-5 of mean |c|
+/* fp16 x 2 planes (terms = 2 below): a row = [hi | lo'] with hi = fp16(x), lo' = fp16((x - hi) * 2^11) — 22 significand bits; the linear
+ * computes hi.hi + 2^-11 (hi.lo' + lo'.hi) on v_mfma_f32_16x16x32_f16 (three K-blocks, the two cross blocks first, scaled, then hi.hi).
+ * |x| must stay below fp16's 65 504 (normed activations, ReLU outputs and weights of the path do; a residual stream would not). */
+int gdr_split_f32_f16x2(const float* in, void* out_planes, int64_t rows, int K, int64_t ld_out, void* stream);
+/* terms = 6: the form above.  terms = 2: the fp16 x 2 form (A3 / W3 rows [hi | lo'], lda / ldw >= 2 K, K % 128 == 0).  terms = 3: hi.hi + hi.mid + mid.hi only — 16 significand bits, NARROWER than fp32 (error ~3e-5 of mean |c|
  * against fp32's ~8e-6 on the encoder's shapes), half the MFMA work: a measured knob, reported as such, never called fp32. */
 int gdr_linear_split_bf16(const void* A3, int64_t lda, const void* W3, int64_t ldw, float* C, int64_t ldc, int64_t M, int N, int K,
                           int terms, int epilogue, const float* bias, const float* residual, int64_t ldr, void* stream);
@@ -192,7 +196,7 @@ int gdr_t5_encoder_forward_ragged_bf16(const GdrT5EncoderWeights* w, const int64
 size_t gdr_t5_encoder_split_workspace_bytes(const GdrT5Dims* dims, int B, int L);
 int gdr_t5_encoder_forward_ragged_split(const GdrT5EncoderWeights* w, const int64_t* ids, const int64_t* mask, int B, int L,
                                         float* out_hidden, float* out_pooled, int64_t live_rows_hint, int terms, void* workspace,
-                                        size_t workspace_bytes, void* stream);   /* terms: 6 (fp32-level) or 3, as gdr_linear_split_bf16 */
+                                        size_t workspace_bytes, void* stream);   /* terms: 6 / 3 (weights as bf16 planes) or 2 (weights as fp16 x 2 rows), as gdr_linear_split_bf16 */
 
 /* bf16 precision mode (BASELINE config C5): the SAME structs, but the four linear weights of every layer (wqkv, wo, wi,
  * wo_ff) point to bf16 [N,K] matrices (round-to-nearest-even of the fp32 checkpoint, e.g. gdr_cast_f32_bf16); the

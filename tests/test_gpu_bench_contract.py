@@ -61,7 +61,7 @@ def test_bench_line_contract_fp32():
     assert "static" in r["traffic_source"] or r["traffic"] is None
     assert c["cpu_model"]
     ss = j["stages_summary"]                           # a dozen scalars of the other stages; the full object is on the #stages line
-    assert len(ss) <= 32, ss
+    assert len(ss) <= 40, ss
     for k_, v in ss.items():                           # positive numbers; the *_violations counts are zero; one triple of embed times
         if k_.endswith("violations"):
             assert v == 0, (k_, v)
@@ -88,7 +88,8 @@ def test_bench_line_contract_fp32():
     sp = det["stages"]["c2_step_split_bf16"]           # exploratory rows beside the headline: 24 bits carried (fp32-level) and 16 bits
     assert sp["terms6"]["topk_vs_fp32_step"]["rows_violating_tie_rule"] == 0 and sp["terms6"]["pooled_max_abs_diff_vs_fp32"] < 5e-5
     assert sp["terms3"]["pooled_max_abs_diff_vs_fp32"] < 2e-4 and sp["terms3"]["significand_bits_carried"] == 16
-    assert "c2_split3_16bit_qps" in ss
+    assert "c2_split3_16bit_qps" in ss and ss["c2_split_f16x2_qps"] > 0
+    assert sp["f16x2"]["topk_vs_fp32_step"]["rows_violating_tie_rule"] == 0 and sp["f16x2"]["pooled_max_abs_diff_vs_fp32"] < 5e-5
     c5 = det["stages"]["c5_two_stage"]
     assert c5["parity"]["stage1_rows_violating"] == 0 and c5["parity"]["stage2_rows_violating"] == 0 and c5["queries_per_s"] > 0
     assert det["stages"]["c3_two_stage"]["parity"]["stage2_queries"] == 64

@@ -57,6 +57,9 @@ for M in (12308, 20480):
         cp3 = ops.linear_split_bf16(Ap, Wp, K, terms=3).clone()
         assert torch.equal(cp3, c3), "3-term plane-addressed kernel differs from the concatenated-operand GEMM"
         tp3 = timed(lambda: ops.linear_split_bf16(Ap, Wp, K, out=C, terms=3))
+        Ah, Wh = ops.split_f16x2(A), ops.split_f16x2(W)                   # fp16 x 2: [hi | (x - hi) * 2^11], 22 bits, three blocks
+        ch = ops.linear_split_bf16(Ah, Wh, K, terms=2).clone()
+        th = timed(lambda: ops.linear_split_bf16(Ah, Wh, K, out=C, terms=2))
         rows = torch.arange(0, M, max(1, M // 64), device=dev)[:64]
         ref = (A[rows].double() @ W.double().T)
         scale = float(ref.abs().mean())
@@ -68,4 +71,4 @@ for M in (12308, 20480):
         print(f"M {M:6d} N {N:5d} K {K:5d} | max err / mean|c|: fp32 {err(c32):.2e}  split6 {err(c6):.2e}  split3 {err(c3):.2e}  bf16 {err(c1):.2e}"
               f" | fp32 {t32 * 1e6:7.1f} us {fl / t32 / 1e12:6.1f} TF  split6 {t6 * 1e6:7.1f} us {fl / t6 / 1e12:6.1f} TF-equiv ({t32 / t6:4.2f}x)"
               f"  split3 {t3 * 1e6:7.1f} us ({t32 / t3:4.2f}x)  [form {ops.lib().gdr_linear_bf16_tile_form(M, N, 6 * K, 0)}]"
-              f"  | planes kernel {tp * 1e6:7.1f} us ({t32 / tp:4.2f}x), 3 terms {tp3 * 1e6:7.1f} us ({t32 / tp3:4.2f}x), split of A {tsplit * 1e6:6.1f} us")
+              f"  | planes kernel {tp * 1e6:7.1f} us ({t32 / tp:4.2f}x), 3 terms {tp3 * 1e6:7.1f} us ({t32 / tp3:4.2f}x), fp16x2 {th * 1e6:7.1f} us ({t32 / th:4.2f}x) err {err(ch):.2e}, split of A {tsplit * 1e6:6.1f} us")
