@@ -562,6 +562,15 @@ def stages(dev, cfg, D, D_dev, a):
         "corpus_320k_embed_s": 320000 / (256 / t16),
         "note": "parity: tests/test_gpu_decode.py::test_doc_tower_bf16_mode_vs_oracle_emulation (the build's own bf16 emulation; unpinned)"}
     del tower16
+    tower_s = EncoderModel.from_state_dict(bc, bsd, dev, split=True)      # exploratory: fp16 x 2 split linears (fp32-level embeddings)
+    ts_ = timed(lambda: tower_s.bert.forward(pids, pmask, want_hidden=False, live_rows_hint=live)[1], reps=5, warm=2)
+    p_a = tower.bert.forward(pids, pmask, want_hidden=False, ragged=True)[1]
+    p_b = tower_s.bert.forward(pids, pmask, want_hidden=False)[1]
+    out["doc_tower_bert_base_L128"]["ragged_split_f16x2"] = {
+        "ms_per_256_passages": ts_ * 1e3, "passages_per_s": 256 / ts_, "corpus_320k_embed_s": 320000 / (256 / ts_),
+        "pooled_max_abs_diff_vs_fp32": float((p_a - p_b).abs().max()), "pooled_mean_abs": float(p_a.abs().mean()),
+        "note": "exploratory: fp32 operands of every linear carried as fp16 hi + fp16 (x - hi) * 2^11 planes (22 bits), fp32 accumulate"}
+    del tower_s
     del tower
     torch.cuda.empty_cache()
     # ---- config C5 on this GPU (1M x 768 bf16 corpus, 512 queries, beam 30, bf16 linears): `--workload c5` for 3 steps, with its
@@ -696,6 +705,7 @@ def stages_summary(st):
             "doc_tower_frac_of_f32_mfma_peak": st["doc_tower_bert_base_L128"]["frac_of_f32_mfma_peak"],
             "doc_tower_320k_embed_s": [st["doc_tower_bert_base_L128"][k_]["corpus_320k_embed_s"] if k_ else
                                        st["doc_tower_bert_base_L128"]["corpus_320k_embed_s"] for k_ in ("", "ragged_f32", "ragged_bf16")],
+            "doc_tower_split_f16x2_embed_s": st["doc_tower_bert_base_L128"]["ragged_split_f16x2"]["corpus_320k_embed_s"],
             "B1_beam100_launches": g["B1_beam100"]["kernel_launches_per_call"],
             "B1_beam100_frac_of_floor_executed": g["B1_beam100"]["frac_of_floor_executed"],
             "c3_parity_violations": (lambda p_: None if p_ is None else p_["stage1_rows_violating"] + p_["stage2_rows_violating"])(

@@ -136,6 +136,7 @@ SIGNATURES = {
     "gdr_bert_encoder_forward": (_i, [C.POINTER(GdrBertWeights), _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "gdr_bert_encoder_ragged_workspace_bytes": (_sz, [C.POINTER(GdrBertWeights), _i, _i]),
     "gdr_bert_encoder_forward_ragged": (_i, [C.POINTER(GdrBertWeights), _vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "gdr_bert_encoder_forward_ragged_split": (_i, [C.POINTER(GdrBertWeights), _vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "gdr_bert_encoder_forward_ragged_bf16": (_i, [C.POINTER(GdrBertWeights), _vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "gdr_t5_generate_workspace_bytes": (_sz, [C.POINTER(GdrT5DecoderWeights), _i, _i, _i, _i]),
     "gdr_t5_generate": (_i, [C.POINTER(GdrT5DecoderWeights), _vp, _vp, _i, _i, _i, _i, C.c_double, _i, C.POINTER(GdrTrie),

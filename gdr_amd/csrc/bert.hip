@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void bert_embed_packed_kernel(const float* __r
 }
 
 struct BertRagWs {
-  size_t seq_len, seq_off, row_src, rows_total, ctx_cls, x_cls, t_cls, ff_cls, x16, total;
+  size_t seq_len, seq_off, row_src, rows_total, ctx_cls, x_cls, t_cls, ff_cls, x16, pl_ff, total;
 };
 static BertRagWs bert_rag_ws(const GdrBertWeights& w, int B, int L) {
   BertRagWs r{};
@@ -194,14 +194,18 @@ static BertRagWs bert_rag_ws(const GdrBertWeights& w, int B, int L) {
   r.x_cls = o, o += align_up((size_t)B * d * 4, 256);
   r.t_cls = o, o += align_up((size_t)B * d * 4, 256);
   r.ff_cls = o, o += align_up((size_t)B * w.d_ff * 4, 256);
-  r.x16 = o, o += align_up(M * d * 2, 256);  // bf16 mode: the bf16 image of the block input x
+  r.x16 = o, o += align_up(M * 2 * d * 2, 256);  // bf16 mode: the bf16 image of the block input x; fp16 x 2 form: its plane rows [M, 2 d]
+  r.pl_ff = o, o += align_up(M * 2 * (size_t)w.d_ff * 2, 256);  // fp16 x 2 form: the plane rows of the GeLU output [M, 2 d_ff]
   r.total = o;
   return r;
 }
 
+// prec: 0 fp32, 1 bf16 precision mode, 2 the fp16 x 2 split form of the fp32 linears (r06, exploratory: fp32-level error on the fp16 MFMA
+// path; weights as plane rows [N, 2 K] fp16; everything but the linears is the fp32 path's)
 static int bert_ragged_impl(const GdrBertWeights* w, const int64_t* ids, const int64_t* mask, const int64_t* token_type_ids, int B,
                             int L, float* out_hidden, float* out_pooled, int64_t live_rows_hint, void* workspace,
-                            size_t workspace_bytes, bool bf16, hipStream_t stream) {
+                            size_t workspace_bytes, int prec, hipStream_t stream) {
+  const bool bf16 = prec == 1, f16s = prec == 2;
   if (B == 0) return GDR_OK;
   GDR_CHECK_ARG(w && ids && mask && workspace && (out_hidden || out_pooled), "bert_ragged: null pointer");
   GDR_CHECK_ARG(B > 0 && L > 0 && L <= 128 && L <= w->max_pos, "bert_ragged: B=%d L=%d (L must be <= min(128, max_pos))", B, L);
@@ -226,9 +230,9 @@ static int bert_ragged_impl(const GdrBertWeights* w, const int64_t* ids, const i
   if ((rc = launch_pack_plan(mask, B, L, seq_len, seq_off, row_src, rows_dev, stream))) return rc;
   const int64_t tiles = ((M + 127) / 128) * ((d + 127) / 128);
   const bool packs = dh == 64 && d % 32 == 0 && dff % 32 == 0;
-  if (bf16) {
-    GDR_CHECK_ARG(packs && d % 64 == 0 && dff % 64 == 0, "bert_ragged(bf16): needs head width 64 and d, d_ff multiples of 64 (d=%d H=%d d_ff=%d)", d,
-                  H, dff);
+  if (bf16 || f16s) {
+    GDR_CHECK_ARG(packs && d % 128 == 0 && dff % 128 == 0,
+                  "bert_ragged(bf16 / split): needs head width 64 and d, d_ff multiples of 128 (d=%d H=%d d_ff=%d)", d, H, dff);
   } else if (!packs || tiles < 192) {
     // small problem / other head size: the padded forward, then the rows the packed form would not have computed are zeroed
     float* full = out_hidden ? out_hidden : reinterpret_cast<float*>(base + ws.qkv);  // qkv is dead when the last LayerNorm runs
@@ -255,7 +259,11 @@ static int bert_ragged_impl(const GdrBertWeights* w, const int64_t* ids, const i
   hipLaunchKernelGGL(bert_embed_packed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, w->word_emb, w->pos_emb, w->type_emb,
                      ids, token_type_ids, row_src, rows_dev, L, d / 4, w->vocab_size, w->type_vocab, t);
   GDR_CHECK_LAUNCH("bert_embed_packed_kernel");
-  if ((rc = launch_layernorm_dev(t, w->emb_ln_w, w->emb_ln_b, x, rows_dev, M, d, w->eps, nullptr, stream, bf16 ? x16 : nullptr))) return rc;
+  void* pl_ff = base + rw.pl_ff;
+  const int ld_d = 2 * d, ld_ff = 2 * dff;  // fp16 x 2 plane rows
+  if ((rc = launch_layernorm_dev(t, w->emb_ln_w, w->emb_ln_b, x, rows_dev, M, d, w->eps, nullptr, stream, (bf16 || f16s) ? x16 : nullptr,
+                                 f16s ? ld_d : 0)))
+    return rc;
 
   AttnArgs at{};
   at.ldq = at.ldk = at.ldv = 3 * d, at.ldo = d;
@@ -289,6 +297,18 @@ static int bert_ragged_impl(const GdrBertWeights* w, const int64_t* ids, const i
     }
     return rc_;
   };
+  // fp16 x 2 split GEMM over plane rows P [rows, 2 K]; out_planes: the (activated) output leaves as plane rows [rows, 2 N]
+  auto gsplit = [&](const void* P, const float* W, void* C, int64_t ldc, int64_t rows, const int64_t* md, int N, int K, int act,
+                    const float* bias, const float* residual, int out_planes) -> int {
+    ProfScope prof(PROF_LINEAR, 2.0 * (double)(md && live_rows_hint >= 0 ? live_rows_hint : rows) * (double)N * (double)K, stream);
+    const int rc_ = launch_linear_bf16_glds(P, 2 * K, W, 2 * K, static_cast<float*>(C), ldc, rows, N, K, bias != nullptr, residual != nullptr, act,
+                                            bias, residual, ldc, out_planes ? 3 : 0, stream, md, 2);
+    if (rc_ > 0) {
+      set_error("bert_ragged(split): shape not served by the LDS-DMA linear");
+      return GDR_EINVAL;
+    }
+    return rc_;
+  };
   const bool pooled_only = out_hidden == nullptr;
   for (int i = 0; i < w->num_layers; ++i) {
     const GdrBertLayer& ly = w->layers[i];
@@ -296,6 +316,36 @@ static int bert_ragged_impl(const GdrBertWeights* w, const int64_t* ids, const i
                       ly.ln2_b,
                   "bert_ragged: layer %d null weight", i);
     const bool last = i + 1 == w->num_layers;
+    if (f16s) {
+      // x (fp32) and its plane rows x16 come from the LayerNorm in front; attention is the fp32 path's
+      const bool big = M >= 8192;  // the plane epilogue lives in the 256-row tile kernel
+      if ((rc = gsplit(x16, ly.wqkv, qkv, 3 * d, M, rows_dev, 3 * d, d, 0, ly.bqkv, nullptr, 0))) return rc;
+      if ((rc = launch_attention(at, stream))) return rc;
+      if (pooled_only && last) {
+        if ((rc = launch_gather_rows(ctx, seq_off, B, d, ctx_cls, stream))) return rc;
+        if ((rc = launch_gather_rows(x, seq_off, B, d, x_cls, stream))) return rc;
+        if ((rc = launch_split_f32_bf16x3(ctx_cls, d, x16, ld_d, B, d, nullptr, stream, 1))) return rc;
+        if ((rc = gsplit(x16, ly.wo, t_cls, d, B, nullptr, d, d, 0, ly.bo, x_cls, 0))) return rc;
+        if ((rc = launch_layernorm(t_cls, ly.ln1_w, ly.ln1_b, x_cls, B, d, w->eps, nullptr, stream, x16, ld_d))) return rc;
+        if ((rc = gsplit(x16, ly.wi, ff_cls, dff, B, nullptr, dff, d, 2, ly.bi, nullptr, 0))) return rc;
+        if ((rc = launch_split_f32_bf16x3(ff_cls, dff, pl_ff, ld_ff, B, dff, nullptr, stream, 1))) return rc;
+        if ((rc = gsplit(pl_ff, ly.wo2, t_cls, d, B, nullptr, d, dff, 0, ly.bo2, x_cls, 0))) return rc;
+        return launch_layernorm(t_cls, ly.ln2_w, ly.ln2_b, out_pooled, B, d, w->eps, nullptr, stream);
+      }
+      if ((rc = launch_split_f32_bf16x3(ctx, d, x16, ld_d, M, d, rows_dev, stream, 1))) return rc;  // x16 is free: x's planes fed qkv already
+      if ((rc = gsplit(x16, ly.wo, t, d, M, rows_dev, d, d, 0, ly.bo, x, 0))) return rc;
+      if ((rc = launch_layernorm_dev(t, ly.ln1_w, ly.ln1_b, x, rows_dev, M, d, w->eps, nullptr, stream, x16, ld_d))) return rc;
+      if (big) {
+        if ((rc = gsplit(x16, ly.wi, pl_ff, ld_ff, M, rows_dev, dff, d, 2, ly.bi, nullptr, 1))) return rc;  // GeLU, plane rows out
+      } else {
+        if ((rc = gsplit(x16, ly.wi, ff, dff, M, rows_dev, dff, d, 2, ly.bi, nullptr, 0))) return rc;
+        if ((rc = launch_split_f32_bf16x3(ff, dff, pl_ff, ld_ff, M, dff, rows_dev, stream, 1))) return rc;
+      }
+      if ((rc = gsplit(pl_ff, ly.wo2, t, d, M, rows_dev, d, dff, 0, ly.bo2, x, 0))) return rc;
+      if ((rc = launch_layernorm_dev(t, ly.ln2_w, ly.ln2_b, x, rows_dev, M, d, w->eps, nullptr, stream, last ? nullptr : x16, last ? 0 : ld_d)))
+        return rc;
+      continue;
+    }
     if (bf16) {
       if ((rc = lin16(x16, ly.wqkv, qkv, 3 * d, M, rows_dev, 3 * d, d, 0, ly.bqkv, nullptr, 1))) return rc;  // q, k, v as bf16
       if ((rc = launch_attention(at, stream))) return rc;
@@ -356,12 +406,19 @@ extern "C" int gdr_bert_encoder_forward_ragged(const GdrBertWeights* w, const in
                                                const int64_t* token_type_ids, int B, int L, float* out_hidden, float* out_pooled,
                                                int64_t live_rows_hint, void* workspace, size_t workspace_bytes, void* stream_) {
   return gdr::bert_ragged_impl(w, ids, mask, token_type_ids, B, L, out_hidden, out_pooled, live_rows_hint, workspace, workspace_bytes,
-                               false, static_cast<hipStream_t>(stream_));
+                               0, static_cast<hipStream_t>(stream_));
 }
 
 extern "C" int gdr_bert_encoder_forward_ragged_bf16(const GdrBertWeights* w, const int64_t* ids, const int64_t* mask,
                                                     const int64_t* token_type_ids, int B, int L, float* out_hidden, float* out_pooled,
                                                     int64_t live_rows_hint, void* workspace, size_t workspace_bytes, void* stream_) {
   return gdr::bert_ragged_impl(w, ids, mask, token_type_ids, B, L, out_hidden, out_pooled, live_rows_hint, workspace, workspace_bytes,
-                               true, static_cast<hipStream_t>(stream_));
+                               1, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int gdr_bert_encoder_forward_ragged_split(const GdrBertWeights* w, const int64_t* ids, const int64_t* mask,
+                                                     const int64_t* token_type_ids, int B, int L, float* out_hidden, float* out_pooled,
+                                                     int64_t live_rows_hint, void* workspace, size_t workspace_bytes, void* stream_) {
+  return gdr::bert_ragged_impl(w, ids, mask, token_type_ids, B, L, out_hidden, out_pooled, live_rows_hint, workspace, workspace_bytes,
+                               2, static_cast<hipStream_t>(stream_));
 }

@@ -89,10 +89,11 @@ int launch_rmsnorm_bf16_dev(const float* x, const float* w, void* y_bf16, const 
                             float eps, hipStream_t stream);
 // y = (x - mean) / sqrt(var + eps) * w + b   (torch.nn.LayerNorm; BERT / nn.TransformerDecoderLayer)
 // optional addv [d]: y = LN(x + addv)  (the adaptor's constant single-key cross-attention output)
+// f16x2_ld != 0: y16 receives plane rows [fp16 hi | fp16 (y - hi) * 2^11] of f16x2_ld >= 2 d elements (the fp16 x 2 split form's operand)
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int d, float eps,
-                     const float* addv, hipStream_t stream, void* y16 = nullptr);
+                     const float* addv, hipStream_t stream, void* y16 = nullptr, int f16x2_ld = 0);
 int launch_layernorm_dev(const float* x, const float* w, const float* b, float* y, const int64_t* rows_dev, int64_t max_rows,
-                         int d, float eps, const float* addv, hipStream_t stream, void* y16 = nullptr);
+                         int d, float eps, const float* addv, hipStream_t stream, void* y16 = nullptr, int f16x2_ld = 0);
 // y = LN(LN(x; w1, b1) + addv; w2, b2) in one pass (bit-identical to the two launches); rows_dev may be null (= max_rows rows);
 // returns 1 when d > 2048 (not served: run the two launches)
 int launch_layernorm2(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* addv, float* y,

@@ -374,7 +374,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ b, float* __restrict__ y,
                                                         int64_t rows, int d4, float eps,
                                                         const float* __restrict__ addv,
-                                                        const int64_t* __restrict__ rows_dev, uint2* __restrict__ y16) {
+                                                        const int64_t* __restrict__ rows_dev, uint2* __restrict__ y16,
+                                                        int f16x2_ld = 0) {
+  // f16x2_ld != 0 (the fp16 x 2 split form, r06): y16 receives the row as plane rows [fp16 hi | fp16 (y - hi) * 2^11] of f16x2_ld elements
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (rows_dev) rows = *rows_dev;
   if (row >= rows) return;
@@ -412,7 +414,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     o.x = (v.x - mean) * rstd * g.x + bb.x, o.y = (v.y - mean) * rstd * g.y + bb.y;
     o.z = (v.z - mean) * rstd * g.z + bb.z, o.w = (v.w - mean) * rstd * g.w + bb.w;
     yr[c] = o;
-    if (y16) (y16 + row * d4)[c] = pack_bf16x4(o.x, o.y, o.z, o.w);
+    if (y16 && f16x2_ld) {
+      _Float16* pl = reinterpret_cast<_Float16*>(y16) + row * (int64_t)f16x2_ld + 4 * c;
+      const float v4[4] = {o.x, o.y, o.z, o.w};
+      union {
+        _Float16 h[4];
+        uint2 u;
+      } hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hi.h[j] = (_Float16)v4[j];
+        lo.h[j] = (_Float16)((v4[j] - (float)hi.h[j]) * 2048.0f);
+      }
+      *reinterpret_cast<uint2*>(pl) = hi.u;
+      *reinterpret_cast<uint2*>(pl + 4 * d4) = lo.u;
+    } else if (y16) {
+      (y16 + row * d4)[c] = pack_bf16x4(o.x, o.y, o.z, o.w);
+    }
   }
 }
 
@@ -502,21 +520,21 @@ int launch_layernorm2(const float* x, const float* w1, const float* b1, const fl
 }
 
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int64_t rows, int d, float eps,
-                     const float* addv, hipStream_t stream, void* y16) {
-  GDR_CHECK_ARG(d % 4 == 0, "layernorm: d %% 4 != 0");
+                     const float* addv, hipStream_t stream, void* y16, int f16x2_ld) {
+  GDR_CHECK_ARG(d % 4 == 0 && (f16x2_ld == 0 || (y16 && f16x2_ld >= 2 * d && f16x2_ld % 4 == 0)), "layernorm: d %% 4 != 0 or a bad plane row");
   if (rows == 0) return GDR_OK;
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, b, y, rows, d / 4,
-                     eps, addv, (const int64_t*)nullptr, static_cast<uint2*>(y16));
+                     eps, addv, (const int64_t*)nullptr, static_cast<uint2*>(y16), f16x2_ld);
   GDR_CHECK_LAUNCH("layernorm_kernel");
   return GDR_OK;
 }
 
 int launch_layernorm_dev(const float* x, const float* w, const float* b, float* y, const int64_t* rows_dev, int64_t max_rows,
-                         int d, float eps, const float* addv, hipStream_t stream, void* y16) {
-  GDR_CHECK_ARG(d % 4 == 0, "layernorm: d %% 4 != 0");
+                         int d, float eps, const float* addv, hipStream_t stream, void* y16, int f16x2_ld) {
+  GDR_CHECK_ARG(d % 4 == 0 && (f16x2_ld == 0 || (y16 && f16x2_ld >= 2 * d && f16x2_ld % 4 == 0)), "layernorm: d %% 4 != 0 or a bad plane row");
   if (max_rows == 0) return GDR_OK;
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((max_rows + 3) / 4)), dim3(256), 0, stream, x, w, b, y, max_rows, d / 4,
-                     eps, addv, rows_dev, static_cast<uint2*>(y16));
+                     eps, addv, rows_dev, static_cast<uint2*>(y16), f16x2_ld);
   GDR_CHECK_LAUNCH("layernorm_kernel(dev rows)");
   return GDR_OK;
 }

@@ -175,7 +175,7 @@ class EncoderModel:
         self.output, self.bert, self.ragged = output, bert, ragged
 
     @staticmethod
-    def from_state_dict(bcfg, state_dict, device, prefix="ctx_encoder.bert_model.", dtype=torch.float32, ragged=None):
+    def from_state_dict(bcfg, state_dict, device, prefix="ctx_encoder.bert_model.", dtype=torch.float32, ragged=None, split=False):
         """state_dict with the reference's doc-tower keys; a Lightning checkpoint prefixes them `encoder.model.`.
         ragged: PAD positions of a padded batch are not computed (bit-identical pooled output in fp32; r06).  dtype=torch.bfloat16:
         the bf16 precision mode (bf16 linear operands, fp32 accumulate), which exists in the ragged form only."""
@@ -183,8 +183,8 @@ class EncoderModel:
         lp = "encoder.model."
         if any(k.startswith(lp) for k in sd):
             sd = {k[len(lp):]: v for k, v in sd.items() if k.startswith(lp)}
-        ragged = (dtype == torch.bfloat16) if ragged is None else ragged
-        return EncoderModel(bert=ops.BertEncoderHandle(bcfg, sd, device, prefix, dtype=dtype), ragged=ragged)
+        ragged = (dtype == torch.bfloat16 or bool(split)) if ragged is None else ragged
+        return EncoderModel(bert=ops.BertEncoderHandle(bcfg, sd, device, prefix, dtype=dtype, split=split), ragged=ragged)
 
     def __call__(self, passage=None, query_enc=None):
         if passage is not None:

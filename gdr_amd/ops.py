@@ -559,10 +559,14 @@ class BertEncoderHandle:
     device, the attention's 1/sqrt(dh) is folded into the q rows of wqkv / bqkv (exact: a power of two at dh = 64), and forward()
     runs gdr_bert_encoder_forward_ragged_bf16 — the packed form is the only bf16 form."""
 
-    def __init__(self, bcfg, sd, device, prefix="ctx_encoder.bert_model.", dtype=torch.float32):
+    def __init__(self, bcfg, sd, device, prefix="ctx_encoder.bert_model.", dtype=torch.float32, split=False):
+        """split=True (r06, exploratory; dtype float32): the linear weights are stored as fp16 x 2 plane rows (split_f16x2) and forward()
+        runs gdr_bert_encoder_forward_ragged_split — fp32-level embeddings through the fp16 MFMA path."""
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("BertEncoderHandle: dtype must be float32 or bfloat16")
-        self.bcfg, self.device, self.dtype = bcfg, device, dtype
+        if split and dtype != torch.float32:
+            raise ValueError("BertEncoderHandle: split=True is a form of the float32 mode")
+        self.bcfg, self.device, self.dtype, self.split = bcfg, device, dtype, bool(split)
         bf = dtype == torch.bfloat16
         keep = []
 
@@ -576,6 +580,10 @@ class BertEncoderHandle:
             if bf:
                 keep.pop()
                 t = to_bf16(t)
+                keep.append(t)
+            elif split:
+                keep.pop()
+                t = split_f16x2(t)
                 keep.append(t)
             return t
 
@@ -619,9 +627,9 @@ class BertEncoderHandle:
         mode (its only form), padded otherwise."""
         _need_cuda(input_ids, attention_mask, token_type_ids)
         bf = self.dtype == torch.bfloat16
-        ragged = bf if ragged is None else ragged
-        if bf and not ragged:
-            raise _ffi.GdrError("BertEncoderHandle(bf16): the bf16 precision mode exists in the packed (ragged) form only")
+        ragged = (bf or self.split) if ragged is None else ragged
+        if (bf or self.split) and not ragged:
+            raise _ffi.GdrError("BertEncoderHandle: the bf16 precision mode and the split form exist in the packed (ragged) form only")
         ids = input_ids.to(torch.int64).contiguous()
         B, L = ids.shape
         mask = (torch.ones_like(ids) if attention_mask is None else attention_mask.to(torch.int64)).contiguous()
@@ -632,7 +640,8 @@ class BertEncoderHandle:
         if ragged:
             need = lib().gdr_bert_encoder_ragged_workspace_bytes(C.byref(self.struct), B, L)
             ws = self.ws.get(need)
-            fn = lib().gdr_bert_encoder_forward_ragged_bf16 if bf else lib().gdr_bert_encoder_forward_ragged
+            fn = (lib().gdr_bert_encoder_forward_ragged_bf16 if bf else lib().gdr_bert_encoder_forward_ragged_split if self.split
+                  else lib().gdr_bert_encoder_forward_ragged)
             check(fn(C.byref(self.struct), ptr(ids), ptr(mask), ptr(tt), B, L, ptr(hid), ptr(pooled), int(live_rows_hint), ptr(ws),
                      ws.numel(), stream_ptr()), "gdr_bert_encoder_forward_ragged")
             return hid, pooled

@@ -403,6 +403,13 @@ int gdr_bert_encoder_forward_ragged(const GdrBertWeights* w, const int64_t* ids,
 int gdr_bert_encoder_forward_ragged_bf16(const GdrBertWeights* w, const int64_t* ids, const int64_t* mask,
                                          const int64_t* token_type_ids, int B, int L, float* out_hidden, float* out_pooled,
                                          int64_t live_rows_hint, void* workspace, size_t workspace_bytes, void* stream);
+/* EXPLORATORY (r06), beside gdr_bert_encoder_forward_ragged: every linear in the fp16 x 2 split form of gdr_linear_split_bf16 (terms = 2:
+ * fp32 operands carried as [fp16 hi | fp16 (x - hi) * 2^11], fp32-level error on the fp16 MFMA path); embeddings, LayerNorm, attention,
+ * GeLU and the residual stream are the fp32 path's.  The linear weight pointers of `w` point to fp16 plane rows [N, 2 K]
+ * (gdr_split_f32_f16x2); biases stay fp32.  Needs head width 64 and d_model, d_ff multiples of 128.  Same workspace size. */
+int gdr_bert_encoder_forward_ragged_split(const GdrBertWeights* w, const int64_t* ids, const int64_t* mask,
+                                          const int64_t* token_type_ids, int B, int L, float* out_hidden, float* out_pooled,
+                                          int64_t live_rows_hint, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Docid beam decode — replaces `_generate_beam_search` (transformers/generation_utils.py:629-921, with

@@ -256,6 +256,32 @@ def test_doc_tower_ragged_form_is_bit_identical_to_the_padded_form(dev):
         np.testing.assert_allclose(pooled.cpu().numpy(), g[name + "_pooled"], rtol=tol, atol=tol)
 
 
+def test_doc_tower_split_form_keeps_fp32_level_embeddings(dev):
+    """gdr_bert_encoder_forward_ragged_split (r06, exploratory): the doc tower's linears in the fp16 x 2 split form (22 bits carried, fp32
+    accumulate).  bert-base: 8 short passages (the 64-row tiles, separate split launches) and 96 passages of 32-128 tokens (the 256-row
+    tiles, the GeLU epilogue's plane output): pooled embeddings within 5e-5 of the fp32 ragged form's and of the CPU oracle's at the fp32
+    tolerance; PAD rows of the hidden states zero."""
+    from gdr_amd.modeling import EncoderModel
+    from oracle import bert_ref
+    bc = synth.bert_config(False)
+    sd = synth.make_bert_state_dict(bc, seed=77)
+    e32 = EncoderModel.from_state_dict(bc, sd, dev, ragged=True)
+    esp = EncoderModel.from_state_dict(bc, sd, dev, split=True)
+    for n, seed in ((8, 10), (96, 12)):
+        ids_n, mask_n = synth.make_tokens(n, L=128, vocab_hi=bc["vocab_size"], seed=seed, min_len=32)
+        ids, mask = torch.from_numpy(ids_n).to(dev), torch.from_numpy(mask_n).to(dev)
+        p32 = e32(passage={"input_ids": ids, "attention_mask": mask})
+        psp = esp(passage={"input_ids": ids, "attention_mask": mask})
+        hsp, psp2 = esp.bert.forward(ids, mask)
+        diff = float((psp - p32).abs().max())
+        print(f"fp16 x 2 doc tower, {n} passages: max |pooled - fp32 pooled| = {diff:.2e}")
+        assert diff <= 5e-5 and float((psp2 - psp).abs().max()) <= 1e-5
+        assert int((hsp[torch.from_numpy(mask_n == 0).to(dev)] != 0).sum()) == 0
+        if n == 8:
+            _, ref = bert_ref.bert_forward(sd, bc, torch.from_numpy(ids_n), torch.from_numpy(mask_n))
+            np.testing.assert_allclose(psp.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4)
+
+
 def test_doc_tower_bf16_mode_vs_oracle_emulation(dev):
     """gdr_bert_encoder_forward_ragged_bf16 (r06; config C5 keeps its corpus in bf16, the reference has no bf16 mode — parity is against the
     build's own statement of the rounding points, oracle/bert_ref.bert_forward(bf16=True): "parity unpinned", tolerances measured and
