@@ -134,6 +134,28 @@ bw = _ffi.GdrBertWeights(30522, 768, 12, 3072, 1, 512, 2, 1e-12, FAKE.value, FAK
 bneed = l.gdr_bert_encoder_workspace_bytes(C.byref(bw), 2, 16)
 assert E(l.gdr_bert_encoder_forward(C.byref(bw), FAKE, FAKE, None, 2, 16, FAKE, FAKE, FAKE, bneed, None))
 assert E(l.gdr_bert_encoder_forward(C.byref(bw), FAKE, FAKE, None, 2, 16, FAKE, FAKE, FAKE, 8, None))
+# r06: the doc tower's ragged / bf16 / split forms, the split linears and encoder, the tile-form query
+rneed = l.gdr_bert_encoder_ragged_workspace_bytes(C.byref(bw), 2, 16)
+assert rneed > bneed and l.gdr_bert_encoder_ragged_workspace_bytes(C.byref(bw), 0, 16) == 0
+for fn in (l.gdr_bert_encoder_forward_ragged, l.gdr_bert_encoder_forward_ragged_bf16, l.gdr_bert_encoder_forward_ragged_split):
+    assert E(fn(C.byref(bw), FAKE, FAKE, None, 2, 16, FAKE, FAKE, -1, FAKE, 8, None))                     # ENOSPC
+    assert E(fn(C.byref(bw), FAKE, None, None, 2, 16, FAKE, FAKE, -1, FAKE, rneed, None))                  # null mask
+    assert E(fn(C.byref(bw), FAKE, FAKE, None, 2, 16, FAKE, FAKE, -1, FAKE, rneed, None))                  # EHIP (first launch) or EINVAL
+assert l.gdr_split_row_elems(768, 6) == 2304 and l.gdr_split_row_elems(768, 2) == 1536 and l.gdr_split_row_elems(100, 6) == 320
+assert l.gdr_split_row_elems(0, 6) == 0
+assert E(l.gdr_split_f32_bf16x3(None, None, 4, 768, 2304, None)) and E(l.gdr_split_f32_bf16x3(FAKE, FAKE, 4, 768, 100, None))   # ld_out < 3 K
+assert E(l.gdr_split_f32_f16x2(FAKE, FAKE, 4, 768, 1000, None))                                                               # ld_out < 2 K
+assert E(l.gdr_linear_split_bf16(FAKE, 2304, FAKE, 2304, FAKE, 768, 4, 768, 768, 5, 0, None, None, 0, None))   # terms
+assert E(l.gdr_linear_split_bf16(FAKE, 1000, FAKE, 2304, FAKE, 768, 4, 768, 768, 6, 0, None, None, 0, None))   # lda < 3 K
+assert E(l.gdr_linear_split_bf16(FAKE, 2304, FAKE, 2304, FAKE, 768, 4, 768, 768, 6, 3, None, None, 0, None))   # bias epilogue, no bias
+assert E(l.gdr_linear_split_bf16(FAKE, 192, FAKE, 192, FAKE, 768, 4, 768, 96, 2, 0, None, None, 0, None))      # fp16 x 2 needs K % 128 == 0
+sneed = l.gdr_t5_encoder_split_workspace_bytes(C.byref(dims), 8, 16)
+assert sneed > need and l.gdr_t5_encoder_split_workspace_bytes(C.byref(dims), 0, 16) == 0
+assert E(l.gdr_t5_encoder_forward_ragged_split(C.byref(ew), FAKE, FAKE, 8, 16, FAKE, None, -1, 5, FAKE, sneed, None))    # terms
+assert E(l.gdr_t5_encoder_forward_ragged_split(C.byref(ew), FAKE, FAKE, 8, 16, FAKE, None, -1, 2, FAKE, 64, None))       # ENOSPC
+assert E(l.gdr_t5_encoder_forward_ragged_split(C.byref(ew), FAKE, FAKE, 8, 16, FAKE, None, -1, 2, FAKE, sneed, None))    # EHIP
+assert l.gdr_linear_bf16_tile_form(20480, 768, 3072, 0) == 256 and l.gdr_linear_bf16_tile_form(100, 768, 768, 0) == 64
+assert l.gdr_linear_bf16_tile_form(100, 768, 100, 0) == 0
 assert l.gdr_prof_enable(8) in (0, _ffi.GDR_EHIP, _ffi.GDR_EINVAL)
 n_, ms_, w_ = (C.c_int64 * 8)(), (C.c_double * 8)(), (C.c_double * 8)()
 l.gdr_prof_collect(n_, ms_, w_)
