@@ -22,7 +22,7 @@ def timed(fn, n=20):
 
 rows = []
 ws = torch.empty(48 << 20, dtype=torch.uint8, device=dev)   # split-K / stream-K scratch, as the encoder's linears have it
-for M in (20480, 12308):
+for M in (20480, 15360, 12308):
     for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
         A = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) * 0.03
