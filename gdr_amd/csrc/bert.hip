@@ -195,7 +195,9 @@ static BertRagWs bert_rag_ws(const GdrBertWeights& w, int B, int L) {
   r.t_cls = o, o += align_up((size_t)B * d * 4, 256);
   r.ff_cls = o, o += align_up((size_t)B * w.d_ff * 4, 256);
   r.x16 = o, o += align_up(M * 2 * d * 2, 256);  // bf16 mode: the bf16 image of the block input x; fp16 x 2 form: its plane rows [M, 2 d]
-  r.pl_ff = o, o += align_up(M * 2 * (size_t)w.d_ff * 2, 256);  // fp16 x 2 form: the plane rows of the GeLU output [M, 2 d_ff]
+  // fp16 x 2 form: the plane rows of the GeLU output [M, 2 d_ff] — from 8 192 rows on the wi GEMM's epilogue writes them and the fp32 `ff`
+  // buffer (the same size) is free to hold them; below that both exist
+  r.pl_ff = o, o += align_up((M < 8192 ? M : 0) * 2 * (size_t)w.d_ff * 2, 256);
   r.total = o;
   return r;
 }
@@ -259,7 +261,7 @@ static int bert_ragged_impl(const GdrBertWeights* w, const int64_t* ids, const i
   hipLaunchKernelGGL(bert_embed_packed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, w->word_emb, w->pos_emb, w->type_emb,
                      ids, token_type_ids, row_src, rows_dev, L, d / 4, w->vocab_size, w->type_vocab, t);
   GDR_CHECK_LAUNCH("bert_embed_packed_kernel");
-  void* pl_ff = base + rw.pl_ff;
+  void* pl_ff = M < 8192 ? static_cast<void*>(base + rw.pl_ff) : static_cast<void*>(ff);
   const int ld_d = 2 * d, ld_ff = 2 * dff;  // fp16 x 2 plane rows
   if ((rc = launch_layernorm_dev(t, w->emb_ln_w, w->emb_ln_b, x, rows_dev, M, d, w->eps, nullptr, stream, (bf16 || f16s) ? x16 : nullptr,
                                  f16s ? ld_d : 0)))

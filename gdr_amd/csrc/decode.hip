@@ -1095,6 +1095,18 @@ static const float* w_at(const float* W, size_t elems, bool bf16) {
   return reinterpret_cast<const float*>(reinterpret_cast<const char*>(W) + elems * (bf16 ? 2 : 4));
 }
 
+// GDR_DECODE_FUSED, read once: bit mask 1 self-attention, 2 cross-attention, 4 feed-forward sub-block fused (decode_fused.hip).
+// OFF by default: measured slower than the per-phase launches at every decode shape (profiles/r06_fused_decode_ab.txt: 64 x 10 beams
+// 11.97 -> 14.55 ms, 1 x 100 6.48 -> 7.54 with all three on; the self-attention form alone is neutral at 640 rows).  Kept exact and
+// tested (test_gpu_decode_knobs.py).  The slab scratch is only part of the workspace when the knob is on.
+static int decode_fused_mask() {
+  static const int mask = [] {
+    const char* e = getenv("GDR_DECODE_FUSED");
+    return e ? atoi(e) : 0;
+  }();
+  return mask;
+}
+
 // ------------------------------------------------------------------------------------------ model workspace
 struct GenWs {
   size_t beam, dcache, acache, crosskv, xd, xa, nx, ctx, qc, ff, tmp, A, hl, splitk, ctx2, ff2, splitk2, qkv_c, abf, abf2, img1, img2, c16a, c16b, f16a, f16b, fslab, total;
@@ -1135,7 +1147,7 @@ static GenWs gen_ws(const GdrT5DecoderWeights& w, const BeamDims& bd, int L) {
   g.f16a = carve(o, 2 * rows * ffw);                       // the linear behind them, which then needs no cast launch
   g.f16b = carve(o, 2 * rows * (size_t)w.adaptor_ff);
   // fused sub-blocks (decode_fused.hip, <= 1 024 rows): the partial slabs of one sub-block, per chain
-  const bool fused = decode_fused_rt((int64_t)rows, (int)d, (int)inner, dm.d_kv) != 0;
+  const bool fused = decode_fused_mask() != 0 && decode_fused_rt((int64_t)rows, (int)d, (int)inner, dm.d_kv) != 0;
   g.fslab = carve(o, fused ? decode_fused_slab_bytes((int64_t)rows, (int)d, dm.d_ff, dm.num_heads) : 0);
   g.total = o;
   return g;
@@ -1311,12 +1323,7 @@ static int generate_impl(const GdrT5DecoderWeights* w, const float* enc_hidden, 
                                 2 * inner, d, GDR_EPI_NONE, nullptr, nullptr, 0));
   }
 
-  static const int fused_mask = [] {
-    const char* e = getenv("GDR_DECODE_FUSED");  // bit mask: 1 self-attention, 2 cross-attention, 4 feed-forward sub-block fused (decode_fused.hip).
-    return e ? atoi(e) : 0;                      // OFF by default: measured slower than the per-phase launches at every decode shape
-                                                 // (profiles/r06_fused_decode_ab.txt: 64 x 10 beams 11.97 -> 14.55 ms, 1 x 100 6.48 -> 7.54 with all three
-                                                 // on; the self-attention form alone is neutral at 640 rows).  Kept exact, tested (test_gpu_decode_knobs.py)
-  }();
+  static const int fused_mask = decode_fused_mask();
   static const bool slab_q_on = [] {
     const char* e = getenv("GDR_DECODE_SLAB_Q");  // A/B knob: 0 = reduce the cross-attention q projection in its own launch
     return e ? atoi(e) != 0 : true;
