@@ -140,6 +140,12 @@ def parse():
                     help="ragged (default): PAD token rows are not computed and only the CLS rows go through the last "
                          "block (exact: pooled output bit-identical to the padded form); padded: every one of the "
                          "batch x 40 rows through all 48 linears, as the reference does")
+    ap.add_argument("--encoder-form", choices=["f32", "f16x2", "bf16x3", "bf16x3-16"], default="f32",
+                    help="c2, --dtype f32 only.  f32 (default, the headline): strict-fp32 MFMA linears.  EXPLORATORY forms beside it (r06): the "
+                         "encoder's fp32 linears carried through 16-bit MFMAs as planes, fp32 accumulate — f16x2: fp16 hi + fp16 (x - hi) * 2^11, "
+                         "22 bits, three blocks (GEMM error against float64 below the fp32 MFMA kernel's); bf16x3: 24 bits, six blocks; "
+                         "bf16x3-16: the first three bf16 blocks, 16 bits (narrower than fp32).  The line says so: workload tag, dtype, and the "
+                         "roofline prices the 16-bit MFMA work against the bf16 matrix peak")
     ap.add_argument("--replicated-merge", action="store_true",
                     help="N > 1: all-gather the per-shard lists and merge all queries on every rank (instead of the "
                          "all-to-all that hands each rank the lists of its own queries)")
@@ -920,7 +926,10 @@ def main():
     cfg = GDRConfig.base()
     sd = synth.make_state_dict(cfg, seed=1234, with_decoder=False)
     bf16 = a.dtype == "bf16"
-    enc = ops.T5EncoderHandle(cfg, sd, dev, dtype=torch.bfloat16 if bf16 else torch.float32)
+    form_terms = {"f32": 0, "f16x2": 2, "bf16x3": 6, "bf16x3-16": 3}[a.encoder_form]
+    if form_terms and (bf16 or a.encoder != "ragged"):
+        raise SystemExit("bench: --encoder-form is a form of the fp32 ragged encoder (--dtype f32, --encoder ragged)")
+    enc = ops.T5EncoderHandle(cfg, sd, dev, dtype=torch.bfloat16 if bf16 else torch.float32, split=form_terms)
     lo, hi = shard_bounds(a.corpus, world, rank, cluster_size=12)
     t_c = time.perf_counter()
     D = synth.make_corpus(a.corpus, cfg.d_model, rows=(lo, hi) if world > 1 else None)   # N > 1: this rank's rows only (bit-identical
@@ -1012,7 +1021,7 @@ def main():
     # ---- the same step with the PADDED encoder (every one of the batch x 40 token rows through all 48 linears, as the reference
     # computes it): the reference-equivalent-work number beside the headline's exact work elimination; same protocol, own roofline
     padded = None
-    if world == 1 and not bf16 and ragged and not a.no_stages:
+    if world == 1 and not bf16 and ragged and not a.no_stages and not form_terms:
         def step_pad():
             _, pooled = enc.forward(ids, mask, want_hidden=False, ragged=False)
             return index.search(pooled, a.k, return_status=True)
@@ -1039,7 +1048,7 @@ def main():
     # split-bf16 form (gdr_t5_encoder_forward_ragged_split: fp32 operands carried as three bf16 planes, six bf16 MFMA products, fp32
     # accumulate — the fp32 linear's error against float64, not its bits).  Its top-k lists are held to the fp32 step's by the top-k rule.
     split = None
-    if world == 1 and not bf16 and ragged and not a.no_stages:
+    if world == 1 and not bf16 and ragged and not a.no_stages and not form_terms:
         _, p_f = enc.forward(ids, mask, want_hidden=False, ragged=True, live_rows_hint=live_rows)
         out_f = index.search(p_f, a.k, return_status=True)
         split = {}
@@ -1108,13 +1117,18 @@ def main():
                     traffic_stale = tj.get("gemm_f32_sha16") != hashlib.sha256(f.read()).hexdigest()[:16]
             except Exception:
                 traffic, traffic_stale = None, None
-        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else F32_MFMA_PEAK_TFLOPS
+        peak = BF16_MFMA_PEAK_TFLOPS if (bf16 or form_terms) else F32_MFMA_PEAK_TFLOPS
+        if form_terms:      # the 16-bit MFMA work really executed: (3 or 6 blocks) x the fp32-equivalent flops the profiler prices
+            blocks = 3 if form_terms == 2 else form_terms
+            lin["tflops"] *= blocks
+            lin["gflop_per_launch"] *= blocks
         result = {
             "metric": "queries/sec on NQ-320k (768-d)", "value": total_q / dt, "unit": "queries/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype if not form_terms else a.encoder_form, "data": "synthetic",
             "config": {"workload": ("C2" if world == 1 else "C4-layout") + ("/ragged" if ragged else "/padded") + ("/bf16" if bf16 else "") +
-                       ("/prefilter" if use_pre else "") +
+                       ("/prefilter" if use_pre else "") + (f"/{a.encoder_form}-linears(exploratory)" if form_terms else "") +
                        f": t5-base encoder {a.batch} q/GPU + Q.D^T top-{a.k}, {a.corpus}x{cfg.d_model} corpus",
                        "dist_backend": a.backend if dist.is_initialized() else None,
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": 40,
@@ -1123,11 +1137,12 @@ def main():
                        "corpus_setup_s": round(t_corpus, 2), "corpus_rows_on_host": int(D.shape[0])},
             "roofline": {"bound": "mfma",
                          "kernel": ("gdr::gemm_nt_bf16 (glds / persist256): every encoder linear" if bf16 else
+                                    "gdr::gemm_nt_bf16_tile256_kernel<BN, split>: every encoder linear as 16-bit plane blocks" if form_terms else
                                     "gdr::gemm_nt_f32_persistent_kernel / gemm_nt_f32_streamk_kernel: every encoder linear"),
                          "achieved": lin["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": lin["tflops"] / peak,
-                         "traffic": None if bf16 else traffic,
-                         "traffic_source": None if (bf16 or traffic is None) else "static: profiles/traffic.json (rocprofv3 --pmc passes of this command)",
-                         "traffic_stale": None if (bf16 or traffic is None) else bool(traffic_stale),
+                         "traffic": None if (bf16 or form_terms) else traffic,
+                         "traffic_source": None if (bf16 or form_terms or traffic is None) else "static: profiles/traffic.json (rocprofv3 --pmc passes of this command)",
+                         "traffic_stale": None if (bf16 or form_terms or traffic is None) else bool(traffic_stale),
                          "launches": lin["launches"], "timed_steps": n_prof_steps, "avg_launch_ms": lin["avg_ms"],
                          "algorithmic_gflop_per_launch": lin["gflop_per_launch"], "share_of_step": lin["share_of_step"]},
         }
@@ -1189,7 +1204,7 @@ def main():
                     raise SystemExit(f"bench: {bad} rows differ from the CPU oracle outside tolerance-tie groups")
             result["cpu_baseline"] = cpu_baseline(sd, cfg, ids_all, mask_all, D, a.k)
         result["stages_summary"] = None
-        if world == 1 and not a.no_stages and not bf16:
+        if world == 1 and not a.no_stages and not bf16 and not form_terms:
             del enc
             if pre is not None:
                 del P, index_p

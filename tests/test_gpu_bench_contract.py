@@ -139,6 +139,15 @@ def test_bench_all_fp32_similarity_form_is_still_a_headline_option():
     assert j["stages_summary"]["c5_qps"] is None
 
 
+def test_bench_exploratory_encoder_form_is_labelled_as_such():
+    """--encoder-form f16x2: the exploratory line (fp32 linears carried as fp16 x 2 planes) names itself in the workload tag and in dtype,
+    prices its roofline against the 16-bit matrix peak, and keeps the recall parity with the CPU oracle (the similarity is the headline's)."""
+    j = _run("--encoder-form", "f16x2", "--no-stages")
+    assert j["dtype"] == "f16x2" and "f16x2-linears(exploratory)" in j["config"]["workload"] and len(j["config"]["workload"]) <= 140
+    assert j["roofline"]["peak"] == 2500.0 and 0 < j["roofline"]["frac"] < 1 and j["roofline"]["traffic"] is None
+    assert j["recall"]["gpu"] == j["recall"]["cpu_oracle"] and j["recall"]["rows_violating_tie_rule"] == 0 and j["stages_summary"] is None
+
+
 def test_bench_padded_encoder_form_gives_the_same_recall():
     a, b = _run("--encoder", "padded", "--no-stages", "--prof-every", "1"), _run("--no-stages")
     assert a["roofline"]["timed_steps"] == 2 and a["roofline"]["launches"] == 96          # --prof-every 1: every step carries the events

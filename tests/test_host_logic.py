@@ -184,6 +184,26 @@ def test_reference_model_variants_the_kernels_do_not_implement_fail_loudly(flag,
     assert unsupported_variant(gmain.parsers_parser(["--mode", "eval"])) is None
 
 
+def test_synthetic_corpus_shard_is_bit_identical_to_the_slice_of_the_whole():
+    """r06: an N-GPU rank materialises only its own rows of the synthetic corpus (synth.make_corpus(rows=), bench.py / main.py): the
+    shard must be the slice of the whole corpus BIT FOR BIT — every chunk geometry (shard inside one chunk, spanning chunks, starting /
+    ending on a chunk edge, empty, the whole) — and make_gold must reproduce make_queries' gold ids without the corpus."""
+    from gdr_amd import synth
+    from gdr_amd.dist import shard_bounds
+    N, d, chunk = 5000, 32, 1024
+    whole = synth.make_corpus(N, d, chunk=chunk)
+    for lo, hi in ((0, N), (0, 700), (100, 900), (1000, 2100), (1024, 2048), (3000, 5000), (4999, 5000), (2500, 2500)):
+        part = synth.make_corpus(N, d, chunk=chunk, rows=(lo, hi))
+        assert part.shape == (hi - lo, d) and np.array_equal(part, whole[lo:hi]), (lo, hi)
+    for world in (2, 3, 8):
+        parts = [synth.make_corpus(N, d, chunk=chunk, rows=shard_bounds(N, world, r, cluster_size=12)) for r in range(world)]
+        assert np.array_equal(np.concatenate(parts), whole)
+    with pytest.raises(ValueError):
+        synth.make_corpus(N, d, rows=(10, N + 1))
+    _, gold = synth.make_queries(whole, 77)
+    assert np.array_equal(gold, synth.make_gold(N, 77))
+
+
 def _gloo_worker(rank, world, port, tmp):
     import os
     import numpy as np
