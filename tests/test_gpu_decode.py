@@ -280,6 +280,12 @@ def test_doc_tower_split_form_keeps_fp32_level_embeddings(dev):
         if n == 8:
             _, ref = bert_ref.bert_forward(sd, bc, torch.from_numpy(ids_n), torch.from_numpy(mask_n))
             np.testing.assert_allclose(psp.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4)
+    # the tiny shape of the g10 golden (hidden 128, 2 heads of 64, d_ff 256: two K-tiles per block) through the split form
+    g = golden("g10_doc_tower")
+    bct = synth.bert_config(True)
+    et = EncoderModel.from_state_dict(bct, synth.make_bert_state_dict(bct, seed=int(g["seed"])), dev, split=True)
+    pt = et(passage={"input_ids": torch.from_numpy(g["tiny_ids"]).to(dev), "attention_mask": torch.from_numpy(g["tiny_mask"]).to(dev)})
+    np.testing.assert_allclose(pt.cpu().numpy(), g["tiny_pooled"], rtol=1e-4, atol=1e-4)
 
 
 def test_doc_tower_bf16_mode_vs_oracle_emulation(dev):
